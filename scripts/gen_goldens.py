@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by IMPORTING the reference's own Python (build container
+only - /root/reference does not exist on the GPU box).  Output: small .npz fixtures under
+tests/golden/ (data only: seeded weights + inputs + the reference's outputs).
+
+Reference pieces exercised (importable on CPU with inert stubs for packages that are only
+imported, never called, on these code paths - SURVEY.md section 8(c)):
+  crowd_ppo/utils.py::calc_sdf                                   -> calc_sdf_ref.npz
+  models/models_GAMMA_primitive.py::GAMMAPrimitiveVAE.decode     -> cvae_ref.npz
+  models/models_GAMMA_primitive.py::MoshRegressor._forward, RotConverter.cont2rotmat -> regressor_ref.npz
+  models/models_policy_ppo.py::{GAMMAPolicyBase,GAMMAActor,GAMMACritic} -> policy_ref.npz
+  models/baseops.py::CanonicalCoordinateExtractor.get_new_coordinate_torch -> canon_ref.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/motion"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+    _stub("torchgeometry")
+    _stub("tensorboardX", SummaryWriter=_Dummy)
+    _stub("smplx")
+    tv = _stub("torchvision")
+    tv.models = _stub("torchvision.models")
+    tv.transforms = _stub("torchvision.transforms")
+    try:
+        import matplotlib  # noqa
+    except Exception:
+        mp = _stub("matplotlib")
+        mp.pyplot = _stub("matplotlib.pyplot")
+
+
+def sd_to_np(sd, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def fill_module(mod, seed, gain=1.0):
+    """Overwrite every tensor of `mod` with egogen_amd.synth.seeded_fill values (so the fixture only
+    needs the seed, not the weights).  Returns the name->shape dict the tests rebuild from."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from egogen_amd.synth import seeded_fill
+    sd = mod.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    vals = seeded_fill(shapes, seed, gain=gain)
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+    return shapes
+
+
+def main():
+    install_stubs()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+
+    # ---- calc_sdf -------------------------------------------------------------------------
+    from crowd_ppo.utils import calc_sdf
+    out = {}
+    g = torch.Generator().manual_seed(0)
+    for tag, D in (("a", 8), ("b", 16), ("c", 33)):
+        sdf = torch.randn(D, D, D, generator=g)
+        center = torch.tensor([0.3, -0.2, 1.0])
+        scale = torch.tensor(0.25)
+        pts = torch.cat([
+            (torch.rand(2, 200, 3, generator=g) * 2 - 1) / scale + center,          # inside
+            (torch.rand(2, 60, 3, generator=g) * 2 - 1) * 1.6 / scale + center,     # some outside -> border clamp
+        ], dim=1)
+        # exact faces / corners of the cube
+        corners = torch.tensor([[sx, sy, sz] for sx in (-1., 1.) for sy in (-1., 0., 1.) for sz in (-1., 1.)]) / scale + center
+        pts = torch.cat([pts, corners.unsqueeze(0).repeat(2, 1, 1)], dim=1)
+        val = calc_sdf(pts, {"center": center, "scale": scale, "sdf": sdf})
+        out[f"{tag}_sdf"], out[f"{tag}_center"], out[f"{tag}_scale"] = sdf.numpy(), center.numpy(), scale.numpy()
+        out[f"{tag}_pts"], out[f"{tag}_val"] = pts.numpy(), val.numpy()
+    np.savez_compressed(os.path.join(OUT, "calc_sdf_ref.npz"), **out)
+    print("calc_sdf_ref", {k: v.shape for k, v in out.items() if k.endswith("val")})
+
+    # ---- C-VAE decode ---------------------------------------------------------------------
+    from models.models_GAMMA_primitive import GAMMAPrimitiveVAE, MoshRegressor
+    from models.baseops import RotConverter, CanonicalCoordinateExtractor
+    torch.manual_seed(0)
+    vae = GAMMAPrimitiveVAE({"body_repr": "ssm2_67", "h_dim": 256, "z_dim": 128, "t_his": 2, "t_pred": 18,
+                             "use_drnn_mlp": True, "hdims_mlp": [512, 256], "residual": True}).eval()
+    nparam = sum(p.numel() for p in vae.parameters())
+    vae_shapes = fill_module(vae, seed=100)
+    b = 5
+    X = torch.randn(2, b, 201, generator=g) * 0.5
+    z = torch.randn(b, 128, generator=g)
+    with torch.no_grad():
+        Y = vae.sample_prior(X, z)
+    out = {"fill_seed": np.int64(100), "state_dict_keys": np.array(list(vae_shapes.keys())),
+           "state_dict_shapes": np.array([str(v) for v in vae_shapes.values()]), "X": X.numpy(), "z": z.numpy(), "Y": Y.numpy()}
+    np.savez_compressed(os.path.join(OUT, "cvae_ref.npz"), **out)
+    print("cvae_ref", Y.shape, nparam)
+
+    # ---- regressor (6-D output) + cont2rotmat ---------------------------------------------
+    torch.manual_seed(1)
+    reg = MoshRegressor({"body_repr": "ssm2_67", "h_dim": 128, "n_blocks": 10, "n_recur": 3,
+                         "actfun": "relu", "use_cont": True}).eval()
+    reg_shapes = fill_module(reg, seed=101, gain=0.6)
+    n = 7
+    mk = torch.randn(n, 201, generator=g) * 0.5
+    betas = torch.randn(n, 10, generator=g)
+    with torch.no_grad():
+        xb6 = reg._forward(mk, torch.zeros(n, 3), torch.zeros(n, 6), torch.zeros(n, 126),
+                           torch.zeros(n, 12), torch.zeros(n, 12), betas)
+        rotm = RotConverter.cont2rotmat(xb6[:, 3:3 + 132].contiguous().view(n, -1, 6))
+    out = {"fill_seed": np.int64(101), "fill_gain": np.float64(0.6), "state_dict_keys": np.array(list(reg_shapes.keys())),
+           "state_dict_shapes": np.array([str(v) for v in reg_shapes.values()]), "markers": mk.numpy(), "betas": betas.numpy(), "xb6": xb6.numpy(), "rotmat": rotm.numpy()}
+    np.savez_compressed(os.path.join(OUT, "regressor_ref.npz"), **out)
+    print("regressor_ref", xb6.shape, rotm.shape, sum(p.numel() for p in reg.parameters()))
+
+    # ---- canonical frame --------------------------------------------------------------------
+    jts = torch.randn(6, 22, 3, generator=g)
+    ext = CanonicalCoordinateExtractor(torch.device("cpu"))
+    R, T = ext.get_new_coordinate_torch(jts.clone())
+    np.savez_compressed(os.path.join(OUT, "canon_ref.npz"), jts=jts.numpy(), R=R.numpy(), T=T.numpy())
+    print("canon_ref", R.shape, T.shape)
+
+    # ---- policy ---------------------------------------------------------------------------------
+    from models.models_policy_ppo import GAMMAPolicyBase, GAMMAActor, GAMMACritic
+    cfg = {"h_dim": 512, "z_dim": 128, "n_blocks": 2, "n_recur": -1, "body_repr": "ssm2_67_condi_marker_map",
+           "actfun": "lrelu", "is_stochastic": True, "min_logvar": -2.5, "max_logvar": 2.5}
+    torch.manual_seed(2)
+    actor, critic, base = GAMMAActor(cfg).eval(), GAMMACritic(cfg).eval(), GAMMAPolicyBase(cfg).eval()
+    fill_module(base, seed=102)
+    fill_module(actor, seed=103, gain=1.4)
+    fill_module(critic, seed=104, gain=1.4)
+    key_shapes = {}
+    for pre, mod in (("shared_net.", base), ("actor.", actor), ("critic.", critic)):
+        for k, v in mod.state_dict().items():
+            key_shapes[pre + k] = tuple(v.shape)
+    nb = 6
+    obs = {"state": torch.randn(nb, 2, 402, generator=g) * 0.5, "egosensing": torch.rand(nb, 2, 32, generator=g) * 2 - 1,
+           "dist": torch.rand(nb, generator=g), "time": torch.rand(nb, 1, generator=g)}
+    with torch.no_grad():
+        hx = base(obs)
+        (mu, logvar), _ = actor(hx)
+        val = critic(hx)
+    out = {"fill_seeds": np.array([102, 103, 104], np.int64),
+           "state_dict_keys": np.array(list(key_shapes.keys())),
+           "state_dict_shapes": np.array([str(v) for v in key_shapes.values()])}
+    out.update({"obs_" + k: v.numpy() for k, v in obs.items()})
+    out.update({"hx": hx.numpy(), "mu": mu.numpy(), "logvar": logvar.numpy(), "value": val.numpy()})
+    np.savez_compressed(os.path.join(OUT, "policy_ref.npz"), **out)
+    n_pol = sum(p.numel() for m in (actor, critic, base) for p in m.parameters())
+    print("policy_ref", hx.shape, mu.shape, val.shape, n_pol, "state_dict keys",
+          len(base.state_dict()) + len(actor.state_dict()) + len(critic.state_dict()))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

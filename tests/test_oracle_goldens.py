@@ -1,0 +1,63 @@
+"""Pin the CPU oracle against vectors produced by the reference's own code
+(scripts/gen_goldens.py imported the reference classes in the build container)."""
+import numpy as np
+import torch
+
+from oracle import nets, rot, sdf
+from tests.helpers import load_golden, max_abs, rebuild_state_dict
+
+
+def test_calc_sdf_matches_reference():
+    g = load_golden("calc_sdf_ref.npz")
+    for tag in "abc":
+        d = {"sdf": torch.from_numpy(g[f"{tag}_sdf"]), "center": torch.from_numpy(g[f"{tag}_center"]),
+             "scale": torch.from_numpy(g[f"{tag}_scale"])}
+        out = sdf.calc_sdf(torch.from_numpy(g[f"{tag}_pts"]), d).numpy()
+        assert out.shape == g[f"{tag}_val"].shape
+        assert max_abs(out, g[f"{tag}_val"]) < 2e-6, tag
+
+
+def test_cvae_decode_matches_reference():
+    g = load_golden("cvae_ref.npz")
+    sd = rebuild_state_dict(g, [g["fill_seed"]], [""])
+    sd = {"predictor." + k: v for k, v in sd.items()}
+    Y = nets.cvae_decode(sd, torch.from_numpy(g["X"]), torch.from_numpy(g["z"])).numpy()
+    assert Y.shape == (18, 5, 201)
+    assert max_abs(Y, g["Y"]) < 2e-5
+
+
+def test_regressor_6d_and_cont2rotmat_match_reference():
+    g = load_golden("regressor_ref.npz")
+    sd = rebuild_state_dict(g, [g["fill_seed"]], [""], gains=[float(g["fill_gain"])])
+    sd = {"regressor." + k: v for k, v in sd.items()}
+    xb6 = nets.regressor_6d(sd, torch.from_numpy(g["markers"]), torch.from_numpy(g["betas"]))
+    assert max_abs(xb6.numpy(), g["xb6"]) < 2e-5 * max(1.0, np.abs(g["xb6"]).max())
+    R = rot.cont2rotmat(torch.from_numpy(g["xb6"])[:, 3:135].contiguous().view(7, -1, 6)).numpy()
+    assert max_abs(R, g["rotmat"]) < 1e-6
+    # full forward: 6D -> axis-angle through the restated tgm path must reproduce the rotation
+    xb = nets.regressor_forward(sd, torch.from_numpy(g["markers"]), torch.from_numpy(g["betas"]))
+    assert xb.shape == (7, 93)
+    Rback = rot.tgm_angle_axis_to_rotation_matrix(xb[:, 3:69].reshape(-1, 3)).numpy()
+    assert max_abs(Rback, g["rotmat"]) < 5e-5
+
+
+def test_policy_matches_reference():
+    g = load_golden("policy_ref.npz")
+    sd = rebuild_state_dict(g, g["fill_seeds"], ["shared_net.", "actor.", "critic."], gains=[1.0, 1.4, 1.4])
+    assert len(sd) == 28
+    obs = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("obs_")}
+    hx = nets.policy_base(sd, obs)
+    mu, logvar = nets.policy_actor(sd, hx)
+    val = nets.policy_critic(sd, hx)
+    assert max_abs(hx.numpy(), g["hx"]) < 2e-5
+    assert max_abs(mu.numpy(), g["mu"]) < 1e-4 * max(1.0, np.abs(g["mu"]).max())
+    assert max_abs(logvar.numpy(), g["logvar"]) < 1e-4 * max(1.0, np.abs(g["logvar"]).max())
+    assert max_abs(val.numpy(), g["value"]) < 1e-4 * max(1.0, np.abs(g["value"]).max())
+
+
+def test_canonical_frame_matches_reference():
+    from oracle import env as oenv
+    g = load_golden("canon_ref.npz")
+    R, T = oenv.get_new_coordinate(torch.from_numpy(g["jts"]))
+    assert max_abs(R.numpy(), g["R"]) < 1e-6
+    assert max_abs(T.numpy(), g["T"]) == 0.0
