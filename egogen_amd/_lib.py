@@ -37,6 +37,64 @@ class SdfGrid(C.Structure):
                 ("center", C.c_float * 3), ("scale", C.c_float)]
 
 
+class LinearDesc(C.Structure):
+    _fields_ = [("num_rows", C.c_int), ("out_features", C.c_int), ("num_segments", C.c_int),
+                ("seg_ptr", C.c_void_p * 4), ("seg_width", C.c_int * 4), ("seg_ld", C.c_int * 4),
+                ("weight", C.c_void_p), ("weight_ld", C.c_int), ("bias", C.c_void_p),
+                ("residual", C.c_void_p), ("residual_ld", C.c_int),
+                ("out", C.c_void_p), ("out_ld", C.c_int), ("activation", C.c_int), ("leaky_slope", C.c_float)]
+
+
+class PriorWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x_enc_w_ih", "x_enc_w_hh", "x_enc_b_ih", "x_enc_b_hh")] + \
+               [("drnn_w", C.c_void_p * 3), ("drnn_b", C.c_void_p * 3)] + \
+               [(n, C.c_void_p) for n in ("d_rnn_w_ih", "d_rnn_w_hh", "d_rnn_b_ih", "d_rnn_b_hh")] + \
+               [("d_mlp_w", C.c_void_p * 2), ("d_mlp_b", C.c_void_p * 2), ("d_out_w", C.c_void_p), ("d_out_b", C.c_void_p),
+                ("reg_in_w", C.c_void_p), ("reg_in_b", C.c_void_p), ("reg_blk_w", C.c_void_p * 20), ("reg_blk_b", C.c_void_p * 20),
+                ("reg_out_w", C.c_void_p), ("reg_out_b", C.c_void_p)]
+
+
+class PolicyWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x_enc_w_ih", "x_enc_w_hh", "x_enc_b_ih", "x_enc_b_hh",
+                                          "ego_enc_w_ih", "ego_enc_w_hh", "ego_enc_b_ih", "ego_enc_b_hh")] + \
+               [("actor_w", C.c_void_p * 4), ("actor_b", C.c_void_p * 4), ("actor_out_w", C.c_void_p), ("actor_out_b", C.c_void_p),
+                ("critic_w", C.c_void_p * 4), ("critic_b", C.c_void_p * 4), ("critic_out_w", C.c_void_p), ("critic_out_b", C.c_void_p)]
+
+
+class VposerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mu_w", "mu_b")]
+
+
+class EnvConfig(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("reproj_factor", "goal_thresh", "pene_thres", "weight_skate", "weight_floor",
+                                         "weight_face_target", "weight_look_target", "weight_success", "weight_target_dist",
+                                         "weight_pene", "weight_vp")] + \
+               [(n, C.c_int) for n in ("max_depth", "scene_kind", "terminate_on_penetration", "pene_type_body")] + \
+               [("ray_len", C.c_float)]
+
+
+class EnvScenes(C.Structure):
+    _fields_ = [("edges", C.c_void_p), ("edge_off", C.c_void_p), ("tris", C.c_void_p), ("tri_off", C.c_void_p),
+                ("floor_height", C.c_void_p), ("map_lin", C.c_void_p), ("map_res", C.c_int)]
+
+
+class EnvState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("state", "seed", "R0", "T0", "dist", "steps", "wpath", "scene_idx")]
+
+
+class EnvStepIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("Y_gen", "pred_params", "joints", "markers_proj", "pene_count", "vp_emb",
+                                          "feet_marker_idx", "reward", "terminated", "reward_terms", "obs_ego", "obs_dist",
+                                          "obs_time", "out_marker_b", "out_prev_frame")]
+
+
+class EnvResetIO(C.Structure):
+    _fields_ = [("num_candidates", C.c_int)] + \
+               [(n, C.c_void_p) for n in ("mask", "cand_pairs", "cand_yaw", "cand_variant", "cand_scene", "cand_valid", "tab_joints",
+                                          "tab_markers", "tab_glorot", "tab_transl", "tab_pose", "obs_ego", "obs_dist",
+                                          "obs_time", "out_choice")]
+
+
 # name -> (restype, argtypes); must list every symbol of include/egogen_hip.h
 SIGNATURES = {
     "egx_last_error": (C.c_char_p, []),
@@ -50,6 +108,24 @@ SIGNATURES = {
                                   C.c_void_p, C.POINTER(SdfGrid), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "egx_sdf_sample": (C.c_int, [C.POINTER(SdfGrid), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "egx_linear": (C.c_int, [C.POINTER(LinearDesc), C.c_void_p]),
+    "egx_gru_pointwise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "egx_cont6d_to_aa": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "egx_posenc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "egx_sample_prior_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "egx_sample_prior": (C.c_int, [C.POINTER(PriorWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egx_policy_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "egx_policy_forward": (C.c_int, [C.POINTER(PolicyWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egx_assemble_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "egx_env_step_post": (C.c_int, [C.POINTER(EnvConfig), C.POINTER(EnvScenes), C.POINTER(EnvState), C.POINTER(EnvStepIO),
+                                    C.c_int, C.c_void_p]),
+    "egx_env_reset": (C.c_int, [C.POINTER(EnvConfig), C.POINTER(EnvScenes), C.POINTER(EnvState), C.POINTER(EnvResetIO),
+                                C.c_int, C.c_void_p]),
+    "egx_vposer_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "egx_vposer_encode": (C.c_int, [C.POINTER(VposerWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,376 @@
+"""Batched CrowdEnv on the GPU: host-side mirror of crowd_ppo/crowd_env_2f.py (SDF scene) and
+crowd_ppo/crowd_env_2f_box.py (random box scenes) of the reference, for A independent agents at once.
+
+One `step(actions[A,128])` enqueues, with no host synchronisation:
+    egx_sample_prior  ->  egx_assemble_params  ->  egx_lbs_forward (+SDF counts)  ->  egx_vposer_encode
+    ->  egx_env_step_post  ->  (auto-reset of finished agents: egx_env_reset)
+and can be captured once into a HIP graph (`use_graph=True`).  The reference's per-env gym API
+(reset() -> (obs, {}), step(a) -> (obs, reward, terminated, truncated, info)) is provided by `CrowdEnv`,
+a 1-agent view, for drop-in use; the vector API is what the trainer uses (the reference's DummyVectorEnv
+steps its envs one after the other, main_ppo.py:97).
+
+Observation dict (crowd_env_2f.py:49-51,311-312): state[A,2,402], egosensing[A,2,32], dist[A], time[A].
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+from .body_model import BodyModelHandle, SdfScene
+from .models import GAMMAPrimitiveCombo, VPoserEncoder
+
+DEFAULT_CFG = {  # crowd_ppo/cfg_samp20/MPVAEPolicy_samp_collision.yaml
+    "reproj_factor": 0.5, "goal_thresh": 0.1, "max_depth": 13, "pene_thres": 3,
+    "weight_vp": 0.1, "weight_floor": 0.1, "weight_skate": 0.3, "weight_target_dist": 1.0,
+    "weight_face_target": 0.1, "weight_look_target": 0.3, "weight_pene": 0.1, "weight_success": 0.5,
+    "map_res": 16, "map_extent": 0.8, "pene_type": "body", "ray_len": 7.0,
+}
+BOX_CFG = dict(DEFAULT_CFG, weight_look_target=0.1, max_depth=11)  # ..._collision_2.yaml (primitive_model.py:77-78)
+
+
+def _rodrigues_np(aa: np.ndarray) -> np.ndarray:
+    aa = np.asarray(aa, np.float64)
+    th = np.linalg.norm(aa)
+    if th < 1e-12:
+        return np.eye(3)
+    k = aa / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+class VecCrowdEnv:
+    def __init__(self, num_agents: int, body_model: BodyModelHandle, prior: GAMMAPrimitiveCombo, vposer: VPoserEncoder,
+                 scene_kind: str = "sdf", sdf_dict: Optional[dict] = None, rings: Optional[List[np.ndarray]] = None,
+                 pairs: Optional[np.ndarray] = None, box_scenes: Optional[List[dict]] = None,
+                 motion_seed: Optional[dict] = None, cfg: Optional[dict] = None, finetuning: bool = False,
+                 seed: int = 0, num_candidates: Optional[int] = None, use_graph: bool = False,
+                 keep_rollout: bool = False, device: str = "cuda"):
+        if not torch.cuda.is_available():
+            raise _lib.EgxError("VecCrowdEnv needs a HIP device (no CPU fallback)")
+        self.lib = _lib.load()
+        self.A = A = int(num_agents)
+        self.dev = torch.device(device)
+        self.bm, self.prior, self.vposer = body_model, prior, vposer
+        self.scene_kind = scene_kind
+        self.cfg = dict(cfg or (BOX_CFG if scene_kind == "box" else DEFAULT_CFG))
+        self.finetuning = finetuning
+        self.use_graph = use_graph
+        self.keep_rollout = keep_rollout
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(int(seed))
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        z = lambda *s: torch.zeros(*s, **f32)
+
+        # ---- persistent state ----
+        self.state, self.seed = z(A, 2, 402), z(A, 2, 93)
+        self.R0, self.T0 = z(A, 3, 3), z(A, 3)
+        self.dist, self.wpath = z(A), z(A, 2, 3)
+        self.steps = torch.zeros(A, **i32)
+        self.scene_idx = torch.zeros(A, **i32)
+        A20 = A * 20
+        # ---- step intermediates / outputs ----
+        self.z = z(A, 128)
+        self.Y_gen, self.Yb_gen = z(18, A, 201), z(18, A, 93)
+        self.pred_params = z(A, 20, 93)
+        self.joints, self.markers = z(A20, synth.NUM_JOINTS_OUT, 3), z(A20, body_model.M, 3)
+        self.pene_count = torch.zeros(A20, **i32)
+        self.vp_emb = z(A20, 32)
+        self.reward, self.rterms = z(A), z(A, 8)
+        self.terminated = torch.zeros(A, **i32)
+        self.obs_ego, self.obs_dist, self.obs_time = z(A, 2, 32), z(A), z(A)
+        self.marker_b = z(A, 20, 67, 3) if keep_rollout else None
+        self.prev_frame = z(A, 12) if keep_rollout else None
+        self.feet_marker_idx = torch.tensor(synth.feet_marker_idx(), **i32)
+        self._lbs_out = {"joints": self.joints, "markers": self.markers, "pene_count": self.pene_count}
+
+        # ---- motion seed (data/locomotion/subseq_00343.npz in the reference) ----
+        ms = motion_seed or {k: synth.load_assets()[f"seed_{k}"] for k in ("poses", "trans", "betas")}
+        self.motion_seed = {k: np.asarray(v, np.float64) for k, v in ms.items()}
+        self.betas = torch.tensor(self.motion_seed["betas"], **f32).reshape(1, 10).repeat(A, 1).contiguous()
+        if scene_kind == "sdf":
+            starts = [5]                                           # environments.py:193 fixed start frame
+        else:
+            starts = list(range(len(self.motion_seed["poses"]) - 1))  # environments.py:483 random start frame
+        self.variant_starts = starts
+        self._build_seed_tables(starts)
+
+        # ---- scenes ----
+        self.sdf = None
+        if scene_kind == "sdf":
+            if sdf_dict is None or rings is None or pairs is None:
+                raise ValueError("sdf scene needs sdf_dict, rings (walkable polygon) and start/target pairs")
+            self.sdf = sdf_dict if isinstance(sdf_dict, SdfScene) else SdfScene(sdf_dict, device=self.dev)
+            edges = [synth.rings_to_edges(rings).astype(np.float32)]
+            tris = [np.zeros((0, 6), np.float32)]
+            floor = [0.0]
+            self.pairs_all = torch.tensor(np.asarray(pairs, np.float32), **f32).reshape(-1, 2, 3)
+            self.K = int(num_candidates or 1)
+        elif scene_kind == "box":
+            if not box_scenes:
+                raise ValueError("box scene kind needs box_scenes")
+            edges = [np.asarray(s["edges"], np.float32) for s in box_scenes]
+            tris = [np.asarray(s["tris"], np.float32).reshape(-1, 6) for s in box_scenes]
+            floor = [float(s["floor_height"]) for s in box_scenes]
+            P = min(len(s["pairs"]) for s in box_scenes)
+            self.box_pairs = torch.tensor(np.stack([np.asarray(s["pairs"][:P], np.float32) for s in box_scenes]), **f32)
+            self.K = int(num_candidates or 8)
+        else:
+            raise ValueError(f"unknown scene_kind {scene_kind!r}")
+        self.num_scenes = len(edges)
+        self.edges = torch.tensor(np.concatenate(edges, 0), **f32).contiguous()
+        self.edge_off = torch.tensor(np.cumsum([0] + [len(e) for e in edges]), **i32)
+        self.tris = torch.tensor(np.concatenate(tris, 0), **f32).contiguous() if sum(len(t) for t in tris) else z(1, 6)
+        self.tri_off = torch.tensor(np.cumsum([0] + [len(t) for t in tris]), **i32)
+        self.floor_h = torch.tensor(floor, **f32)
+        self.map_lin = torch.linspace(-self.cfg["map_extent"], self.cfg["map_extent"], self.cfg["map_res"]).to(self.dev)
+
+        # ---- candidate buffers ----
+        K = self.K
+        self.cand_pairs = z(A, K, 2, 3)
+        self.cand_yaw = z(A, K)
+        self.cand_variant = torch.zeros(A, K, **i32)
+        self.cand_scene = torch.zeros(A, K, **i32)
+        self.choice = torch.zeros(A, **i32)
+        self.ones_mask = torch.ones(A, **i32)
+
+        # ---- C structs ----
+        c = self.cfg
+        ec = _lib.EnvConfig()
+        ec.reproj_factor, ec.goal_thresh, ec.pene_thres = c["reproj_factor"], c["goal_thresh"], c["pene_thres"]
+        ec.weight_skate, ec.weight_floor, ec.weight_face_target = c["weight_skate"], c["weight_floor"], c["weight_face_target"]
+        ec.weight_look_target, ec.weight_success, ec.weight_target_dist = c["weight_look_target"], c["weight_success"], c["weight_target_dist"]
+        ec.weight_vp = c["weight_vp"]
+        if scene_kind == "sdf":
+            ec.weight_pene = 0.1 if finetuning else 1.0          # crowd_env_2f.py:268-271
+            ec.terminate_on_penetration = 1 if finetuning else 0  # :299-302
+        else:
+            ec.weight_pene = c["weight_pene"]                    # crowd_env_2f_box.py:303
+            ec.terminate_on_penetration = 1                      # :325
+        ec.max_depth = int(c["max_depth"])
+        ec.scene_kind = 0 if scene_kind == "sdf" else 1
+        ec.pene_type_body = 1 if c["pene_type"] == "body" else 0
+        ec.ray_len = float(c["ray_len"])
+        self._ec = ec
+        sc = _lib.EnvScenes()
+        sc.edges, sc.edge_off, sc.tris, sc.tri_off = self.edges.data_ptr(), self.edge_off.data_ptr(), self.tris.data_ptr(), self.tri_off.data_ptr()
+        sc.floor_height, sc.map_lin, sc.map_res = self.floor_h.data_ptr(), self.map_lin.data_ptr(), int(c["map_res"])
+        self._sc = sc
+        self._st = self._make_state_struct(self.state, self.seed, self.R0, self.T0, self.dist, self.steps, self.wpath, self.scene_idx)
+        io = _lib.EnvStepIO()
+        io.Y_gen, io.pred_params, io.joints, io.markers_proj = self.Y_gen.data_ptr(), self.pred_params.data_ptr(), self.joints.data_ptr(), self.markers.data_ptr()
+        io.pene_count = self.pene_count.data_ptr() if scene_kind == "sdf" else None
+        io.vp_emb, io.feet_marker_idx = self.vp_emb.data_ptr(), self.feet_marker_idx.data_ptr()
+        io.reward, io.terminated, io.reward_terms = self.reward.data_ptr(), self.terminated.data_ptr(), self.rterms.data_ptr()
+        io.obs_ego, io.obs_dist, io.obs_time = self.obs_ego.data_ptr(), self.obs_dist.data_ptr(), self.obs_time.data_ptr()
+        io.out_marker_b = self.marker_b.data_ptr() if keep_rollout else None
+        io.out_prev_frame = self.prev_frame.data_ptr() if keep_rollout else None
+        self._io = io
+
+        # workspaces are sized now so that nothing allocates during graph capture
+        self.bm.workspace(A20)
+        self.prior._ws.get(self.lib.egx_sample_prior_workspace_bytes(A), self.dev)
+        self.vposer._ws.get(self.lib.egx_vposer_workspace_bytes(A20), self.dev)
+        if self.vposer._folded is None:
+            self.vposer.fold()
+        self.prior._weights()
+        self._graph = None
+        self._injected = False
+
+        self.valid_pairs = None
+        if scene_kind == "sdf":
+            self._prevalidate_pairs()
+
+    # ------------------------------------------------------------------------------------------
+    def _make_state_struct(self, state, seed, R0, T0, dist, steps, wpath, scene_idx):
+        st = _lib.EnvState()
+        st.state, st.seed, st.R0, st.T0 = state.data_ptr(), seed.data_ptr(), R0.data_ptr(), T0.data_ptr()
+        st.dist, st.steps, st.wpath, st.scene_idx = dist.data_ptr(), steps.data_ptr(), wpath.data_ptr(), scene_idx.data_ptr()
+        return st
+
+    def _build_seed_tables(self, starts):
+        """Motion-seed bodies at identity global orient / zero transl (one LBS call): the scene sampler only
+        ever rotates / translates them rigidly (environments.py:216-247), so reset needs no SMPL-X call."""
+        ms = self.motion_seed
+        NV = len(starts)
+        xb = torch.zeros(NV * 2, 93)
+        glorot = np.zeros((NV, 2, 3, 3))
+        transl = np.zeros((NV, 2, 3))
+        pose = np.zeros((NV, 2, 63))
+        for v, s in enumerate(starts):
+            for f in range(2):
+                pose[v, f] = ms["poses"][s + f, 3:66]
+                glorot[v, f] = _rodrigues_np(ms["poses"][s + f, :3])
+                transl[v, f] = ms["trans"][s + f]
+        xb[:, 6:69] = torch.tensor(pose.reshape(NV * 2, 63), dtype=torch.float32)
+        betas = torch.tensor(ms["betas"], dtype=torch.float32).reshape(1, 10).to(self.dev)
+        out = self.bm.forward(xb.to(self.dev), betas.repeat(NV * 2, 1).contiguous(), 1, want_verts=False)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.tab_joints = out["joints"].reshape(NV, 2, -1, 3).clone().contiguous()
+        self.tab_markers = out["markers"].reshape(NV, 2, -1, 3).clone().contiguous()
+        self.tab_glorot = torch.tensor(glorot, **f32).contiguous()
+        self.tab_transl = torch.tensor(transl, **f32).contiguous()
+        self.tab_pose = torch.tensor(pose, **f32).contiguous()
+
+    def _reset_io(self, A, K, mask, cand_pairs, cand_yaw, cand_variant, cand_scene, cand_valid, obs_ego, obs_dist, obs_time, choice):
+        io = _lib.EnvResetIO()
+        io.num_candidates = int(K)
+        io.mask = mask.data_ptr() if mask is not None else None
+        io.cand_pairs = cand_pairs.data_ptr()
+        io.cand_yaw = cand_yaw.data_ptr() if cand_yaw is not None else None
+        io.cand_variant = cand_variant.data_ptr() if cand_variant is not None else None
+        io.cand_scene = cand_scene.data_ptr() if cand_scene is not None else None
+        io.cand_valid = cand_valid.data_ptr() if cand_valid is not None else None
+        io.tab_joints, io.tab_markers = self.tab_joints.data_ptr(), self.tab_markers.data_ptr()
+        io.tab_glorot, io.tab_transl, io.tab_pose = self.tab_glorot.data_ptr(), self.tab_transl.data_ptr(), self.tab_pose.data_ptr()
+        io.obs_ego, io.obs_dist, io.obs_time = obs_ego.data_ptr(), obs_dist.data_ptr(), obs_time.data_ptr()
+        io.out_choice = choice.data_ptr() if choice is not None else None
+        return io
+
+    def _prevalidate_pairs(self, batch: int = 2048):
+        """SDF env: the rejection loop of CrowdEnv.reset (crowd_env_2f.py:326-396) accepts a start iff no non-feet
+        vertex of the two seed frames has sdf < 0.  For the room sampler that is a deterministic function of the
+        start/target pair, so every pair is evaluated once here (sampler kernel -> SMPL-X + SDF kernel) and reset
+        then draws uniformly among the accepted pairs - the same distribution as rejection sampling."""
+        N = self.pairs_all.shape[0]
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        valid = torch.zeros(N, dtype=torch.bool, device=self.dev)
+        for s in range(0, N, batch):
+            n = min(batch, N - s)
+            tmp = dict(state=torch.zeros(n, 2, 402, **f32), seed=torch.zeros(n, 2, 93, **f32), R0=torch.zeros(n, 3, 3, **f32),
+                       T0=torch.zeros(n, 3, **f32), dist=torch.zeros(n, **f32), steps=torch.zeros(n, **i32),
+                       wpath=torch.zeros(n, 2, 3, **f32), scene_idx=torch.zeros(n, **i32))
+            st = self._make_state_struct(**tmp)
+            ego, od, ot = torch.zeros(n, 2, 32, **f32), torch.zeros(n, **f32), torch.zeros(n, **f32)
+            cp = self.pairs_all[s:s + n].reshape(n, 1, 2, 3).contiguous()
+            io = self._reset_io(n, 1, None, cp, None, None, None, None, ego, od, ot, None)
+            _lib.check(self.lib.egx_env_reset(C.byref(self._ec), C.byref(self._sc), C.byref(st), C.byref(io), n,
+                                              _lib.current_stream_ptr()), "egx_env_reset")
+            betas = self.betas[:1].repeat(n, 1).contiguous()
+            out = self.bm.forward(tmp["seed"].reshape(n * 2, 93), betas, 2, want_joints=False, want_markers=False,
+                                  sdf=self.sdf, R0=tmp["R0"], T0=tmp["T0"])
+            valid[s:s + n] = out["pene_count"].reshape(n, 2).sum(1) == 0
+        self.pair_valid_mask = valid
+        self.valid_pairs = self.pairs_all[valid].contiguous()
+        if self.valid_pairs.shape[0] == 0:
+            raise RuntimeError("no start/target pair passes the SDF start check")
+
+    # ------------------------------------------------------------------------------------------
+    def sample_candidates(self):
+        """Draw reset candidates for every agent (used only where the mask says so)."""
+        A, K, g = self.A, self.K, self.gen
+        if self.scene_kind == "sdf":
+            idx = torch.randint(0, self.valid_pairs.shape[0], (A * K,), generator=g, device=self.dev)
+            self.cand_pairs.copy_(self.valid_pairs[idx].reshape(A, K, 2, 3))
+        else:
+            sc = torch.randint(0, self.num_scenes, (A * K,), generator=g, device=self.dev)
+            pi = torch.randint(0, self.box_pairs.shape[1], (A * K,), generator=g, device=self.dev)
+            self.cand_pairs.copy_(self.box_pairs[sc, pi].reshape(A, K, 2, 3))
+            self.cand_scene.copy_(sc.reshape(A, K).to(torch.int32))
+            self.cand_variant.copy_(torch.randint(0, len(self.variant_starts), (A, K), generator=g, device=self.dev).to(torch.int32))
+            u = torch.rand(A, K, generator=g, device=self.dev) * 2 - 1
+            self.cand_yaw.copy_(u * (2 * np.pi * 0.1))           # environments.py:529
+
+    def set_candidates(self, pairs, yaw=None, variant=None, scene=None):
+        """Inject reset candidates (parity tests): pairs[A,K,2,3]."""
+        self.cand_pairs.copy_(torch.as_tensor(pairs, dtype=torch.float32).reshape(self.A, self.K, 2, 3))
+        if yaw is not None:
+            self.cand_yaw.copy_(torch.as_tensor(yaw, dtype=torch.float32).reshape(self.A, self.K))
+        if variant is not None:
+            self.cand_variant.copy_(torch.as_tensor(variant, dtype=torch.int32).reshape(self.A, self.K))
+        if scene is not None:
+            self.cand_scene.copy_(torch.as_tensor(scene, dtype=torch.int32).reshape(self.A, self.K))
+        self._injected = True
+
+    def _launch_reset(self, mask):
+        box = self.scene_kind == "box"
+        io = self._reset_io(self.A, self.K, mask, self.cand_pairs, self.cand_yaw if box else None,
+                            self.cand_variant if box else None, self.cand_scene if box else None, None,
+                            self.obs_ego, self.obs_dist, self.obs_time, self.choice)
+        _lib.check(self.lib.egx_env_reset(C.byref(self._ec), C.byref(self._sc), C.byref(self._st), C.byref(io), self.A,
+                                          _lib.current_stream_ptr()), "egx_env_reset")
+
+    def obs(self) -> Dict[str, torch.Tensor]:
+        return {"state": self.state, "egosensing": self.obs_ego, "dist": self.obs_dist, "time": self.obs_time}
+
+    def reset(self, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        if not self._injected:
+            self.sample_candidates()
+        self._injected = False
+        self._launch_reset(mask)
+        return self.obs()
+
+    # ------------------------------------------------------------------------------------------
+    def _step_core(self):
+        lib, A = self.lib, self.A
+        st = _lib.current_stream_ptr()
+        # C-VAE decode + regressor (crowd_env_2f.py:109)
+        self.prior.sample_prior_into(self.state[:, 0], self.state[:, 1], 804, self.betas, self.z, self.Y_gen, self.Yb_gen)
+        _lib.check(lib.egx_assemble_params(_lib.ptr(self.seed), _lib.ptr(self.Yb_gen), A, _lib.ptr(self.pred_params), st),
+                   "egx_assemble_params")
+        # SMPL-X on A*20 bodies; SDF counts fused (crowd_env_2f.py:133-175)
+        self.bm.forward(self.pred_params.reshape(A * 20, 93), self.betas, 20, want_verts=False,
+                        sdf=self.sdf, R0=self.R0 if self.sdf is not None else None,
+                        T0=self.T0 if self.sdf is not None else None, out=self._lbs_out)
+        # VPoser embedding of the 20 body poses (crowd_env_2f.py:197-198)
+        self.vposer.encode_mean_into(self.pred_params.reshape(A * 20, 93)[:, 6:], 93, A * 20, self.vp_emb)
+        _lib.check(lib.egx_env_step_post(C.byref(self._ec), C.byref(self._sc), C.byref(self._st), C.byref(self._io), A, st),
+                   "egx_env_step_post")
+
+    def step(self, actions: torch.Tensor, auto_reset: bool = True):
+        """actions[A,128] -> (obs, reward[A], terminated[A] int32).  Returned tensors are views of internal
+        buffers, valid until the next call.  With auto_reset, finished agents are re-initialised and their
+        entries of obs are the reset observation (tianshou Collector semantics)."""
+        if actions.shape != (self.A, 128):
+            raise ValueError(f"actions must be [{self.A},128], got {tuple(actions.shape)}")
+        self.z.copy_(actions)
+        if self.use_graph:
+            if self._graph is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_core()
+                self._graph = g
+            self._graph.replay()
+        else:
+            self._step_core()
+        if auto_reset:
+            if not self._injected:
+                self.sample_candidates()
+            self._injected = False
+            self._launch_reset(self.terminated)
+        return self.obs(), self.reward, self.terminated
+
+
+class CrowdEnv:
+    """Single-agent gym-style view with the reference's interface (crowd_env_2f.py:34-51,78,320,519)."""
+
+    def __init__(self, vec_env: VecCrowdEnv):
+        if vec_env.A != 1:
+            raise ValueError("CrowdEnv wraps a 1-agent VecCrowdEnv")
+        self.vec = vec_env
+        self.action_space = {"low": -6.0, "high": 6.0, "shape": (128,)}
+        self.observation_space = {"state": (2, 402), "egosensing": (2, 32), "dist": (), "time": ()}
+
+    def seed(self, seed):
+        self.vec.gen.manual_seed(int(seed))
+
+    def _obs0(self):
+        o = self.vec.obs()
+        return {"state": o["state"][0], "egosensing": o["egosensing"][0], "dist": o["dist"][0:1], "time": o["time"][0:1]}
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            self.seed(seed)
+        self.vec.reset()
+        return self._obs0(), {}
+
+    def step(self, action_z):
+        a = torch.as_tensor(action_z, dtype=torch.float32, device=self.vec.dev).reshape(1, 128)
+        _, rew, term = self.vec.step(a, auto_reset=False)
+        return self._obs0(), float(rew[0].item()), bool(term[0].item()), False, {}

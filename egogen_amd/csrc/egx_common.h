@@ -42,16 +42,18 @@ struct SdfDev {
 };
 
 __device__ __forceinline__ float egx_sdf_neg_trilinear(const SdfDev& s, float x, float y, float z) {
-  const float nx = (x - s.cx) * s.scale, ny = (y - s.cy) * s.scale, nz = (z - s.cz) * s.scale;
-  float px = ((nx + 1.f) * (float)s.d0 - 1.f) * 0.5f;
-  float py = ((ny + 1.f) * (float)s.d1 - 1.f) * 0.5f;
-  float pz = ((nz + 1.f) * (float)s.d2 - 1.f) * 0.5f;
+  // explicit _rn intrinsics: immune to fma contraction, so the coordinates round exactly like the CPU path
+  const float nx = __fmul_rn(__fsub_rn(x, s.cx), s.scale), ny = __fmul_rn(__fsub_rn(y, s.cy), s.scale),
+              nz = __fmul_rn(__fsub_rn(z, s.cz), s.scale);
+  float px = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.f), (float)s.d0), 1.f), 0.5f);
+  float py = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.f), (float)s.d1), 1.f), 0.5f);
+  float pz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nz, 1.f), (float)s.d2), 1.f), 0.5f);
   px = fminf(fmaxf(px, 0.f), (float)(s.d0 - 1));
   py = fminf(fmaxf(py, 0.f), (float)(s.d1 - 1));
   pz = fminf(fmaxf(pz, 0.f), (float)(s.d2 - 1));
   const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
-  const float wx1 = px - x0, wy1 = py - y0, wz1 = pz - z0;
-  const float wx0 = (x0 + 1.f) - px, wy0 = (y0 + 1.f) - py, wz0 = (z0 + 1.f) - pz;
+  const float wx1 = __fsub_rn(px, x0), wy1 = __fsub_rn(py, y0), wz1 = __fsub_rn(pz, z0);
+  const float wx0 = __fsub_rn(__fadd_rn(x0, 1.f), px), wy0 = __fsub_rn(__fadd_rn(y0, 1.f), py), wz0 = __fsub_rn(__fadd_rn(z0, 1.f), pz);
   const int ix0 = (int)x0, iy0 = (int)y0, iz0 = (int)z0;
   const int ix1 = min(ix0 + 1, s.d0 - 1), iy1 = min(iy0 + 1, s.d1 - 1);
   const bool z1_in = (iz0 + 1) < s.d2;
@@ -73,3 +75,51 @@ __device__ __forceinline__ float egx_sdf_neg_trilinear(const SdfDev& s, float x,
   acc = __fadd_rn(acc, __fmul_rn(r11[dz], __fmul_rn(__fmul_rn(wx1e, wy1e), wz1e)));
   return -acc;
 }
+
+// ---- rotation helpers shared with the env kernels (torchgeometry 0.1.2 semantics) ----
+__device__ __forceinline__ void egx_tgm_rotmat_to_aa(const float* R /*row-major 3x3*/, float* aa) {
+  // rotation_matrix_to_quaternion works on R^T: m[a][b] = R[b][a]
+  const float m00 = R[0], m01 = R[3], m02 = R[6], m10 = R[1], m11 = R[4], m12 = R[7], m20 = R[2], m21 = R[5], m22 = R[8];
+  float q0, q1, q2, q3, t;
+  if (m22 < 1e-6f) {
+    if (m00 > m11) {
+      t = 1.f + m00 - m11 - m22;
+      q0 = m12 - m21; q1 = t; q2 = m01 + m10; q3 = m20 + m02;
+    } else {
+      t = 1.f - m00 + m11 - m22;
+      q0 = m20 - m02; q1 = m01 + m10; q2 = t; q3 = m12 + m21;
+    }
+  } else {
+    if (m00 < -m11) {
+      t = 1.f - m00 - m11 + m22;
+      q0 = m01 - m10; q1 = m20 + m02; q2 = m12 + m21; q3 = t;
+    } else {
+      t = 1.f + m00 + m11 + m22;
+      q0 = t; q1 = m12 - m21; q2 = m20 - m02; q3 = m01 - m10;
+    }
+  }
+  const float sc = 0.5f / sqrtf(t);
+  q0 *= sc; q1 *= sc; q2 *= sc; q3 *= sc;
+  const float sin_sq = q1 * q1 + q2 * q2 + q3 * q3;
+  const float sin_t = sqrtf(sin_sq);
+  const float two_theta = 2.f * ((q0 < 0.f) ? atan2f(-sin_t, -q0) : atan2f(sin_t, q0));
+  const float k = (sin_sq > 0.f) ? two_theta / sin_t : 2.f;
+  aa[0] = q1 * k; aa[1] = q2 * k; aa[2] = q3 * k;
+}
+
+__device__ __forceinline__ void egx_tgm_aa_to_rotmat(const float* aa, float* R) {
+  const float theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (theta2 > 1e-6f) {
+    const float theta = sqrtf(theta2);
+    const float wx = aa[0] / (theta + 1e-6f), wy = aa[1] / (theta + 1e-6f), wz = aa[2] / (theta + 1e-6f);
+    const float c = cosf(theta), s = sinf(theta), oc = 1.f - c;
+    R[0] = c + wx * wx * oc;      R[1] = wx * wy * oc - wz * s; R[2] = wy * s + wx * wz * oc;
+    R[3] = wz * s + wx * wy * oc; R[4] = c + wy * wy * oc;      R[5] = -wx * s + wy * wz * oc;
+    R[6] = -wy * s + wx * wz * oc; R[7] = wx * s + wy * wz * oc; R[8] = c + wz * wz * oc;
+  } else {
+    R[0] = 1.f; R[1] = -aa[2]; R[2] = aa[1];
+    R[3] = aa[2]; R[4] = 1.f; R[5] = -aa[0];
+    R[6] = -aa[1]; R[7] = aa[0]; R[8] = 1.f;
+  }
+}
+

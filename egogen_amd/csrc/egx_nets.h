@@ -1,0 +1,16 @@
+// Internal launch helpers shared by nets.hip / prior.hip (not part of the C ABI).
+#pragma once
+#include "egx_common.h"
+
+struct EgxSeg {
+  const float* p;
+  int w, ld;
+};
+
+// out = act(cat(segs) W^T + b) + res      (W: [N,K] torch layout)
+int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg, const float* W, const float* b,
+                      int act, float slope, const float* res, int ldr, float* out, int ldo);
+int egx_launch_gru_pointwise(hipStream_t st, const float* gi, const float* gh, const float* hprev, int ldh, float* hout,
+                             int ldo, int M, int H);
+int egx_launch_cont6d_to_aa(hipStream_t st, const float* xb6, int n, float* out, int ldo);
+int egx_launch_posenc(hipStream_t st, const float* dist, const float* time, int A, float* out);

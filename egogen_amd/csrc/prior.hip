@@ -1,0 +1,234 @@
+// Whole-network entry points: the motion prior (C-VAE decode + body regressor), the policy networks and
+// the VPoser encoder, each as one C call that enqueues its chain of fused dense-layer kernels.
+#include "egx_nets.h"
+
+namespace {
+constexpr int H = 256, ZD = 128, MK = 201, T_PRED = 18;
+
+struct Carver {
+  char* base;
+  size_t off = 0, cap;
+  Carver(void* p, size_t c) : base(static_cast<char*>(p)), cap(c) {}
+  float* take(size_t nfloat) {
+    float* r = reinterpret_cast<float*>(base + off);
+    off = egx_align_up(off + nfloat * sizeof(float), 256);
+    return r;
+  }
+};
+size_t carve_bytes(std::initializer_list<size_t> nfloats) {
+  size_t off = 0;
+  for (size_t n : nfloats) off = egx_align_up(off + n * sizeof(float), 256);
+  return off;
+}
+}  // namespace
+
+extern "C" size_t egx_sample_prior_workspace_bytes(int A) {
+  if (A <= 0) return 0;
+  const size_t a = A, m = (size_t)A * T_PRED;
+  return carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 512, a * H, m * 128, m * 128, m * 159});
+}
+
+extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, const float* x1, int x_ld,
+                                const float* betas, const float* z, int A, float* out_Y, float* out_Yb,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+  EGX_REQUIRE(w && x0 && x1 && betas && z && out_Y && out_Yb, "null argument");
+  EGX_REQUIRE(A > 0 && x_ld >= MK, "bad sizes");
+  if (!workspace || workspace_bytes < egx_sample_prior_workspace_bytes(A)) {
+    egx_set_error("egx_sample_prior: workspace too small");
+    return EGX_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  Carver cv(workspace, workspace_bytes);
+  const int M = A * T_PRED;
+  float* hx = cv.take((size_t)A * H);
+  float* hA = cv.take((size_t)A * H);
+  float* hB = cv.take((size_t)A * H);
+  float* gi = cv.take((size_t)A * 3 * H);
+  float* gh = cv.take((size_t)A * 3 * H);
+  float* t512 = cv.take((size_t)A * 512);
+  float* t256 = cv.take((size_t)A * H);
+  float* rh = cv.take((size_t)M * 128);
+  float* rt = cv.take((size_t)M * 128);
+  float* xb6 = cv.take((size_t)M * 159);
+
+  // ---- x_enc GRU over the 2 history frames (zero initial state) -> hx
+  {
+    EgxSeg s0{x0, MK, x_ld};
+    egx_launch_linear(st, A, 3 * H, &s0, 1, w->x_enc_w_ih, w->x_enc_b_ih, 0, 0.f, nullptr, 0, gi, 3 * H);
+    // zero initial state, kept explicit so both steps share one code path
+    EGX_HIP_CHECK(hipMemsetAsync(hA, 0, (size_t)A * H * sizeof(float), st));
+    EgxSeg sh{hA, H, H};
+    egx_launch_linear(st, A, 3 * H, &sh, 1, w->x_enc_w_hh, w->x_enc_b_hh, 0, 0.f, nullptr, 0, gh, 3 * H);
+    egx_launch_gru_pointwise(st, gi, gh, hA, H, hB, H, A, H);
+    EgxSeg s1{x1, MK, x_ld};
+    egx_launch_linear(st, A, 3 * H, &s1, 1, w->x_enc_w_ih, w->x_enc_b_ih, 0, 0.f, nullptr, 0, gi, 3 * H);
+    EgxSeg shb{hB, H, H};
+    egx_launch_linear(st, A, 3 * H, &shb, 1, w->x_enc_w_hh, w->x_enc_b_hh, 0, 0.f, nullptr, 0, gh, 3 * H);
+    egx_launch_gru_pointwise(st, gi, gh, hB, H, hx, H, A, H);
+  }
+  // ---- h_rnn = drnn_mlp(hx)  (tanh after every layer)
+  float* hcur = hA;
+  float* hnext = hB;
+  {
+    EgxSeg s{hx, H, H};
+    egx_launch_linear(st, A, 512, &s, 1, w->drnn_w[0], w->drnn_b[0], 1, 0.f, nullptr, 0, t512, 512);
+    EgxSeg s2{t512, 512, 512};
+    egx_launch_linear(st, A, H, &s2, 1, w->drnn_w[1], w->drnn_b[1], 1, 0.f, nullptr, 0, t256, H);
+    EgxSeg s3{t256, H, H};
+    egx_launch_linear(st, A, H, &s3, 1, w->drnn_w[2], w->drnn_b[2], 1, 0.f, nullptr, 0, hcur, H);
+  }
+  // ---- 18 decode steps
+  for (int i = 0; i < T_PRED; ++i) {
+    const float* yp = (i == 0) ? x1 : out_Y + (size_t)(i - 1) * A * MK;
+    const int yp_ld = (i == 0) ? x_ld : MK;
+    EgxSeg in[3] = {{hx, H, H}, {z, ZD, ZD}, {yp, MK, yp_ld}};
+    egx_launch_linear(st, A, 3 * H, in, 3, w->d_rnn_w_ih, w->d_rnn_b_ih, 0, 0.f, nullptr, 0, gi, 3 * H);
+    EgxSeg sh{hcur, H, H};
+    egx_launch_linear(st, A, 3 * H, &sh, 1, w->d_rnn_w_hh, w->d_rnn_b_hh, 0, 0.f, nullptr, 0, gh, 3 * H);
+    egx_launch_gru_pointwise(st, gi, gh, hcur, H, hnext, H, A, H);
+    EgxSeg s1{hnext, H, H};
+    egx_launch_linear(st, A, 512, &s1, 1, w->d_mlp_w[0], w->d_mlp_b[0], 1, 0.f, nullptr, 0, t512, 512);
+    EgxSeg s2{t512, 512, 512};
+    egx_launch_linear(st, A, H, &s2, 1, w->d_mlp_w[1], w->d_mlp_b[1], 1, 0.f, nullptr, 0, t256, H);
+    EgxSeg s3{t256, H, H};
+    // y_i = d_out(hfc) + y_p   (residual)
+    egx_launch_linear(st, A, MK, &s3, 1, w->d_out_w, w->d_out_b, 0, 0.f, yp, yp_ld, out_Y + (size_t)i * A * MK, MK);
+    float* tmp = hcur; hcur = hnext; hnext = tmp;
+  }
+  // ---- regressor on all 18*A frames: rows ordered [t][a] like Y_gen.view(nt*nb,-1); betas row = a
+  // (betas.repeat(t_pred, b, 1) in the reference = same betas for every frame of an agent)
+  EGX_HIP_CHECK(hipMemsetAsync(xb6, 0, (size_t)M * 159 * sizeof(float), st));
+  // betas are [A,10] shared by the 18 frames of an agent: expand once into the (now free) gi buffer
+  // (A*768 floats >= 18*A*10)
+  float* betas_rep = gi;  // [M,10]
+  for (int t = 0; t < T_PRED; ++t)
+    EGX_HIP_CHECK(hipMemcpyAsync(betas_rep + (size_t)t * A * 10, betas, (size_t)A * 10 * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+  for (int rcr = 0; rcr < 3; ++rcr) {
+    EgxSeg in[3] = {{out_Y, MK, MK}, {xb6, 159, 159}, {betas_rep, 10, 10}};
+    egx_launch_linear(st, M, 128, in, 3, w->reg_in_w, w->reg_in_b, 0, 0.f, nullptr, 0, rh, 128);
+    for (int b = 0; b < 10; ++b) {
+      EgxSeg s1{rh, 128, 128};
+      egx_launch_linear(st, M, 128, &s1, 1, w->reg_blk_w[2 * b], w->reg_blk_b[2 * b], 2, 0.f, nullptr, 0, rt, 128);
+      EgxSeg s2{rt, 128, 128};
+      egx_launch_linear(st, M, 128, &s2, 1, w->reg_blk_w[2 * b + 1], w->reg_blk_b[2 * b + 1], 2, 0.f, rh, 128, rh, 128);
+    }
+    EgxSeg so{rh, 128, 128};
+    egx_launch_linear(st, M, 159, &so, 1, w->reg_out_w, w->reg_out_b, 0, 0.f, xb6, 159, xb6, 159);
+  }
+  egx_launch_cont6d_to_aa(st, xb6, M, out_Yb, 93);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" size_t egx_policy_workspace_bytes(int n) {
+  if (n <= 0) return 0;
+  const size_t m = n;
+  return carve_bytes({m * 1536, m * 1536, m * 512, m * 512, m * 512, m * 128, m * 1152, m * 1152, m * 256});
+}
+
+extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* state, const float* ego, const float* dist,
+                                  const float* time, int n, float* out_mu, float* out_logvar, float* out_value,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+  EGX_REQUIRE(w && state && ego && dist && time, "null argument");
+  EGX_REQUIRE(n > 0, "num_rows must be positive");
+  EGX_REQUIRE((out_mu == nullptr) == (out_logvar == nullptr), "mu and logvar come together");
+  if (!workspace || workspace_bytes < egx_policy_workspace_bytes(n)) {
+    egx_set_error("egx_policy_forward: workspace too small");
+    return EGX_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  Carver cv(workspace, workspace_bytes);
+  const size_t m = n;
+  float* gi = cv.take(m * 1536);
+  float* gh = cv.take(m * 1536);
+  float* h0 = cv.take(m * 512);
+  float* hxs = cv.take(m * 512);
+  float* hes = cv.take(m * 512);
+  float* pe = cv.take(m * 128);
+  float* a1 = cv.take(m * 1152);
+  float* a2 = cv.take(m * 1152);
+  float* zp = cv.take(m * 256);
+  constexpr int HD = 512;
+  EGX_HIP_CHECK(hipMemsetAsync(h0, 0, m * HD * sizeof(float), st));
+  auto gru2 = [&](const float* x, int in_dim, const float* wih, const float* whh, const float* bih, const float* bhh,
+                  float* hout, float* htmp) {
+    // sequence of 2 steps: x[n,2,in_dim]
+    EgxSeg s0{x, in_dim, 2 * in_dim};
+    egx_launch_linear(st, n, 3 * HD, &s0, 1, wih, bih, 0, 0.f, nullptr, 0, gi, 3 * HD);
+    EgxSeg sh{h0, HD, HD};
+    egx_launch_linear(st, n, 3 * HD, &sh, 1, whh, bhh, 0, 0.f, nullptr, 0, gh, 3 * HD);
+    egx_launch_gru_pointwise(st, gi, gh, h0, HD, htmp, HD, n, HD);
+    EgxSeg s1{x + in_dim, in_dim, 2 * in_dim};
+    egx_launch_linear(st, n, 3 * HD, &s1, 1, wih, bih, 0, 0.f, nullptr, 0, gi, 3 * HD);
+    EgxSeg sh1{htmp, HD, HD};
+    egx_launch_linear(st, n, 3 * HD, &sh1, 1, whh, bhh, 0, 0.f, nullptr, 0, gh, 3 * HD);
+    egx_launch_gru_pointwise(st, gi, gh, htmp, HD, hout, HD, n, HD);
+  };
+  gru2(state, 402, w->x_enc_w_ih, w->x_enc_w_hh, w->x_enc_b_ih, w->x_enc_b_hh, hxs, a1);
+  gru2(ego, 32, w->ego_enc_w_ih, w->ego_enc_w_hh, w->ego_enc_b_ih, w->ego_enc_b_hh, hes, a1);
+  egx_launch_posenc(st, dist, time, n, pe);
+  const float slope = 0.01f;  // torch.nn.LeakyReLU() default (baseops.py:627-628)
+  auto mlp_block = [&](const float* const* W, const float* const* B, const float* Wo, const float* Bo, int nout,
+                       float* out, int ldo) {
+    // h = hx; for blk: h = lrelu(fc2(lrelu(fc1(h)))) + h ; y = out_fc(h)
+    EgxSeg hx4[4] = {{hxs, HD, HD}, {hes, HD, HD}, {pe, 64, 128}, {pe + 64, 64, 128}};
+    egx_launch_linear(st, n, 1152, hx4, 4, W[0], B[0], 3, slope, nullptr, 0, a1, 1152);
+    // the residual of block 0 is the concatenated hx: materialise it once as one [n,1152] buffer (a2)
+    EGX_HIP_CHECK(hipMemcpy2DAsync(a2, 1152 * sizeof(float), hxs, HD * sizeof(float),
+                                   HD * sizeof(float), n, hipMemcpyDeviceToDevice, st));
+    EGX_HIP_CHECK(hipMemcpy2DAsync(a2 + HD, 1152 * sizeof(float), hes, HD * sizeof(float), HD * sizeof(float), n,
+                                   hipMemcpyDeviceToDevice, st));
+    EGX_HIP_CHECK(hipMemcpy2DAsync(a2 + 2 * HD, 1152 * sizeof(float), pe, 128 * sizeof(float), 128 * sizeof(float), n,
+                                   hipMemcpyDeviceToDevice, st));
+    EgxSeg s1{a1, 1152, 1152};
+    egx_launch_linear(st, n, 1152, &s1, 1, W[1], B[1], 3, slope, a2, 1152, a2, 1152);
+    EgxSeg s2{a2, 1152, 1152};
+    egx_launch_linear(st, n, 1152, &s2, 1, W[2], B[2], 3, slope, nullptr, 0, a1, 1152);
+    egx_launch_linear(st, n, 1152, &s1, 1, W[3], B[3], 3, slope, a2, 1152, a2, 1152);
+    egx_launch_linear(st, n, nout, &s2, 1, Wo, Bo, 0, 0.f, nullptr, 0, out, ldo);
+    return EGX_OK;
+  };
+  if (out_mu) {
+    int rc = mlp_block(w->actor_w, w->actor_b, w->actor_out_w, w->actor_out_b, 256, zp, 256);
+    if (rc) return rc;
+    EGX_HIP_CHECK(hipMemcpy2DAsync(out_mu, 128 * sizeof(float), zp, 256 * sizeof(float), 128 * sizeof(float), n,
+                                   hipMemcpyDeviceToDevice, st));
+    EGX_HIP_CHECK(hipMemcpy2DAsync(out_logvar, 128 * sizeof(float), zp + 128, 256 * sizeof(float), 128 * sizeof(float), n,
+                                   hipMemcpyDeviceToDevice, st));
+  }
+  if (out_value) {
+    int rc = mlp_block(w->critic_w, w->critic_b, w->critic_out_w, w->critic_out_b, 1, out_value, 1);
+    if (rc) return rc;
+  }
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" size_t egx_vposer_workspace_bytes(int n) {
+  if (n <= 0) return 0;
+  return carve_bytes({(size_t)n * 512, (size_t)n * 512});
+}
+
+extern "C" int egx_vposer_encode(const egx_vposer_weights* w, const float* x, int x_ld, int n, float* out,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
+  EGX_REQUIRE(w && x && out && n > 0 && x_ld >= 63, "bad arguments");
+  if (!workspace || workspace_bytes < egx_vposer_workspace_bytes(n)) {
+    egx_set_error("egx_vposer_encode: workspace too small");
+    return EGX_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  Carver cv(workspace, workspace_bytes);
+  float* t1 = cv.take((size_t)n * 512);
+  float* t2 = cv.take((size_t)n * 512);
+  EgxSeg s0{x, 63, x_ld};
+  egx_launch_linear(st, n, 512, &s0, 1, w->fc1_w, w->fc1_b, 3, 0.2f, nullptr, 0, t1, 512);
+  EgxSeg s1{t1, 512, 512};
+  egx_launch_linear(st, n, 512, &s1, 1, w->fc2_w, w->fc2_b, 3, 0.2f, nullptr, 0, t2, 512);
+  EgxSeg s2{t2, 512, 512};
+  egx_launch_linear(st, n, 32, &s2, 1, w->mu_w, w->mu_b, 0, 0.f, nullptr, 0, out, 32);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}

@@ -1,0 +1,368 @@
+"""Network containers of the hot path with the reference's module / state_dict layout, executed by the
+HIP library for inference.
+
+Mirrors (names, attribute structure and therefore state_dict keys are the reference's, so its
+checkpoints load unchanged):
+  models/baseops.py:615-641                     MLP
+  models/models_GAMMA_primitive.py:36-101        GAMMAPrimitiveVAE   (decode / sample_prior)
+  models/models_GAMMA_primitive.py:160-301       ResNetBlock, MoshRegressor
+  models/models_GAMMA_primitive.py:307-360       GAMMAPrimitiveCombo (sample_prior)
+  models/models_policy_ppo.py:24-39,233-358      MLPBlock, GAMMAPolicyBase, GAMMAActor, GAMMACritic, ActorCritic
+  human_body_prior VPoser v1 encoder [upstream]  VPoserEncoder
+
+The torch modules only own the parameters (and provide the autograd forward used by the PPO update);
+every rollout-time forward goes through libegogen_hip.so and raises if tensors are not on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+
+_ACT = {"tanh": torch.tanh, "relu": torch.relu, "lrelu": lambda x: F.leaky_relu(x, 0.01)}
+
+
+def _p(t: torch.Tensor) -> int:
+    assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32, "HIP path needs contiguous fp32 cuda tensors"
+    return t.data_ptr()
+
+
+class _Workspace:
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class MLP(nn.Module):
+    def __init__(self, in_dim, h_dims=(128, 128), activation="tanh"):
+        super().__init__()
+        self.act_name = activation
+        self.out_dim = h_dims[-1]
+        self.layers = nn.ModuleList()
+        d = in_dim
+        for h in h_dims:
+            self.layers.append(nn.Linear(d, h))
+            d = h
+
+    def forward(self, x):
+        for fc in self.layers:
+            x = _ACT[self.act_name](fc(x))
+        return x
+
+
+class GAMMAPrimitiveVAE(nn.Module):
+    """Marker predictor.  Only the prior-sampling half (decode) is on the crowd_ppo path; the encoder
+    parameters exist so that reference checkpoints (`epoch-400.ckp`) load with strict=True."""
+
+    def __init__(self, configs):
+        super().__init__()
+        if configs["body_repr"] != "ssm2_67":
+            raise NotImplementedError("only body_repr ssm2_67 is used by crowd_ppo")
+        self.in_dim = in_dim = 67 * 3
+        self.h_dim = h = configs["h_dim"]
+        self.z_dim = z = configs["z_dim"]
+        hd = list(configs["hdims_mlp"])
+        assert (h, z, hd, configs["use_drnn_mlp"], configs["residual"]) == (256, 128, [512, 256], True, True), \
+            "HIP decode is specialised to the released MPVAE_samp20_2frame_rollout config"
+        self.x_enc = nn.GRU(in_dim, h)
+        self.e_rnn = nn.GRU(in_dim, h)
+        self.e_mlp = MLP(2 * h, hd, "tanh")
+        self.e_mu = nn.Linear(self.e_mlp.out_dim, z)
+        self.e_logvar = nn.Linear(self.e_mlp.out_dim, z)
+        self.drnn_mlp = MLP(h, hd + [h], "tanh")
+        self.d_rnn = nn.GRUCell(in_dim + z + h, h)
+        self.d_mlp = MLP(h, hd, "tanh")
+        self.d_out = nn.Linear(self.d_mlp.out_dim, in_dim)
+
+
+class ResNetBlock(nn.Module):
+    def __init__(self, in_dim, h_dim, out_dim, n_blocks, actfun="relu"):
+        super().__init__()
+        self.in_fc = nn.Linear(in_dim, h_dim)
+        self.layers = nn.ModuleList([MLP(h_dim, (h_dim, h_dim), actfun) for _ in range(n_blocks)])
+        self.out_fc = nn.Linear(h_dim, out_dim)
+
+
+class MoshRegressor(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        assert (config["h_dim"], config["n_blocks"], config["n_recur"], config["actfun"], config.get("use_cont", False)) == \
+            (128, 10, 3, "relu", True), "HIP regressor is specialised to the released MoshRegressor_v3 config"
+        self.in_dim = 67 * 3
+        self.body_dim = 3 + 6 + 21 * 6 + 24
+        self.pnet = ResNetBlock(self.in_dim + self.body_dim + 10, 128, self.body_dim, 10, "relu")
+
+
+class GAMMAPrimitiveCombo(nn.Module):
+    def __init__(self, markercfg, bparamscfg):
+        super().__init__()
+        self.predictor = GAMMAPrimitiveVAE(markercfg)
+        self.regressor = MoshRegressor(bparamscfg)
+        self._ws = _Workspace()
+        self._wstruct = None
+        self._wkey = None
+
+    def _weights(self) -> _lib.PriorWeights:
+        p, r = self.predictor, self.regressor.pnet
+        key = (p.x_enc.weight_ih_l0.data_ptr(), r.out_fc.weight.data_ptr())
+        if self._wstruct is not None and self._wkey == key:
+            return self._wstruct
+        w = _lib.PriorWeights()
+        w.x_enc_w_ih, w.x_enc_w_hh = _p(p.x_enc.weight_ih_l0), _p(p.x_enc.weight_hh_l0)
+        w.x_enc_b_ih, w.x_enc_b_hh = _p(p.x_enc.bias_ih_l0), _p(p.x_enc.bias_hh_l0)
+        for i in range(3):
+            w.drnn_w[i], w.drnn_b[i] = _p(p.drnn_mlp.layers[i].weight), _p(p.drnn_mlp.layers[i].bias)
+        w.d_rnn_w_ih, w.d_rnn_w_hh = _p(p.d_rnn.weight_ih), _p(p.d_rnn.weight_hh)
+        w.d_rnn_b_ih, w.d_rnn_b_hh = _p(p.d_rnn.bias_ih), _p(p.d_rnn.bias_hh)
+        for i in range(2):
+            w.d_mlp_w[i], w.d_mlp_b[i] = _p(p.d_mlp.layers[i].weight), _p(p.d_mlp.layers[i].bias)
+        w.d_out_w, w.d_out_b = _p(p.d_out.weight), _p(p.d_out.bias)
+        w.reg_in_w, w.reg_in_b = _p(r.in_fc.weight), _p(r.in_fc.bias)
+        for b in range(10):
+            for k in range(2):
+                w.reg_blk_w[2 * b + k], w.reg_blk_b[2 * b + k] = _p(r.layers[b].layers[k].weight), _p(r.layers[b].layers[k].bias)
+        w.reg_out_w, w.reg_out_b = _p(r.out_fc.weight), _p(r.out_fc.bias)
+        self._wstruct, self._wkey = w, key
+        return w
+
+    @torch.no_grad()
+    def sample_prior_into(self, x0: torch.Tensor, x1: torch.Tensor, x_ld: int, betas: torch.Tensor, z: torch.Tensor,
+                          out_Y: torch.Tensor, out_Yb: torch.Tensor):
+        """Raw form used by the vector env: x0/x1 are views of the two history frames with row stride x_ld."""
+        lib = _lib.load()
+        A = int(z.shape[0])
+        ws = self._ws.get(lib.egx_sample_prior_workspace_bytes(A), z.device)
+        w = self._weights()
+        rc = lib.egx_sample_prior(C.byref(w), C.c_void_p(x0.data_ptr()), C.c_void_p(x1.data_ptr()), int(x_ld),
+                                  _lib.ptr(betas), _lib.ptr(z), A, _lib.ptr(out_Y), _lib.ptr(out_Yb),
+                                  _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr())
+        _lib.check(rc, "egx_sample_prior")
+
+    @torch.no_grad()
+    def sample_prior(self, X: torch.Tensor, betas: torch.Tensor, z: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """models_GAMMA_primitive.py:334-360.  X[t_his=2,b,201], betas[18,b,10] (or [b,10]), z[b,128] or None
+        -> Y_gen[18,b,201], Yb_gen[18,b,93] (axis-angle)."""
+        if not X.is_cuda:
+            raise _lib.EgxError("sample_prior runs on the HIP device only (no CPU fallback)")
+        if X.dim() != 3 or X.shape[0] != 2 or X.shape[2] != 201:
+            raise ValueError(f"X must be [2,b,201], got {tuple(X.shape)}")
+        b = X.shape[1]
+        if z is None:
+            z = torch.randn(b, self.predictor.z_dim, device=X.device)
+        X = X.to(torch.float32).contiguous()
+        betas_a = (betas[0] if betas.dim() == 3 else betas).to(torch.float32).contiguous()
+        z = z.to(torch.float32).contiguous()
+        Y = torch.empty(18, b, 201, dtype=torch.float32, device=X.device)
+        Yb = torch.empty(18, b, 93, dtype=torch.float32, device=X.device)
+        self.sample_prior_into(X[0], X[1], 201, betas_a, z, Y, Yb)
+        return Y, Yb
+
+
+# ---------------------------------------------------------------------------------------------
+# policy
+# ---------------------------------------------------------------------------------------------
+
+class MLPBlock(nn.Module):
+    def __init__(self, h_dim, out_dim, n_blocks, actfun="relu", residual=True):
+        super().__init__()
+        self.residual = residual
+        self.layers = nn.ModuleList([MLP(h_dim, (h_dim, h_dim), actfun) for _ in range(n_blocks)])
+        self.out_fc = nn.Linear(h_dim, out_dim)
+
+    def forward(self, x):
+        h = x
+        for layer in self.layers:
+            h = layer(h) + (h if self.residual else 0)
+        return self.out_fc(h)
+
+
+def positional_encoding(x: torch.Tensor, L: int = 32) -> torch.Tensor:
+    """models_policy_ppo.py:276-285: x[b,1] -> [b,2L], [sin(x 2^k), cos(x 2^k)] interleaved per k."""
+    freqs = 2.0 ** torch.arange(L, dtype=x.dtype, device=x.device)
+    xf = x * freqs  # [b,L]
+    return torch.stack([torch.sin(xf), torch.cos(xf)], dim=-1).reshape(x.shape[0], 2 * L)
+
+
+class GAMMAPolicyBase(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.h_dim = config["h_dim"]
+        self.z_dim = config["z_dim"]
+        if config["body_repr"] not in {"ssm2_67_condi_marker", "ssm2_67_condi_marker_map"}:
+            raise NotImplementedError("other body_repr is not implemented yet.")
+        self.in_dim = 67 * 3 * 2
+        self.x_enc = nn.GRU(self.in_dim, self.h_dim)
+        self.ego_enc = nn.GRU(32, self.h_dim)
+
+    def forward(self, obs):
+        """autograd path (PPO update): obs dict -> hx[b,1152]."""
+        nb = obs["state"].shape[0]
+        _, hx = self.x_enc(obs["state"].permute(1, 0, 2))
+        _, he = self.ego_enc(obs["egosensing"].permute(1, 0, 2))
+        d = positional_encoding(obs["dist"].reshape(nb, 1))
+        t = positional_encoding(obs["time"].reshape(nb, 1))
+        return torch.cat([hx[0], he[0], d, t], dim=-1)
+
+
+class GAMMAActor(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.h_dim, self.z_dim = config["h_dim"], config["z_dim"]
+        self.min_logvar = config.get("min_logvar", -1)
+        self.max_logvar = config.get("max_logvar", 3)
+        self.pnet = MLPBlock(self.h_dim * 2 + 128, self.z_dim * 2, config["n_blocks"], actfun=config["actfun"])
+
+    def forward(self, hx, state=None, info={}):
+        zp = self.pnet(hx)
+        return (zp[:, :self.z_dim], zp[:, self.z_dim:]), state
+
+
+class GAMMACritic(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.h_dim, self.z_dim = config["h_dim"], config["z_dim"]
+        self.vnet = MLPBlock(self.h_dim * 2 + 128, 1, config["n_blocks"], actfun=config["actfun"])
+
+    def forward(self, hx, state=None, info={}):
+        return self.vnet(hx)
+
+
+class ActorCritic(nn.Module):
+    def __init__(self, actor, critic, shared_net=None):
+        super().__init__()
+        self.actor = actor
+        self.critic = critic
+        if shared_net is not None:
+            self.shared_net = shared_net
+
+
+class PolicyHipRunner:
+    """Rollout-time forward of (shared_net, actor, critic) through egx_policy_forward."""
+
+    def __init__(self, shared_net: GAMMAPolicyBase, actor: GAMMAActor, critic: GAMMACritic):
+        assert shared_net.h_dim == 512 and actor.z_dim == 128 and len(actor.pnet.layers) == 2
+        self.shared_net, self.actor, self.critic = shared_net, actor, critic
+        self._ws = _Workspace()
+        self._wstruct = None
+        self._wkey = None
+
+    def _weights(self) -> _lib.PolicyWeights:
+        s, a, c = self.shared_net, self.actor.pnet, self.critic.vnet
+        key = (s.x_enc.weight_ih_l0.data_ptr(), a.out_fc.weight.data_ptr(), c.out_fc.weight.data_ptr())
+        if self._wstruct is not None and self._wkey == key:
+            return self._wstruct
+        w = _lib.PolicyWeights()
+        w.x_enc_w_ih, w.x_enc_w_hh, w.x_enc_b_ih, w.x_enc_b_hh = (_p(s.x_enc.weight_ih_l0), _p(s.x_enc.weight_hh_l0),
+                                                                    _p(s.x_enc.bias_ih_l0), _p(s.x_enc.bias_hh_l0))
+        w.ego_enc_w_ih, w.ego_enc_w_hh, w.ego_enc_b_ih, w.ego_enc_b_hh = (_p(s.ego_enc.weight_ih_l0), _p(s.ego_enc.weight_hh_l0),
+                                                                            _p(s.ego_enc.bias_ih_l0), _p(s.ego_enc.bias_hh_l0))
+        for b in range(2):
+            for k in range(2):
+                w.actor_w[2 * b + k], w.actor_b[2 * b + k] = _p(a.layers[b].layers[k].weight), _p(a.layers[b].layers[k].bias)
+                w.critic_w[2 * b + k], w.critic_b[2 * b + k] = _p(c.layers[b].layers[k].weight), _p(c.layers[b].layers[k].bias)
+        w.actor_out_w, w.actor_out_b = _p(a.out_fc.weight), _p(a.out_fc.bias)
+        w.critic_out_w, w.critic_out_b = _p(c.out_fc.weight), _p(c.out_fc.bias)
+        self._wstruct, self._wkey = w, key
+        return w
+
+    @torch.no_grad()
+    def forward(self, obs: Dict[str, torch.Tensor], want_actor=True, want_critic=True, out: Optional[dict] = None):
+        lib = _lib.load()
+        st = obs["state"]
+        if not st.is_cuda:
+            raise _lib.EgxError("policy inference runs on the HIP device only (no CPU fallback)")
+        n = int(st.shape[0])
+        f = lambda t: t.to(torch.float32).contiguous()
+        st, ego, dist, time = f(st), f(obs["egosensing"]), f(obs["dist"]).reshape(n), f(obs["time"]).reshape(n)
+        out = out if out is not None else {}
+        if want_actor and "mu" not in out:
+            out["mu"] = torch.empty(n, 128, dtype=torch.float32, device=st.device)
+            out["logvar"] = torch.empty(n, 128, dtype=torch.float32, device=st.device)
+        if want_critic and "value" not in out:
+            out["value"] = torch.empty(n, dtype=torch.float32, device=st.device)
+        ws = self._ws.get(lib.egx_policy_workspace_bytes(n), st.device)
+        w = self._weights()
+        rc = lib.egx_policy_forward(C.byref(w), _lib.ptr(st), _lib.ptr(ego), _lib.ptr(dist), _lib.ptr(time), n,
+                                    _lib.ptr(out["mu"]) if want_actor else None,
+                                    _lib.ptr(out["logvar"]) if want_actor else None,
+                                    _lib.ptr(out["value"]) if want_critic else None,
+                                    _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr())
+        _lib.check(rc, "egx_policy_forward")
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# VPoser v1 encoder
+# ---------------------------------------------------------------------------------------------
+
+class VPoserEncoder(nn.Module):
+    """Encoder half of human_body_prior v1 VPoser (num_neurons=512, latentD=32) with its parameter names,
+    so a `snapshot` state_dict loads with strict=False.  encode_mean() = vposer.encode(x).loc in eval mode."""
+
+    def __init__(self, num_neurons=512, latentD=32, n_features=63):
+        super().__init__()
+        self.bodyprior_enc_bn1 = nn.BatchNorm1d(n_features)
+        self.bodyprior_enc_fc1 = nn.Linear(n_features, num_neurons)
+        self.bodyprior_enc_bn2 = nn.BatchNorm1d(num_neurons)
+        self.bodyprior_enc_fc2 = nn.Linear(num_neurons, num_neurons)
+        self.bodyprior_enc_mu = nn.Linear(num_neurons, latentD)
+        self.bodyprior_enc_logvar = nn.Linear(num_neurons, latentD)
+        self._ws = _Workspace()
+        self._folded = None
+
+    @torch.no_grad()
+    def fold(self):
+        """Fold the eval-mode BatchNorms into the following Linear (float64 on the host)."""
+        def affine(bn):
+            s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            return s, bn.bias.double() - bn.running_mean.double() * s
+        s1, t1 = affine(self.bodyprior_enc_bn1)
+        s2, t2 = affine(self.bodyprior_enc_bn2)
+        W1, b1 = self.bodyprior_enc_fc1.weight.double(), self.bodyprior_enc_fc1.bias.double()
+        W2, b2 = self.bodyprior_enc_fc2.weight.double(), self.bodyprior_enc_fc2.bias.double()
+        dev = self.bodyprior_enc_fc1.weight.device
+        f = lambda t: t.float().contiguous().to(dev)
+        self._folded = {"fc1_w": f(W1 * s1[None, :]), "fc1_b": f(b1 + W1 @ t1),
+                        "fc2_w": f(W2 * s2[None, :]), "fc2_b": f(b2 + W2 @ t2),
+                        "mu_w": f(self.bodyprior_enc_mu.weight), "mu_b": f(self.bodyprior_enc_mu.bias)}
+        w = _lib.VposerWeights()
+        for k, v in self._folded.items():
+            setattr(w, k, _p(v))
+        self._wstruct = w
+        return self
+
+    @torch.no_grad()
+    def encode_mean_into(self, x: torch.Tensor, x_ld: int, n: int, out: torch.Tensor):
+        lib = _lib.load()
+        if self._folded is None:
+            self.fold()
+        ws = self._ws.get(lib.egx_vposer_workspace_bytes(n), out.device)
+        rc = lib.egx_vposer_encode(C.byref(self._wstruct), C.c_void_p(x.data_ptr()), int(x_ld), int(n), _lib.ptr(out),
+                                   _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr())
+        _lib.check(rc, "egx_vposer_encode")
+
+    @torch.no_grad()
+    def encode_mean(self, body_pose: torch.Tensor) -> torch.Tensor:
+        if not body_pose.is_cuda:
+            raise _lib.EgxError("VPoser encoder runs on the HIP device only (no CPU fallback)")
+        x = body_pose.to(torch.float32).reshape(body_pose.shape[0], -1).contiguous()
+        out = torch.empty(x.shape[0], 32, dtype=torch.float32, device=x.device)
+        self.encode_mean_into(x, x.shape[1], x.shape[0], out)
+        return out
+
+
+PREDICTOR_CFG = {"body_repr": "ssm2_67", "h_dim": 256, "z_dim": 128, "t_his": 2, "t_pred": 18,
+                 "use_drnn_mlp": True, "hdims_mlp": [512, 256], "residual": True}
+REGRESSOR_CFG = {"body_repr": "ssm2_67", "h_dim": 128, "n_blocks": 10, "n_recur": 3, "actfun": "relu", "use_cont": True}
+POLICY_CFG = {"h_dim": 512, "z_dim": 128, "n_blocks": 2, "n_recur": -1, "body_repr": "ssm2_67_condi_marker_map",
+              "actfun": "lrelu", "is_stochastic": True, "min_logvar": -2.5, "max_logvar": 2.5, "reproj_factor": 0.5,
+              "map_res": 16, "map_extent": 0.8}

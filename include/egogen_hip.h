@@ -109,6 +109,195 @@ int egx_lbs_forward(const egx_body_model* m, const float* xb, const float* betas
  */
 int egx_sdf_sample(const egx_sdf_grid* sdf, const float* pts, int64_t n, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers of the rollout networks.  One fused call replaces nn.Linear + torch.cat + activation
+ * (+ residual) as composed in models/baseops.py:615-641 (MLP), models_GAMMA_primitive.py:160-175
+ * (ResNetBlock) and models_policy_ppo.py:24-39 (MLPBlock):   out = act(cat(x_0..x_{s-1}) W^T + b) + residual
+ * ------------------------------------------------------------------------------------------- */
+#define EGX_ACT_NONE 0
+#define EGX_ACT_TANH 1
+#define EGX_ACT_RELU 2
+#define EGX_ACT_LRELU 3
+
+typedef struct egx_linear_desc {
+  int num_rows;          /* M */
+  int out_features;      /* N */
+  int num_segments;      /* 1..4 input segments, concatenated along the feature axis (K = sum widths) */
+  const float* seg_ptr[4];
+  int seg_width[4];
+  int seg_ld[4];         /* row stride of each segment, in floats */
+  const float* weight;   /* [N,K] torch nn.Linear layout */
+  int weight_ld;         /* 0 = K */
+  const float* bias;     /* [N] or NULL */
+  const float* residual; /* [M,N] added AFTER the activation, or NULL */
+  int residual_ld;
+  float* out;            /* [M,N] */
+  int out_ld;            /* 0 = N */
+  int activation;        /* EGX_ACT_* */
+  float leaky_slope;
+} egx_linear_desc;
+
+int egx_linear(const egx_linear_desc* d, void* stream);
+
+/* torch.nn.GRU / GRUCell gate math given gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh ([M,3H], gate order
+ * r,z,n); h_prev may be NULL (zero state).  Used for x_enc / d_rnn (models_GAMMA_primitive.py:84,94) and the
+ * policy's x_enc / ego_enc (models_policy_ppo.py:291,298). */
+int egx_gru_pointwise(const float* gi, const float* gh, const float* h_prev, int h_prev_ld, float* h_out,
+                      int h_out_ld, int num_rows, int hidden, void* stream);
+
+/* MoshRegressor._cont2aa (models_GAMMA_primitive.py:208-219; RotConverter.cont2aa baseops.py:143-162):
+ * xb6 [n,159] (transl3 | 22x6D | hands24) -> out [n,>=93] (transl3 | 22 axis-angles | hands24). */
+int egx_cont6d_to_aa(const float* xb6, int num_rows, float* out, int out_ld, void* stream);
+
+/* GAMMAPolicyBase.positional_encoding of obs['dist'] and obs['time'] (models_policy_ppo.py:276-285,302-303):
+ * out [A,128] = [posenc(dist) 64 | posenc(time) 64]. */
+int egx_posenc(const float* dist, const float* time, int num_agents, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Motion prior: GAMMAPrimitiveCombo.sample_prior(X, betas, z) (models_GAMMA_primitive.py:334-360)
+ *   = GAMMAPrimitiveVAE.decode (:83-101, 18 GRUCell steps, residual)  +  MoshRegressor.forward (:262-301,
+ *     3 recurrences of a 10-block ResNet, 6D -> axis-angle).
+ * Weight pointers alias the torch parameters of the same state_dict keys (`predictor.*`, `regressor.*`).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct egx_prior_weights {
+  const float *x_enc_w_ih, *x_enc_w_hh, *x_enc_b_ih, *x_enc_b_hh; /* predictor.x_enc  GRU(201,256)      */
+  const float *drnn_w[3], *drnn_b[3];                             /* predictor.drnn_mlp 256-512-256-256  */
+  const float *d_rnn_w_ih, *d_rnn_w_hh, *d_rnn_b_ih, *d_rnn_b_hh; /* predictor.d_rnn  GRUCell(585,256)   */
+  const float *d_mlp_w[2], *d_mlp_b[2];                           /* predictor.d_mlp  256-512-256        */
+  const float *d_out_w, *d_out_b;                                 /* predictor.d_out  256-201            */
+  const float *reg_in_w, *reg_in_b;                               /* regressor.pnet.in_fc 370-128        */
+  const float *reg_blk_w[20], *reg_blk_b[20];                     /* regressor.pnet.layers.{0..9}.layers.{0,1} */
+  const float *reg_out_w, *reg_out_b;                             /* regressor.pnet.out_fc 128-159       */
+} egx_prior_weights;
+
+size_t egx_sample_prior_workspace_bytes(int num_agents);
+
+/*   x_hist0 / x_hist1 : the two history frames of markers, [A,201] with row stride x_ld floats
+ *                       (reference passes X = states[:2, :, :201], crowd_env_2f.py:98,109)
+ *   betas [A,10]; z [A,128]
+ *   out_Y  [18,A,201]  predicted markers   (Y_gen)
+ *   out_Yb [18,A,93]   regressed body parameters, axis-angle (Yb_gen)                               */
+int egx_sample_prior(const egx_prior_weights* w, const float* x_hist0, const float* x_hist1, int x_ld,
+                     const float* betas, const float* z, int num_agents, float* out_Y, float* out_Yb,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Policy networks: GAMMAPolicyBase.forward + GAMMAActor.forward + GAMMACritic.forward
+ * (models_policy_ppo.py:287-306,326-330,348-350).  Pointers alias the torch parameters
+ * `shared_net.*`, `actor.pnet.*`, `critic.vnet.*`.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct egx_policy_weights {
+  const float *x_enc_w_ih, *x_enc_w_hh, *x_enc_b_ih, *x_enc_b_hh;         /* shared_net.x_enc   GRU(402,512) */
+  const float *ego_enc_w_ih, *ego_enc_w_hh, *ego_enc_b_ih, *ego_enc_b_hh; /* shared_net.ego_enc GRU(32,512)  */
+  const float *actor_w[4], *actor_b[4];   /* actor.pnet.layers.{0,1}.layers.{0,1}  1152x1152 */
+  const float *actor_out_w, *actor_out_b; /* actor.pnet.out_fc   256x1152                    */
+  const float *critic_w[4], *critic_b[4]; /* critic.vnet.layers.{0,1}.layers.{0,1}           */
+  const float *critic_out_w, *critic_out_b; /* critic.vnet.out_fc 1x1152                     */
+} egx_policy_weights;
+
+size_t egx_policy_workspace_bytes(int num_rows);
+
+/*   state [n,2,402], egosensing [n,2,32], dist [n], time [n]   (the obs dict, crowd_env_2f.py:311-312)
+ *   out_mu [n,128], out_logvar [n,128] (unclamped, as the actor returns them), out_value [n];
+ *   any output may be NULL (actor or critic branch skipped).                                          */
+int egx_policy_forward(const egx_policy_weights* w, const float* state, const float* egosensing, const float* dist,
+                       const float* time, int num_rows, float* out_mu, float* out_logvar, float* out_value,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* VPoser v1 encoder mean, eval mode (human_body_prior [upstream]; call site crowd_env_2f.py:198).
+ * BatchNorm layers are folded into fc1 / fc2 by the host.  x: [n,63] with row stride x_ld -> out [n,32]. */
+typedef struct egx_vposer_weights {
+  const float *fc1_w, *fc1_b; /* 512x63  */
+  const float *fc2_w, *fc2_b; /* 512x512 */
+  const float *mu_w, *mu_b;   /* 32x512  */
+} egx_vposer_weights;
+
+size_t egx_vposer_workspace_bytes(int num_rows);
+int egx_vposer_encode(const egx_vposer_weights* w, const float* x, int x_ld, int num_rows, float* out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Vector environment: the per-agent tail of CrowdEnv.step and CrowdEnv.reset
+ * (crowd_ppo/crowd_env_2f.py:78-415, crowd_env_2f_box.py:78-440), batched over A independent agents.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct egx_env_config {   /* cfg_samp20/MPVAEPolicy_samp_collision(_2).yaml fields used by step() */
+  float reproj_factor, goal_thresh, pene_thres;
+  float weight_skate, weight_floor, weight_face_target, weight_look_target, weight_success, weight_target_dist,
+      weight_pene, weight_vp;
+  int max_depth;
+  int scene_kind;               /* 0: SDF scene (crowd_env_2f), 1: box scenes / walkability map (crowd_env_2f_box) */
+  int terminate_on_penetration; /* finetuning (crowd_env_2f.py:299-300) or box env (crowd_env_2f_box.py:325)       */
+  int pene_type_body;           /* lossconfig.pene_type == 'body'                                                 */
+  float ray_len;                /* 7 (2 when rendering), crowd_env_2f.py:556-558                                   */
+} egx_env_config;
+
+typedef struct egx_env_scenes { /* static scene tables, device pointers */
+  const float* edges;      /* [E,4] walkable-polygon ring edges (x0,y0,x1,y1) of all scenes, concatenated */
+  const int32_t* edge_off; /* [S+1] */
+  const float* tris;       /* [F,6] navmesh triangles (x0,y0,x1,y1,x2,y2), box scenes only                */
+  const int32_t* tri_off;  /* [S+1] */
+  const float* floor_height; /* [S] */
+  const float* map_lin;    /* [map_res] = torch.linspace(-extent, extent, res)                            */
+  int map_res;
+} egx_env_scenes;
+
+typedef struct egx_env_state {  /* persistent per-agent state, device pointers, updated in place */
+  float* state;   /* [A,2,402] canonical markers | marker->target unit vectors */
+  float* seed;    /* [A,2,93]  body_param_seed                                  */
+  float* R0;      /* [A,3,3]   canonical frame -> world                         */
+  float* T0;      /* [A,3]                                                      */
+  float* dist;    /* [A]       distance to target at the previous step          */
+  int32_t* steps; /* [A]                                                        */
+  float* wpath;   /* [A,2,3]   start, target (world)                            */
+  int32_t* scene_idx; /* [A] or NULL (single scene); rewritten by egx_env_reset    */
+} egx_env_state;
+
+typedef struct egx_env_step_io {
+  const float* Y_gen;        /* [18,A,201] from egx_sample_prior                       */
+  const float* pred_params;  /* [A,20,93]  from egx_assemble_params                    */
+  const float* joints;       /* [A*20,127,3] from egx_lbs_forward                      */
+  const float* markers_proj; /* [A*20,67,3]                                            */
+  const int32_t* pene_count; /* [A*20] (scene_kind 0) or NULL                          */
+  const float* vp_emb;       /* [A*20,32] from egx_vposer_encode                       */
+  const int32_t* feet_marker_idx; /* [6] main_ppo.py:298-299                           */
+  float* reward;             /* [A]                                                    */
+  int32_t* terminated;       /* [A]                                                    */
+  float* reward_terms;       /* [A,8] skate, floor, face, look, goal, target_dist, pene, vp; or NULL */
+  float* obs_ego;            /* [A,2,32] */
+  float* obs_dist;           /* [A]      */
+  float* obs_time;           /* [A]      */
+  float* out_marker_b;       /* [A,20,67,3] blended markers (save_rollout) or NULL      */
+  float* out_prev_frame;     /* [A,12] R0|T0 before the update (save_rollout) or NULL   */
+} egx_env_step_io;
+
+typedef struct egx_env_reset_io {
+  int num_candidates;        /* K start/target candidates per agent: first accepted wins, last is forced */
+  const int32_t* mask;       /* [A] 1 = reset, or NULL = all                                              */
+  const float* cand_pairs;   /* [A,K,2,3]                                                                 */
+  const float* cand_yaw;     /* [A,K] final yaw jitter (box sampler, environments.py:528-538) or NULL     */
+  const int32_t* cand_variant; /* [A,K] motion-seed variant or NULL                                        */
+  const int32_t* cand_scene; /* [A,K] scene drawn with the candidate (box sampler, environments.py:376-377) or NULL */
+  const int32_t* cand_valid; /* [A,K] precomputed acceptance (SDF start check) or NULL                     */
+  const float* tab_joints;   /* [NV,2,127,3] motion-seed joints at identity global orient, zero transl     */
+  const float* tab_markers;  /* [NV,2,67,3]                                                                */
+  const float* tab_glorot;   /* [NV,2,3,3]  mocap global orient as rotation matrices                       */
+  const float* tab_transl;   /* [NV,2,3]                                                                   */
+  const float* tab_pose;     /* [NV,2,63]                                                                  */
+  float* obs_ego;            /* [A,2,32] */
+  float* obs_dist;           /* [A]      */
+  float* obs_time;           /* [A]      */
+  int32_t* out_choice;       /* [A] index of the committed candidate, or NULL                              */
+} egx_env_reset_io;
+
+/* Yb = cat(seed, Yb_gen) with _blend_params (crowd_env_2f.py:117-123,729-739) -> pred_params [A,20,93] */
+int egx_assemble_params(const float* seed, const float* Yb_gen, int num_agents, float* pred_params, void* stream);
+/* crowd_env_2f.py:151-317 after the SMPL-X call: rewards, termination, re-canonicalisation, features, egosensing */
+int egx_env_step_post(const egx_env_config* cfg, const egx_env_scenes* scenes, const egx_env_state* st,
+                      const egx_env_step_io* io, int num_agents, void* stream);
+/* scene sampler next_body (environments.py:65-335 / 371-627) + CrowdEnv.reset (crowd_env_2f.py:320-415) */
+int egx_env_reset(const egx_env_config* cfg, const egx_env_scenes* scenes, const egx_env_state* st,
+                  const egx_env_reset_io* io, int num_agents, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,3 +40,72 @@ def rel_err(a, b, floor=1e-6):
 
 def max_abs(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+# ---------------------------------------------------------------------------------------------
+# shared synthetic "world" for env / trainer tests
+# ---------------------------------------------------------------------------------------------
+
+def seeded_prior_state_dict(seed=200, pred_gain=0.7, reg_gain=0.6):
+    """Seeded weights for GAMMAPrimitiveCombo (keys of the reference state_dict)."""
+    from egogen_amd.models import GAMMAPrimitiveCombo, PREDICTOR_CFG, REGRESSOR_CFG
+    combo = GAMMAPrimitiveCombo(PREDICTOR_CFG, REGRESSOR_CFG)
+    sd = combo.state_dict()
+    pk = {k: tuple(v.shape) for k, v in sd.items() if k.startswith("predictor.")}
+    rk = {k: tuple(v.shape) for k, v in sd.items() if k.startswith("regressor.")}
+    out = {k: torch.from_numpy(v) for k, v in seeded_fill(pk, seed, gain=pred_gain).items()}
+    out.update({k: torch.from_numpy(v) for k, v in seeded_fill(rk, seed + 1, gain=reg_gain).items()})
+    return out
+
+
+def seeded_vposer_state_dict(seed=210):
+    from egogen_amd.models import VPoserEncoder
+    enc = VPoserEncoder()
+    vals = seeded_fill({k: tuple(v.shape) for k, v in enc.state_dict().items()}, seed)
+    out = {k: torch.from_numpy(v) for k, v in vals.items()}
+    for k in list(out):
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.tensor(0)
+    return out
+
+
+def build_world(V=1536, A=6, scene_kind="sdf", sdf_res=48, n_pairs=64, n_scenes=4, finetuning=False, gpu=True, seed=0):
+    """Body model + scene + nets, as a GPU VecCrowdEnv (if gpu) and the CPU OracleCrowdEnv on the same assets."""
+    from egogen_amd import synth
+    from oracle.env import OracleCrowdEnv
+    from oracle.smplx_lbs import BodyModel
+    bm = synth.make_body_model(seed, num_verts=V)
+    mk, feet, fmi = synth.marker_ids(V), synth.feet_vids(V), synth.feet_marker_idx()
+    prior_sd, vposer_sd = seeded_prior_state_dict(), seeded_vposer_state_dict()
+    w = {"bm": bm, "mk": mk, "feet": feet, "prior_sd": prior_sd, "vposer_sd": vposer_sd, "A": A}
+    rng = np.random.default_rng(seed + 5)
+    if scene_kind == "sdf":
+        scene = synth.make_sdf_scene(sdf_res)
+        rings = synth.sdf_scene_polygon(scene)
+        pairs = np.zeros((n_pairs, 2, 3), np.float32)
+        pairs[:, :, :2] = rng.uniform(-3.0, 3.0, (n_pairs, 2, 2))
+        w.update(scene=scene, rings=rings, pairs=pairs)
+        sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
+        okw = dict(scene_kind="sdf", sdf_dict=sd, edges=synth.rings_to_edges(rings))
+        gkw = dict(scene_kind="sdf", sdf_dict=scene, rings=rings, pairs=pairs)
+    else:
+        scenes = synth.make_box_scenes(n_scenes, n_pairs, seed=seed + 7)
+        w.update(box_scenes=scenes)
+        okw = dict(scene_kind="box", box_scenes=scenes)
+        gkw = dict(scene_kind="box", box_scenes=scenes)
+    w["oracle"] = OracleCrowdEnv(BodyModel(bm), prior_sd, {k: v.float() for k, v in vposer_sd.items()}, mk, feet, fmi,
+                                 finetuning=finetuning, **okw)
+    if gpu:
+        from egogen_amd.body_model import BodyModelHandle
+        from egogen_amd.crowd_env import VecCrowdEnv
+        from egogen_amd.models import GAMMAPrimitiveCombo, PREDICTOR_CFG, REGRESSOR_CFG, VPoserEncoder
+        h = BodyModelHandle(bm, mk, feet)
+        combo = GAMMAPrimitiveCombo(PREDICTOR_CFG, REGRESSOR_CFG)
+        combo.load_state_dict(prior_sd)
+        combo.cuda().eval()
+        vp = VPoserEncoder()
+        vp.load_state_dict(vposer_sd)
+        vp.cuda().eval()
+        w["env"] = VecCrowdEnv(A, h, combo, vp, finetuning=finetuning, seed=seed, **gkw)
+        w["handle"] = h
+    return w

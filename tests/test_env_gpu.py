@@ -1,0 +1,199 @@
+"""GPU parity of the batched CrowdEnv (reset + step, SDF and box scenes) against the CPU oracle,
+through the C ABI.  Tolerance: north_star's 1e-4 relative fp32 (absolute floor stated per quantity)."""
+import numpy as np
+import pytest
+import torch
+
+from egogen_amd import synth
+from tests.helpers import build_world, max_abs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _close(a, b, tol=TOL, what=""):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol * scale:.3e}"
+
+
+def _seed_inputs(env, A, variant):
+    ms = env.motion_seed
+    starts = [env.variant_starts[v] for v in variant]
+    poses = torch.tensor(np.stack([ms["poses"][s:s + 2, :66] for s in starts]), dtype=torch.float32)
+    trans = torch.tensor(np.stack([ms["trans"][s:s + 2] for s in starts]), dtype=torch.float32)
+    betas = torch.tensor(ms["betas"], dtype=torch.float32).reshape(1, 10).repeat(A, 1)
+    return poses, trans, betas
+
+
+def _oracle_reset(w, pairs, variant, yaw=None, scene=None):
+    env, o, A = w["env"], w["oracle"], w["A"]
+    poses, trans, betas = _seed_inputs(env, A, variant)
+    start, target = torch.as_tensor(pairs[:, 0]), torch.as_tensor(pairs[:, 1])
+    tr, go, bp, wpath = o.next_body(start, target, poses, trans, betas, yaw_jitter=None if yaw is None else torch.as_tensor(yaw))
+    return o.reset_from(tr, go, bp, betas, wpath, scene_idx=scene)
+
+
+def _sync_oracle_from_gpu(w):
+    env, o = w["env"], w["oracle"]
+    o.set_state(env.state.cpu(), env.seed.cpu(), env.R0.cpu(), env.T0.cpu().reshape(-1, 1, 3), env.betas.cpu(), env.dist.cpu(),
+                env.steps.cpu(), env.wpath.cpu(), env.scene_idx.cpu())
+
+
+def _compare_state(w, tol=TOL):
+    env, o = w["env"], w["oracle"]
+    _close(env.state, o.state, tol, "state")
+    _close(env.seed[..., :3], o.body_param_seed[..., :3], tol, "seed transl")
+    _close(env.seed[..., 6:], o.body_param_seed[..., 6:], tol, "seed pose")
+    from oracle.rot import tgm_angle_axis_to_rotation_matrix as aa2R
+    _close(aa2R(env.seed[..., 3:6].reshape(-1, 3).cpu()), aa2R(o.body_param_seed[..., 3:6].reshape(-1, 3)), tol, "seed glorot")
+    _close(env.R0, o.R0, tol, "R0")
+    _close(env.T0, o.T0.reshape(-1, 3), tol, "T0")
+    _close(env.dist, o.dist, tol, "dist")
+    _close(env.wpath, o.wpath, tol, "wpath")
+
+
+def test_reset_sdf_matches_oracle():
+    w = build_world(A=5, scene_kind="sdf")
+    env = w["env"]
+    pairs = w["pairs"][:5]
+    env.set_candidates(pairs.reshape(5, 1, 2, 3))
+    obs = env.reset()
+    oobs, accept = _oracle_reset(w, pairs, [0] * 5)
+    _compare_state(w)
+    _close(obs["egosensing"], oobs["egosensing"], 1e-5, "egosensing")
+    _close(obs["dist"], oobs["dist"].reshape(-1), TOL, "obs dist")
+    assert torch.all(obs["time"] == 1)
+    # the pre-validated acceptance mask equals the oracle's start check
+    assert env.pair_valid_mask[:5].cpu().tolist() == accept.tolist()
+
+
+def test_prevalidation_matches_oracle_on_more_pairs():
+    w = build_world(A=2, scene_kind="sdf", n_pairs=24)
+    env, o = w["env"], w["oracle"]
+    n = 24
+    poses, trans, betas = _seed_inputs(env, n, [0] * n)
+    pairs = w["pairs"]
+    tr, go, bp, wpath = o.next_body(torch.as_tensor(pairs[:, 0]), torch.as_tensor(pairs[:, 1]), poses, trans, betas)
+    _, accept = o.reset_from(tr, go, bp, betas, wpath)
+    got = env.pair_valid_mask.cpu()
+    assert accept.any() and (~accept).any(), "fixture should contain both accepted and rejected starts"
+    assert got.tolist() == accept.tolist()
+
+
+@pytest.mark.parametrize("finetuning", [False, True])
+def test_step_sdf_matches_oracle(finetuning):
+    A = 6
+    w = build_world(A=A, scene_kind="sdf", finetuning=finetuning)
+    env, o = w["env"], w["oracle"]
+    env.set_candidates(env.valid_pairs[:A].reshape(A, 1, 2, 3))
+    env.reset()
+    g = torch.Generator().manual_seed(3)
+    for it in range(3):
+        _sync_oracle_from_gpu(w)
+        z = torch.randn(A, 128, generator=g)
+        obs, rew, term = env.step(z.cuda(), auto_reset=False)
+        oobs, orew, oterm = o.step(z)
+        L = o.last
+        _close(env.Y_gen, L["Y_gen"], TOL, "Y_gen (marker trajectories)")
+        _close(env.pred_params[..., :3], L["pred_params"][..., :3], 2e-4, "pred transl")
+        _close(env.joints.reshape(A, 20, -1, 3), L["joints"], 2e-4, "SMPL-X joints")
+        _close(env.markers.reshape(A, 20, -1, 3), L["markers_proj"], 2e-4, "projected markers")
+        names = ["r_skate", "r_floor", "r_face", "r_look", "r_goal", "r_target_dist", "r_pene", "r_vp"]
+        for i, nme in enumerate(names):
+            if nme == "r_pene":
+                continue
+            _close(env.rterms[:, i], L[nme], 2e-4, nme)
+        # integer penetration counts: exact up to vertices within round-off of the zero level set
+        dcnt = (env.pene_count.reshape(A, 20).cpu().long() - L["pene_count"]).abs()
+        assert dcnt.max() <= 3, dcnt.max()
+        _close(env.rterms[:, 6], L["r_pene"], 2e-3, "r_pene")
+        _close(rew, orew, 3e-3, "reward")
+        assert term.cpu().bool().tolist() == oterm.tolist()
+        _compare_state(w, 3e-4)
+        _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
+        _close(obs["dist"], oobs["dist"].reshape(-1), 2e-4, "obs dist")
+        _close(obs["time"], oobs["time"].reshape(-1), 1e-6, "obs time")
+
+
+def test_reset_and_step_box_match_oracle():
+    A = 5
+    w = build_world(A=A, scene_kind="box", n_pairs=32, n_scenes=3)
+    env, o = w["env"], w["oracle"]
+    K = env.K
+    rng = np.random.default_rng(0)
+    scene = rng.integers(0, 3, (A, K))
+    pidx = rng.integers(0, 32, (A, K))
+    pairs = np.stack([[w["box_scenes"][scene[a, k]]["pairs"][pidx[a, k]] for k in range(K)] for a in range(A)])
+    variant = rng.integers(0, len(env.variant_starts), (A, K))
+    yaw = rng.uniform(-1, 1, (A, K)).astype(np.float32) * 2 * np.pi * 0.1
+    env.set_candidates(pairs, yaw, variant, scene)
+    obs = env.reset()
+    choice = env.choice.cpu().numpy()
+    # oracle evaluates every candidate; the first accepted (or the last) must be the one the kernel committed
+    sel = []
+    for a in range(A):
+        acc_k = None
+        for k in range(K):
+            w1 = dict(w, A=1)
+            oo = w["oracle"]
+            poses, trans, betas = _seed_inputs(env, 1, [variant[a, k]])
+            tr, go, bp, wp = oo.next_body(torch.as_tensor(pairs[a, k, 0:1]), torch.as_tensor(pairs[a, k, 1:2]), poses, trans, betas,
+                                          yaw_jitter=torch.as_tensor(yaw[a, k:k + 1]))
+            _, accept = oo.reset_from(tr, go, bp, betas, wp, scene_idx=[scene[a, k]])
+            if bool(accept[0]) or k == K - 1:
+                acc_k = k
+                break
+        sel.append(acc_k)
+    assert choice.tolist() == sel
+    ka = np.array(sel)
+    ar = np.arange(A)
+    oobs, _ = _oracle_reset(w, pairs[ar, ka], variant[ar, ka], yaw[ar, ka], scene[ar, ka])
+    _compare_state(w)
+    assert env.scene_idx.cpu().tolist() == scene[ar, ka].tolist()
+    _close(obs["egosensing"], oobs["egosensing"], 1e-5, "egosensing")
+    g = torch.Generator().manual_seed(5)
+    for it in range(2):
+        _sync_oracle_from_gpu(w)
+        z = torch.randn(A, 128, generator=g)
+        obs, rew, term = env.step(z.cuda(), auto_reset=False)
+        oobs, orew, oterm = o.step(z)
+        _close(env.rterms[:, 6], o.last["r_pene"], 1e-6, "r_pene (box)")
+        _close(rew, orew, 3e-4, "reward")
+        assert term.cpu().bool().tolist() == oterm.tolist()
+        _compare_state(w, 3e-4)
+        _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
+
+
+def test_graph_replay_equals_eager():
+    A = 4
+    w = build_world(A=A, scene_kind="sdf")
+    env = w["env"]
+    env.set_candidates(env.valid_pairs[:A].reshape(A, 1, 2, 3))
+    env.reset()
+    snap = {k: getattr(env, k).clone() for k in ("state", "seed", "R0", "T0", "dist", "steps", "wpath")}
+    z = torch.randn(A, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    env.step(z, auto_reset=False)
+    eager = {k: getattr(env, k).clone() for k in ("state", "seed", "R0", "T0", "dist", "reward", "terminated", "obs_ego")}
+    for k, v in snap.items():
+        getattr(env, k).copy_(v)
+    env.use_graph = True
+    env.step(z, auto_reset=False)
+    torch.cuda.synchronize()
+    for k, v in eager.items():
+        assert torch.equal(getattr(env, k), v), k
+
+
+def test_auto_reset_reinitialises_finished_agents():
+    A = 8
+    w = build_world(A=A, scene_kind="sdf")
+    env = w["env"]
+    env.reset()
+    env.steps.fill_(env.cfg["max_depth"] - 1)  # next step hits max_depth -> all terminate
+    z = torch.zeros(A, 128, device="cuda")
+    obs, rew, term = env.step(z)
+    assert term.sum().item() == A
+    assert env.steps.sum().item() == 0 and torch.all(obs["time"] == 1)

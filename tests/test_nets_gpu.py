@@ -1,0 +1,131 @@
+"""GPU parity of the network kernels (through the C ABI) vs reference goldens and the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_golden, max_abs, rebuild_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _linear(segs, W, b, act=0, slope=0.0, res=None):
+    from egogen_amd import _lib
+    lib = _lib.load()
+    M, N = segs[0].shape[0], W.shape[0]
+    out = torch.empty(M, N, device="cuda")
+    d = _lib.LinearDesc()
+    d.num_rows, d.out_features, d.num_segments = M, N, len(segs)
+    for i, s in enumerate(segs):
+        d.seg_ptr[i], d.seg_width[i], d.seg_ld[i] = s.data_ptr(), s.shape[1], s.stride(0)
+    d.weight, d.weight_ld, d.bias = W.data_ptr(), 0, (b.data_ptr() if b is not None else None)
+    d.residual, d.residual_ld = (res.data_ptr() if res is not None else None), (res.stride(0) if res is not None else 0)
+    d.out, d.out_ld, d.activation, d.leaky_slope = out.data_ptr(), 0, act, slope
+    _lib.check(lib.egx_linear(C.byref(d), _lib.current_stream_ptr()), "egx_linear")
+    return out
+
+
+@pytest.mark.parametrize("M,widths,N,act", [(5, [201], 768, 0), (64, [256, 128, 201], 768, 1), (333, [201, 159, 10], 128, 2),
+                                            (512, [512, 512, 64, 64], 1152, 3), (1, [7], 3, 0), (40, [1152], 1, 0)])
+def test_linear_kernel(M, widths, N, act):
+    g = torch.Generator().manual_seed(M + N)
+    big = [torch.randn(M, w + 5, generator=g).cuda() for w in widths]   # padded rows: exercise ld != width
+    segs = [b[:, 2:2 + w] for b, w in zip(big, widths)]                 # and 8-byte-misaligned starts
+    K = sum(widths)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    out = _linear(segs, W, b, act, 0.2, res)
+    x = torch.cat([s.double() for s in segs], 1)
+    ref = x @ W.double().t() + b.double()
+    ref = [ref, torch.tanh(ref), torch.relu(ref), torch.nn.functional.leaky_relu(ref, 0.2)][act] + res.double()
+    assert max_abs(out.cpu(), ref.cpu()) < 2e-5
+
+
+def _combo():
+    from egogen_amd.models import GAMMAPrimitiveCombo, PREDICTOR_CFG, REGRESSOR_CFG
+    return GAMMAPrimitiveCombo(PREDICTOR_CFG, REGRESSOR_CFG)
+
+
+def test_state_dict_keys_match_reference():
+    from egogen_amd.models import ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase, POLICY_CFG
+    combo = _combo()
+    g = load_golden("cvae_ref.npz")
+    assert ["predictor." + str(k) for k in g["state_dict_keys"]] == [k for k in combo.state_dict() if k.startswith("predictor.")]
+    g = load_golden("regressor_ref.npz")
+    assert ["regressor." + str(k) for k in g["state_dict_keys"]] == [k for k in combo.state_dict() if k.startswith("regressor.")]
+    g = load_golden("policy_ref.npz")
+    ac = ActorCritic(GAMMAActor(POLICY_CFG), GAMMACritic(POLICY_CFG), GAMMAPolicyBase(POLICY_CFG))
+    assert set(str(k) for k in g["state_dict_keys"]) == set(ac.state_dict().keys())
+    assert sum(p.numel() for p in ac.parameters()) == 13168001
+
+
+def test_cvae_decode_matches_reference_golden():
+    g = load_golden("cvae_ref.npz")
+    sd = rebuild_state_dict(g, [g["fill_seed"]], [""])
+    combo = _combo()
+    combo.predictor.load_state_dict(sd, strict=True)
+    combo.cuda()
+    X, z = torch.from_numpy(g["X"]).cuda(), torch.from_numpy(g["z"]).cuda()
+    Y, Yb = combo.sample_prior(X, torch.zeros(18, 5, 10, device="cuda"), z)
+    assert Y.shape == (18, 5, 201) and Yb.shape == (18, 5, 93)
+    assert max_abs(Y.cpu(), g["Y"]) < 1e-4 * max(1.0, np.abs(g["Y"]).max())
+
+
+def test_sample_prior_matches_oracle():
+    from oracle import nets
+    g1, g2 = load_golden("cvae_ref.npz"), load_golden("regressor_ref.npz")
+    sd = {"predictor." + k: v for k, v in rebuild_state_dict(g1, [g1["fill_seed"]], [""]).items()}
+    sd.update({"regressor." + k: v for k, v in rebuild_state_dict(g2, [g2["fill_seed"]], [""], gains=[float(g2["fill_gain"])]).items()})
+    combo = _combo()
+    combo.load_state_dict(sd, strict=True)
+    combo.cuda()
+    gen = torch.Generator().manual_seed(7)
+    A = 37  # ragged: not a multiple of 32
+    X = torch.randn(2, A, 201, generator=gen) * 0.3
+    z = torch.randn(A, 128, generator=gen)
+    betas = torch.randn(A, 10, generator=gen)
+    Y, Yb = combo.sample_prior(X.cuda(), betas[None].repeat(18, 1, 1).cuda(), z.cuda())
+    Yo, Ybo = nets.sample_prior(sd, X, betas[None].repeat(18, 1, 1), z)
+    assert max_abs(Y.cpu(), Yo) < 1e-4 * max(1.0, float(Yo.abs().max()))
+    # the regressed rotations are compared as rotation matrices (axis-angle is discontinuous at pi)
+    from oracle.rot import tgm_angle_axis_to_rotation_matrix as aa2R
+    assert max_abs(Yb.cpu()[..., :3], Ybo[..., :3]) < 2e-4 * max(1.0, float(Ybo[..., :3].abs().max()))
+    assert max_abs(aa2R(Yb.cpu()[..., 3:69].reshape(-1, 3)), aa2R(Ybo[..., 3:69].reshape(-1, 3))) < 2e-4
+    assert max_abs(Yb.cpu()[..., 69:], Ybo[..., 69:]) < 2e-4 * max(1.0, float(Ybo[..., 69:].abs().max()))
+
+
+def test_policy_matches_reference_golden():
+    from egogen_amd.models import (ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase, POLICY_CFG, PolicyHipRunner)
+    g = load_golden("policy_ref.npz")
+    sd = rebuild_state_dict(g, g["fill_seeds"], ["shared_net.", "actor.", "critic."], gains=[1.0, 1.4, 1.4])
+    ac = ActorCritic(GAMMAActor(POLICY_CFG), GAMMACritic(POLICY_CFG), GAMMAPolicyBase(POLICY_CFG))
+    ac.load_state_dict(sd, strict=True)
+    ac.cuda()
+    obs = {k[4:]: torch.from_numpy(v).cuda() for k, v in g.items() if k.startswith("obs_")}
+    out = PolicyHipRunner(ac.shared_net, ac.actor, ac.critic).forward(obs)
+    for k, ref in (("mu", g["mu"]), ("logvar", g["logvar"]), ("value", g["value"].reshape(-1))):
+        assert max_abs(out[k].cpu(), ref) < 1e-4 * max(1.0, np.abs(ref).max()), k
+    # the autograd (update) path computes the same function
+    hx = ac.shared_net(obs)
+    (mu, lv), _ = ac.actor(hx)
+    assert max_abs(mu.detach().cpu(), g["mu"]) < 1e-4 * max(1.0, np.abs(g["mu"]).max())
+    assert max_abs(hx.detach().cpu(), g["hx"]) < 2e-5
+
+
+def test_vposer_encoder_matches_oracle():
+    from egogen_amd.models import VPoserEncoder
+    from egogen_amd.synth import seeded_fill
+    from oracle import nets
+    enc = VPoserEncoder().eval()
+    vals = seeded_fill({k: tuple(v.shape) for k, v in enc.state_dict().items()}, 105)
+    vals = {k: torch.from_numpy(v) for k, v in vals.items()}
+    vals["bodyprior_enc_bn1.num_batches_tracked"] = torch.tensor(0)
+    vals["bodyprior_enc_bn2.num_batches_tracked"] = torch.tensor(0)
+    enc.load_state_dict(vals)
+    enc.cuda()
+    x = torch.randn(100, 63, generator=torch.Generator().manual_seed(1)) * 0.3
+    out = enc.encode_mean(x.cuda())
+    ref = nets.vposer_encode({k: v.float() for k, v in vals.items()}, x)
+    assert max_abs(out.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max()))
