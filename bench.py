@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Benchmark of the crowd_ppo hot path: PPO env-steps/sec (BASELINE.json metric).
+
+One "step" = one on-policy cycle over one batch of synthetic input:
+    collect  n_vec vector steps of A agents (policy forward + action sampling, C-VAE decode + regressor, SMPL-X
+             forward on A*20 bodies with fused SDF counting, VPoser encoder, reward/feature/egosensing kernel,
+             auto-reset)                                                          -> n_vec * A transitions
+    update   critic values + GAE, then all minibatches of the clipped-PPO update (AdamW, grad-norm clip)
+value = transitions of all ranks / wall time of K such steps (max over ranks), inputs resident in HBM.
+
+Workload (BASELINE.json: metric quoted on 512 parallel SMPL-X agents; configs[1]/[2]): A = 512 agents per GPU,
+synthetic seeded SMPL-X-shaped body (V = 10475), single-box SDF scene 256^3 by default (`--scene box` = random-box
+scene set with the walkability-map penetration term), random-init networks, 4 vector steps per collect (2048
+transitions), minibatch 256 per rank -> 8 optimiser steps per collect, repeat 1.
+
+N > 1 (weak scaling): every rank owns A agents and its own scene replica; the only collectives are the
+advantage-moment all-reduce (3 doubles) and one flat 52.7 MB gradient all-reduce per optimiser step.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = egx_lbs_fused_kernel (fp32-MFMA blend GEMM + skinning + SDF epilogue);
+                achieved = 2*496*31425 FLOP/body * bodies per launch / average launch duration measured with HIP events
+                recorded around that kernel inside the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md)
+  cpu_baseline  the CPU oracle (port of the reference's per-agent, x4-replicated structure) timed on the host cores
+                on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_BODY = 2.0 * 496 * 31425          # blend GEMM only (K = 10 betas + 486 pose features)
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def get_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=6)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--agents", type=int, default=512, help="agents per GPU")
+    p.add_argument("--scene", type=str, default="single_box", choices=["single_box", "room0", "box"])
+    p.add_argument("--sdf-res", type=int, default=256)
+    p.add_argument("--vec-steps", type=int, default=4, help="vector steps per collect")
+    p.add_argument("--batch-size", type=int, default=256, help="minibatch per rank")
+    p.add_argument("--num-verts", type=int, default=10475)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-agent-steps", type=int, default=6)
+    p.add_argument("--graph", type=int, default=0, help="capture the env step into a HIP graph")
+    return p.parse_args()
+
+
+class PolicyArgs:
+    seed = 0
+    lr = 3e-4
+    gamma = 0.99
+    gae_lambda = 0.95
+    max_grad_norm = 0.1
+    vf_coef = 1.0
+    ent_coef = 0.01
+    weight_kld = 0
+    rew_norm = False
+    eps_clip = 0.1
+    value_clip = 0
+    dual_clip = None
+    norm_adv = 1
+    recompute_adv = 0
+    deterministic_eval = False
+
+
+def cpu_baseline(args, scene, n_agent_steps):
+    """Reference-structured CPU path (oracle): one agent at a time, batch replicated x4 (crowd_env_2f.py:29-32), host ray
+    casting, plus the CPU cost of the PPO update per transition."""
+    from egogen_amd import synth
+    from egogen_amd.models import (ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase, GAMMAPrimitiveCombo, POLICY_CFG,
+                                   PREDICTOR_CFG, REGRESSOR_CFG, VPoserEncoder)
+    from oracle.env import OracleCrowdEnv
+    from oracle.smplx_lbs import BodyModel
+    from oracle import nets as onets, ppo as oppo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    V = args.num_verts
+    bm = synth.make_body_model(0, num_verts=V)
+    torch.manual_seed(0)
+    combo = GAMMAPrimitiveCombo(PREDICTOR_CFG, REGRESSOR_CFG)
+    vp = VPoserEncoder().eval()
+    psd = {k: v.detach() for k, v in combo.state_dict().items()}
+    vsd = {k: v.detach().float() for k, v in vp.state_dict().items()}
+    if scene["scene_kind"] == "sdf":
+        sd = {k: torch.as_tensor(np.asarray(scene["sdf_dict"][k])) for k in ("sdf", "center", "scale")}
+        okw = dict(scene_kind="sdf", sdf_dict=sd, edges=synth.rings_to_edges(scene["rings"]))
+        pairs = np.asarray(scene["pairs"][:n_agent_steps], np.float32)
+    else:
+        okw = dict(scene_kind="box", box_scenes=scene["box_scenes"])
+        pairs = np.asarray(scene["box_scenes"][0]["pairs"][:n_agent_steps], np.float32)
+    o = OracleCrowdEnv(BodyModel(bm), psd, vsd, synth.marker_ids(V), synth.feet_vids(V), synth.feet_marker_idx(), **okw)
+    ms = synth.load_assets()
+    rep = 4
+    poses = torch.tensor(ms["seed_poses"][5:7, :66], dtype=torch.float32)[None].repeat(rep, 1, 1)
+    trans = torch.tensor(ms["seed_trans"][5:7], dtype=torch.float32)[None].repeat(rep, 1, 1)
+    betas = torch.tensor(ms["seed_betas"], dtype=torch.float32).reshape(1, 10).repeat(rep, 1)
+    ac = ActorCritic(GAMMAActor(POLICY_CFG), GAMMACritic(POLICY_CFG), GAMMAPolicyBase(POLICY_CFG))
+    pol_sd = {k: v.detach() for k, v in ac.state_dict().items()}
+    t_env = 0.0
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for i in range(n_agent_steps):
+            st = torch.as_tensor(pairs[i:i + 1, 0]).repeat(rep, 1)
+            tg = torch.as_tensor(pairs[i:i + 1, 1]).repeat(rep, 1)
+            t0 = time.perf_counter()
+            tr, go, bp, wp = o.next_body(st, tg, poses, trans, betas,
+                                         yaw_jitter=None if scene["scene_kind"] == "sdf" else torch.zeros(rep))
+            obs, _ = o.reset_from(tr, go, bp, betas, wp, scene_idx=None if scene["scene_kind"] == "sdf" else [0] * rep)
+            t_reset = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            hx = onets.policy_base(pol_sd, obs)
+            mu, lv = onets.policy_actor(pol_sd, hx)
+            onets.policy_critic(pol_sd, hx)
+            z = mu + torch.exp(lv.clamp(-2.5, 2.5)) ** 0.5 * torch.randn(rep, 128, generator=g)
+            o.step(z)
+            t_env += time.perf_counter() - t0 + t_reset / 11.0   # one reset per ~max_depth steps
+    per_step = t_env / n_agent_steps
+    # PPO update cost per transition: one minibatch of 256 forward+backward+AdamW on the CPU
+    ac.train()
+    opt = torch.optim.AdamW(ac.parameters(), lr=3e-4, weight_decay=0.01)
+    B = 256
+    obs = {"state": torch.randn(B, 2, 402), "egosensing": torch.rand(B, 2, 32), "dist": torch.rand(B), "time": torch.rand(B)}
+    act, adv, ret, lpo = torch.randn(B, 128), torch.randn(B), torch.randn(B), torch.randn(B) - 180
+    t0 = time.perf_counter()
+    hx = ac.shared_net(obs)
+    (mu, lv), _ = ac.actor(hx)
+    loss, _ = oppo.ppo_loss(mu, lv, ac.critic(hx), act, adv, ret, lpo)
+    opt.zero_grad()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(list(ac.actor.parameters()) + list(ac.critic.parameters()), 0.1)
+    opt.step()
+    per_trans_update = (time.perf_counter() - t0) / B
+    return {"value": 1.0 / (per_step + per_trans_update), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_agent_steps} agent-steps of the oracle env (V={V}, batch x4 per agent as in the reference, "
+                      f"{per_step * 1e3:.0f} ms each) + one 256-sample PPO minibatch on CPU ({per_trans_update * 1e3:.2f} ms/transition)"}
+
+
+def main():
+    args = get_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from egogen_amd import _lib, setup_world as sw, synth
+    from egogen_amd.body_model import BodyModelHandle
+    from egogen_amd.trainer import Collector
+    lib = _lib.load()
+
+    A = args.agents
+    pa = PolicyArgs()
+    bm, _ = sw.load_body_model("male", seed=0, num_verts=args.num_verts)
+    body = BodyModelHandle(bm, synth.marker_ids(args.num_verts), synth.feet_vids(args.num_verts))
+    prior = sw.build_motion_prior(seed=0)
+    vposer = sw.build_vposer(seed=0)
+    scene = sw.build_scene(args.scene, sdf_res=args.sdf_res, seed=0)
+    env = sw.build_env(A, scene, body, prior, vposer, seed=rank, use_graph=bool(args.graph))
+    policy = sw.build_policy(pa)
+    policy.train()
+    collector = Collector(policy, env)
+    collector.reset()
+    n_vec = args.vec_steps
+    global_bs = args.batch_size * world
+
+    def one_step():
+        batch = collector.collect(n_vec)
+        policy.process_fn(batch)
+        return policy.learn(batch, global_bs, 1)
+
+    for _ in range(args.warmup):
+        one_step()
+
+    # HIP events around the fused LBS kernel of every vector step in the timed region
+    n_ev = args.steps * n_vec
+    evs = []
+    for _ in range(n_ev):
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.egx_event_create(C.byref(e0)), "event")
+        _lib.check(lib.egx_event_create(C.byref(e1)), "event")
+        evs.append((e0, e1))
+    env.profile_events = list(evs)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_list = []
+    for e0, e1 in evs:
+        ms = C.c_float()
+        _lib.check(lib.egx_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
+        ms_list.append(ms.value)
+        lib.egx_event_destroy(e0)
+        lib.egx_event_destroy(e1)
+    lbs_ms = float(np.mean(ms_list))
+    bodies = A * 20
+    achieved = FLOP_PER_BODY * bodies / (lbs_ms * 1e-3) / 1e12
+
+    transitions = args.steps * n_vec * A * world
+    result = {
+        "metric": "PPO env-steps/sec (512 parallel SMPL-X agents per GPU)",
+        "value": transitions / elapsed,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"crowd_ppo PPO loop: {A} agents/GPU, scene={args.scene}"
+                               f"{'' if args.scene == 'box' else f' SDF {args.sdf_res}^3'}, synthetic SMPL-X body V={args.num_verts}, "
+                               f"{n_vec} vector steps/collect ({n_vec * A} transitions/GPU), minibatch {args.batch_size}/GPU, repeat 1",
+                   "agents_per_gpu": A, "scene": args.scene, "vec_steps_per_collect": n_vec, "minibatch_per_gpu": args.batch_size,
+                   "parallelism": f"dp{world}" if world > 1 else "single", "hip_graph": bool(args.graph)},
+        "roofline": {"bound": "mfma", "kernel": "egx_lbs_fused_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
+                     "flop_per_body": FLOP_PER_BODY},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, scene, args.cpu_agent_steps)
+        except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+            result["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
+                                      "sample": f"failed: {type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

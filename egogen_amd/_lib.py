@@ -123,6 +123,14 @@ SIGNATURES = {
                                     C.c_int, C.c_void_p]),
     "egx_env_reset": (C.c_int, [C.POINTER(EnvConfig), C.POINTER(EnvScenes), C.POINTER(EnvState), C.POINTER(EnvResetIO),
                                 C.c_int, C.c_void_p]),
+    "egx_sample_action": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "egx_gae": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p,
+                          C.c_void_p, C.c_void_p]),
+    "egx_profile_next_lbs": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "egx_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "egx_event_destroy": (C.c_int, [C.c_void_p]),
+    "egx_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "egx_vposer_workspace_bytes": (C.c_size_t, [C.c_int]),
     "egx_vposer_encode": (C.c_int, [C.POINTER(VposerWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),

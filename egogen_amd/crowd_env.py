@@ -180,6 +180,7 @@ class VecCrowdEnv:
         self.prior._weights()
         self._graph = None
         self._injected = False
+        self.profile_events = []  # [(start_event, stop_event)] consumed one pair per step (bench.py)
 
         self.valid_pairs = None
         if scene_kind == "sdf":
@@ -314,6 +315,9 @@ class VecCrowdEnv:
         _lib.check(lib.egx_assemble_params(_lib.ptr(self.seed), _lib.ptr(self.Yb_gen), A, _lib.ptr(self.pred_params), st),
                    "egx_assemble_params")
         # SMPL-X on A*20 bodies; SDF counts fused (crowd_env_2f.py:133-175)
+        if self.profile_events:
+            ev0, ev1 = self.profile_events.pop(0)
+            _lib.check(lib.egx_profile_next_lbs(ev0, ev1), "egx_profile_next_lbs")
         self.bm.forward(self.pred_params.reshape(A * 20, 93), self.betas, 20, want_verts=False,
                         sdf=self.sdf, R0=self.R0 if self.sdf is not None else None,
                         T0=self.T0 if self.sdf is not None else None, out=self._lbs_out)

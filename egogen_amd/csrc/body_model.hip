@@ -28,6 +28,30 @@ void egx_set_error(const std::string& msg) { g_last_error = msg; }
 extern "C" const char* egx_last_error(void) { return g_last_error.c_str(); }
 extern "C" int egx_version(void) { return 1; }
 
+static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+extern "C" int egx_event_create(void** out_event) {
+  EGX_REQUIRE(out_event, "null argument");
+  hipEvent_t e;
+  EGX_HIP_CHECK(hipEventCreate(&e));
+  *out_event = e;
+  return EGX_OK;
+}
+extern "C" int egx_event_destroy(void* event) {
+  if (event) EGX_HIP_CHECK(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return EGX_OK;
+}
+extern "C" int egx_event_elapsed_ms(void* start_event, void* stop_event, float* out_ms) {
+  EGX_REQUIRE(start_event && stop_event && out_ms, "null argument");
+  EGX_HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(stop_event)));
+  EGX_HIP_CHECK(hipEventElapsedTime(out_ms, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event)));
+  return EGX_OK;
+}
+extern "C" int egx_profile_next_lbs(void* start_event, void* stop_event) {
+  g_prof_start = static_cast<hipEvent_t>(start_event);
+  g_prof_stop = static_cast<hipEvent_t>(stop_event);
+  return EGX_OK;
+}
+
 namespace {
 
 constexpr int NJ = EGX_NUM_JOINTS;
@@ -576,6 +600,9 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     const int per = (p.nbg + 7) / 8;
     const int grid = (p.nbg >= 8) ? 8 * per * m->NVT : p.nbg * m->NVT;
     const size_t lds = out_verts ? 4 * 32 * 97 * sizeof(float) : 0;
+    hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
+    g_prof_start = g_prof_stop = nullptr;
+    if (ev0) EGX_HIP_CHECK(hipEventRecord(ev0, stream));
     if (out_verts && sdf)
       hipLaunchKernelGGL((egx_lbs_fused_kernel<true, true>), dim3(grid), dim3(256), lds, stream, p);
     else if (out_verts)
@@ -584,6 +611,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
       hipLaunchKernelGGL((egx_lbs_fused_kernel<false, true>), dim3(grid), dim3(256), lds, stream, p);
     else
       hipLaunchKernelGGL((egx_lbs_fused_kernel<false, false>), dim3(grid), dim3(256), lds, stream, p);
+    if (ev1) EGX_HIP_CHECK(hipEventRecord(ev1, stream));
   }
   if (need_picks)
     hipLaunchKernelGGL(egx_gather_kernel, dim3(B), dim3(256), 0, stream, picked, B, m->NP, m->M, m->marker_slot,

@@ -184,6 +184,51 @@ __global__ void egx_posenc_kernel(const float* __restrict__ dist, const float* _
   out[idx] = (c & 1) ? cosf(f) : sinf(f);
 }
 
+// GAMMAPPOPolicy.forward tail (crowd_ppo/ppo_policy.py:169-178): clamp logvar, sigma = exp(logvar)^0.5,
+// act = mu + sigma * eps (Normal.sample with injected standard-normal noise), log-prob of Independent(Normal,1).
+__global__ void egx_sample_action_kernel(const float* __restrict__ mu, float* __restrict__ logvar,
+                                         const float* __restrict__ eps, float min_lv, float max_lv, int deterministic,
+                                         int n, float* __restrict__ act, float* __restrict__ logp) {
+  const int row = blockIdx.x;  // one 128-thread block per row
+  const int c = threadIdx.x;
+  __shared__ float sh[128];
+  const size_t i = (size_t)row * 128 + c;
+  const float lv = fminf(fmaxf(logvar[i], min_lv), max_lv);
+  logvar[i] = lv;
+  const float sigma = sqrtf(expf(lv));
+  const float e = deterministic ? 0.f : eps[i];
+  const float a = mu[i] + sigma * e;
+  act[i] = a;
+  const float d = a - mu[i];
+  sh[c] = -(d * d) / (2.f * sigma * sigma) - logf(sigma) - 0.91893853320467274178f;
+  __syncthreads();
+  for (int s = 64; s > 0; s >>= 1) {
+    if (c < s) sh[c] += sh[c + s];
+    __syncthreads();
+  }
+  if (c == 0 && logp) logp[row] = sh[0];
+}
+
+// GAE (ppo_policy.py:105-140 -> tianshou _gae_return [upstream]): values v[n+1,A] of obs_0..obs_n, rew / term [n,A]
+// (time-major).  v_s_ = v[t+1] * (1 - terminated); end_flag = terminated, forced at the last stored step of every
+// env (the sub-buffer's unfinished tail); float64 scan like tianshou's numpy path.
+__global__ void egx_gae_kernel(const float* __restrict__ v, const float* __restrict__ rew, const int* __restrict__ term,
+                               int n, int A, double gamma, double lam, float* __restrict__ returns, float* __restrict__ adv) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  double gae = 0.0;
+  for (int t = n - 1; t >= 0; --t) {
+    const bool tm = term[(size_t)t * A + a] != 0;
+    const double vs = v[(size_t)t * A + a];
+    const double vn = tm ? 0.0 : (double)v[(size_t)(t + 1) * A + a];
+    const double delta = (double)rew[(size_t)t * A + a] + vn * gamma - vs;
+    const bool end = tm || (t == n - 1);
+    gae = delta + (end ? 0.0 : gamma * lam) * gae;
+    adv[(size_t)t * A + a] = (float)gae;
+    returns[(size_t)t * A + a] = (float)(gae + vs);
+  }
+}
+
 // ---- internal launchers ---------------------------------------------------------------------------
 int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg, const float* W, const float* b,
                       int act, float slope, const float* res, int ldr, float* out, int ldo) {
@@ -259,6 +304,24 @@ extern "C" int egx_cont6d_to_aa(const float* xb6, int num_rows, float* out, int 
 extern "C" int egx_posenc(const float* dist, const float* time, int num_agents, float* out, void* stream_) {
   EGX_REQUIRE(dist && time && out && num_agents > 0, "bad arguments");
   egx_launch_posenc(static_cast<hipStream_t>(stream_), dist, time, num_agents, out);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_sample_action(const float* mu, float* logvar, const float* eps, float min_logvar, float max_logvar,
+                                 int deterministic, int num_rows, float* act, float* logp, void* stream_) {
+  EGX_REQUIRE(mu && logvar && act && num_rows > 0 && (deterministic || eps), "bad arguments");
+  hipLaunchKernelGGL(egx_sample_action_kernel, dim3(num_rows), dim3(128), 0, static_cast<hipStream_t>(stream_), mu, logvar, eps,
+                     min_logvar, max_logvar, deterministic, num_rows, act, logp);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_gae(const float* values, const float* rew, const int32_t* terminated, int num_steps, int num_agents,
+                       double gamma, double gae_lambda, float* returns, float* adv, void* stream_) {
+  EGX_REQUIRE(values && rew && terminated && returns && adv && num_steps > 0 && num_agents > 0, "bad arguments");
+  hipLaunchKernelGGL(egx_gae_kernel, dim3(egx_ceil_div(num_agents, 128)), dim3(128), 0, static_cast<hipStream_t>(stream_),
+                     values, rew, terminated, num_steps, num_agents, gamma, gae_lambda, returns, adv);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

@@ -203,14 +203,29 @@ class GAMMAPolicyBase(nn.Module):
         self.x_enc = nn.GRU(self.in_dim, self.h_dim)
         self.ego_enc = nn.GRU(32, self.h_dim)
 
+    @staticmethod
+    def _gru_last(gru: nn.GRU, x_seq: torch.Tensor) -> torch.Tensor:
+        """nn.GRU over x_seq[t,b,in] from a zero state, written as explicit gate math (r,z,n) on F.linear so
+        that the autograd path does not depend on the vendor RNN kernel; returns the last hidden state."""
+        H = gru.hidden_size
+        h = x_seq.new_zeros(x_seq.shape[1], H)
+        for t in range(x_seq.shape[0]):
+            gi = F.linear(x_seq[t], gru.weight_ih_l0, gru.bias_ih_l0)
+            gh = F.linear(h, gru.weight_hh_l0, gru.bias_hh_l0)
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            h = (1 - z) * n + z * h
+        return h
+
     def forward(self, obs):
         """autograd path (PPO update): obs dict -> hx[b,1152]."""
         nb = obs["state"].shape[0]
-        _, hx = self.x_enc(obs["state"].permute(1, 0, 2))
-        _, he = self.ego_enc(obs["egosensing"].permute(1, 0, 2))
+        hx = self._gru_last(self.x_enc, obs["state"].permute(1, 0, 2))
+        he = self._gru_last(self.ego_enc, obs["egosensing"].permute(1, 0, 2))
         d = positional_encoding(obs["dist"].reshape(nb, 1))
         t = positional_encoding(obs["time"].reshape(nb, 1))
-        return torch.cat([hx[0], he[0], d, t], dim=-1)
+        return torch.cat([hx, he, d, t], dim=-1)
 
 
 class GAMMAActor(nn.Module):

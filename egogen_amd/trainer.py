@@ -1,0 +1,221 @@
+"""On-policy collection + training loop reproducing the schedule the reference gets from tianshou
+(`Collector`, `VectorReplayBuffer`, `onpolicy_trainer`; crowd_ppo/main_ppo.py:177-243):
+
+  per epoch:  while steps_in_epoch < step_per_epoch:
+                  collect step_per_collect transitions (= step_per_collect / A vector steps)
+                  process_fn (values + GAE)  ->  learn(batch_size, repeat_per_collect)
+              test: episode_per_test episodes, deterministic if --deterministic-eval
+              save_best_fn (policy.pth) on improvement, save_checkpoint_fn every save_interval epochs
+
+Environments are a batched `VecCrowdEnv` per rank; with torch.distributed initialised every rank owns
+A/world agents and gradients are all-reduced inside `GAMMAPPOPolicy.learn`.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .crowd_env import VecCrowdEnv
+from .ppo_policy import GAMMAPPOPolicy, RolloutBatch
+
+
+class Collector:
+    """Steps a VecCrowdEnv with the policy and fills a RolloutBatch (time-major).  Episode statistics are
+    accumulated on the device; nothing synchronises with the host during collection."""
+
+    def __init__(self, policy: GAMMAPPOPolicy, env: VecCrowdEnv, rollout_dir: Optional[str] = None):
+        self.policy, self.env = policy, env
+        self.A = env.A
+        dev = env.dev
+        self.ep_ret = torch.zeros(self.A, device=dev)
+        self.ep_len = torch.zeros(self.A, device=dev)
+        self.done_ret = torch.zeros((), device=dev)
+        self.done_len = torch.zeros((), device=dev)
+        self.done_cnt = torch.zeros((), device=dev)
+        self._pol_out: dict = {}
+        self._batches: Dict[int, RolloutBatch] = {}
+        self.obs = None
+        self.rollout_dir = rollout_dir
+        self._episodes = [[] for _ in range(self.A)] if rollout_dir else None
+
+    def reset(self):
+        self.obs = self.env.reset()
+        self.ep_ret.zero_()
+        self.ep_len.zero_()
+        self.reset_stat()
+
+    def reset_stat(self):
+        self.done_ret.zero_()
+        self.done_len.zero_()
+        self.done_cnt.zero_()
+
+    def _track(self, rew, term):
+        self.ep_ret += rew
+        self.ep_len += 1
+        d = term.to(self.ep_ret.dtype)
+        self.done_ret += (self.ep_ret * d).sum()
+        self.done_len += (self.ep_len * d).sum()
+        self.done_cnt += d.sum()
+        self.ep_ret *= (1 - d)
+        self.ep_len *= (1 - d)
+
+    def _save_rollouts(self, term):
+        """save_rollout_results per finished episode (crowd_env_2f.py:154-155,305-309) - host side, only when asked."""
+        from .utils import save_rollout_results
+        env = self.env
+        mb = env.marker_b.cpu()
+        pp = env.pred_params.cpu()
+        fr = env.prev_frame.cpu()
+        pel = env.joints.reshape(self.A, 20, -1, 3)[:, :, 0].cpu()
+        tm = term.cpu().numpy()
+        for a in range(self.A):
+            mp = [mb[a:a + 1], pp[a:a + 1], env.betas[a].cpu(), "male", fr[a, :9].reshape(3, 3), fr[a, 9:].reshape(1, 3), pel[a:a + 1], "2-frame"]
+            self._episodes[a].append(mp)
+            if tm[a]:
+                scene = {"wpath": self._wpath_before[a], "navmesh_path": "synthetic"}
+                save_rollout_results(scene, self._episodes[a], self.rollout_dir)
+                self._episodes[a] = []
+
+    def collect(self, n_vec_steps: int) -> RolloutBatch:
+        if self.obs is None:
+            self.reset()
+        b = self._batches.get(n_vec_steps)
+        if b is None:
+            b = RolloutBatch(n_vec_steps, self.A, self.env.dev)
+            self._batches[n_vec_steps] = b
+        for t in range(n_vec_steps):
+            b.store_obs(t, self.obs)
+            out = self.policy(self.obs, out=self._pol_out)
+            b.act[t].copy_(out["act"])
+            b.mu[t].copy_(out["mu"])
+            b.logvar[t].copy_(out["logvar"])
+            b.logp_old[t].copy_(out["logp"])
+            if self._episodes is not None:
+                self._wpath_before = self.env.wpath.cpu()
+            if self._episodes is not None:
+                obs, rew, term = self.env.step(out["act"], auto_reset=False)
+                self._save_rollouts(term)
+                self.env.reset(mask=term)
+            else:
+                obs, rew, term = self.env.step(out["act"])
+            b.rew[t].copy_(rew)
+            b.term[t].copy_(term)
+            self._track(rew, term)
+            self.obs = obs
+        b.store_obs(n_vec_steps, self.obs)
+        return b
+
+    def collect_episodes(self, n_episode: int, max_steps: int = 64) -> Dict[str, float]:
+        """Test collector: run until every env has finished one episode (n_episode == number of test envs in
+        main_ppo.py:239-243); returns mean reward / length of those first episodes."""
+        self.reset()
+        dev = self.env.dev
+        first_ret = torch.zeros(self.A, device=dev)
+        first_len = torch.zeros(self.A, device=dev)
+        got = torch.zeros(self.A, device=dev)
+        run_ret = torch.zeros(self.A, device=dev)
+        run_len = torch.zeros(self.A, device=dev)
+        for _ in range(max_steps):
+            out = self.policy(self.obs, out=self._pol_out)
+            if self._episodes is not None:
+                self._wpath_before = self.env.wpath.cpu()
+                obs, rew, term = self.env.step(out["act"], auto_reset=False)
+                self._save_rollouts(term)
+                self.env.reset(mask=term)
+            else:
+                obs, rew, term = self.env.step(out["act"])
+            run_ret += rew
+            run_len += 1
+            d = term.to(run_ret.dtype) * (1 - got)
+            first_ret += run_ret * d
+            first_len += run_len * d
+            got = torch.clamp(got + d, max=1)
+            run_ret *= (1 - term.to(run_ret.dtype))
+            run_len *= (1 - term.to(run_ret.dtype))
+            self.obs = obs
+            if bool((got.sum() >= min(n_episode, self.A)).item()):
+                break
+        n = max(float(got.sum().item()), 1.0)
+        return {"rew": float(first_ret.sum().item()) / n, "len": float(first_len.sum().item()) / n, "n/ep": n}
+
+
+class ScalarLogger:
+    """TensorBoard SummaryWriter when importable (the reference logs with tianshou's TensorboardLogger,
+    main_ppo.py:192-205), else newline-delimited JSON with the same scalar names."""
+
+    def __init__(self, log_path: str):
+        os.makedirs(log_path, exist_ok=True)
+        self.path = log_path
+        self.writer = None
+        try:
+            from torch.utils.tensorboard import SummaryWriter  # noqa
+            self.writer = SummaryWriter(log_path)
+        except Exception:
+            self.f = open(os.path.join(log_path, "scalars.jsonl"), "a")
+
+    def write(self, prefix: str, step: int, data: Dict[str, float]):
+        for k, v in data.items():
+            if self.writer is not None:
+                self.writer.add_scalar(f"{prefix}/{k}", v, step)
+            else:
+                self.f.write(json.dumps({"tag": f"{prefix}/{k}", "step": step, "value": v}) + "\n")
+        if self.writer is None:
+            self.f.flush()
+
+
+def onpolicy_trainer(policy: GAMMAPPOPolicy, train_collector: Collector, test_collector: Optional[Collector], max_epoch: int,
+                     step_per_epoch: int, repeat_per_collect: int, episode_per_test: int, batch_size: int,
+                     step_per_collect: int, save_best_fn: Optional[Callable] = None, logger: Optional[ScalarLogger] = None,
+                     save_checkpoint_fn: Optional[Callable] = None, save_interval: int = 2, verbose: bool = True):
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    A_global = train_collector.A * world
+    n_vec = max(1, step_per_collect // A_global)
+    env_step, gradient_step = 0, 0
+    best_reward, best_epoch = -float("inf"), 0
+    t_start = time.time()
+    train_collector.reset()
+    for epoch in range(1, max_epoch + 1):
+        policy.train()
+        steps_in_epoch = 0
+        while steps_in_epoch < step_per_epoch:
+            batch = train_collector.collect(n_vec)
+            n_new = n_vec * A_global
+            env_step += n_new
+            steps_in_epoch += n_new
+            policy.process_fn(batch)
+            losses = policy.learn(batch, batch_size, repeat_per_collect)
+            gradient_step += len(losses["loss"])
+            if logger is not None and rank == 0:
+                cnt = float(train_collector.done_cnt.item())
+                if cnt > 0:
+                    logger.write("train", env_step, {"reward": float(train_collector.done_ret.item()) / cnt,
+                                                     "length": float(train_collector.done_len.item()) / cnt, "n/ep": cnt})
+                train_collector.reset_stat()
+                logger.write("update", env_step, {k: float(np.mean(v)) for k, v in losses.items() if v})
+        result = None
+        if test_collector is not None:
+            policy.eval()
+            result = test_collector.collect_episodes(episode_per_test)
+            if logger is not None and rank == 0:
+                logger.write("test", env_step, {"reward": result["rew"], "length": result["len"]})
+            if result["rew"] > best_reward:
+                best_reward, best_epoch = result["rew"], epoch
+                if save_best_fn is not None and rank == 0:
+                    save_best_fn(policy)
+        if save_checkpoint_fn is not None and rank == 0 and epoch % save_interval == 0:
+            save_checkpoint_fn(epoch, env_step, gradient_step)
+        if verbose and rank == 0:
+            msg = f"Epoch #{epoch}: env_step {env_step}, gradient_step {gradient_step}"
+            if result is not None:
+                msg += f", test_reward: {result['rew']:.6f}, best_reward: {best_reward:.6f} in #{best_epoch}"
+            print(msg, flush=True)
+    dur = time.time() - t_start
+    return {"duration": f"{dur:.2f}s", "train_step": env_step, "best_reward": best_reward, "best_epoch": best_epoch,
+            "train_speed": f"{env_step / max(dur, 1e-9):.2f} step/s", "gradient_step": gradient_step}

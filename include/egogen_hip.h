@@ -298,6 +298,27 @@ int egx_env_step_post(const egx_env_config* cfg, const egx_env_scenes* scenes, c
 int egx_env_reset(const egx_env_config* cfg, const egx_env_scenes* scenes, const egx_env_state* st,
                   const egx_env_reset_io* io, int num_agents, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * PPO rollout glue
+ * ------------------------------------------------------------------------------------------- */
+/* GAMMAPPOPolicy.forward tail (crowd_ppo/ppo_policy.py:169-178): logvar is clamped IN PLACE to [min,max];
+ * act = mu + exp(logvar)^0.5 * eps (eps ~ N(0,1) supplied by the caller; ignored when deterministic != 0, the
+ * `deterministic_eval and not training` branch); logp [n] (may be NULL) = Independent(Normal,1).log_prob(act). */
+int egx_sample_action(const float* mu, float* logvar, const float* eps, float min_logvar, float max_logvar,
+                      int deterministic, int num_rows, float* act, float* logp, void* stream);
+
+/* GAE of process_fn/_compute_returns (crowd_ppo/ppo_policy.py:105-140; tianshou compute_episodic_return [upstream]):
+ * values [n+1,A] = critic on obs_0..obs_n, rew/terminated [n,A] time-major -> returns, adv [n,A]. */
+int egx_gae(const float* values, const float* rew, const int32_t* terminated, int num_steps, int num_agents,
+            double gamma, double gae_lambda, float* returns, float* adv, void* stream);
+
+/* Profiling hook for bench.py: the next egx_lbs_forward on this host thread records `start`/`stop`
+ * (hipEvent_t passed as void*) immediately around its fused blend+skinning kernel launch. */
+int egx_profile_next_lbs(void* start_event, void* stop_event);
+int egx_event_create(void** out_event);
+int egx_event_destroy(void* event);
+int egx_event_elapsed_ms(void* start_event, void* stop_event, float* out_ms); /* synchronises on stop_event */
+
 #ifdef __cplusplus
 }
 #endif

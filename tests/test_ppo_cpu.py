@@ -1,0 +1,151 @@
+"""CPU tests of the host logic: PPO loss / GAE restatements, state_dict layout, and the data-parallel update
+path over gloo with world_size 2 (the same code runs over RCCL on the GPUs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from egogen_amd.models import ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase, POLICY_CFG
+from egogen_amd.ppo_policy import GAMMAPPOPolicy, RolloutBatch
+from oracle import ppo as oppo
+
+
+def _policy(seed=0, lr=3e-4):
+    torch.manual_seed(seed)
+    actor, critic, base = GAMMAActor(POLICY_CFG), GAMMACritic(POLICY_CFG), GAMMAPolicyBase(POLICY_CFG)
+    ac = ActorCritic(actor, critic, base)
+    for m in ac.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            torch.nn.init.zeros_(m.bias)
+    optim = torch.optim.AdamW(ac.parameters(), lr=lr, weight_decay=0.01)
+    return GAMMAPPOPolicy(actor, critic, base, optim, None, max_grad_norm=0.1, vf_coef=1.0, ent_coef=0.01, eps_clip=0.1,
+                          advantage_normalization=1, seed=seed)
+
+
+def _fill(batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    batch.state.copy_(torch.randn(batch.state.shape, generator=g) * 0.3)
+    batch.ego.copy_(torch.rand(batch.ego.shape, generator=g) * 2 - 1)
+    batch.dist.copy_(torch.rand(batch.dist.shape, generator=g))
+    batch.time.copy_(torch.rand(batch.time.shape, generator=g))
+    batch.act.copy_(torch.randn(batch.act.shape, generator=g))
+    batch.adv.copy_(torch.randn(batch.adv.shape, generator=g))
+    batch.returns.copy_(torch.randn(batch.returns.shape, generator=g))
+    batch.logp_old.copy_(torch.randn(batch.logp_old.shape, generator=g) * 0.1 - 250.0)
+
+
+def _set_logp(pol, b, seed):
+    """Make logp_old consistent with the policy (ratio ~ 1), as in a real rollout."""
+    with torch.no_grad():
+        _, mu, sigma = pol._dist_params(b.obs_flat())
+        lp = pol.log_prob(mu, sigma, b.act.reshape(-1, 128))
+    b.logp_old.copy_((lp + 0.05 * torch.randn(lp.shape, generator=torch.Generator().manual_seed(seed))).reshape(b.logp_old.shape))
+
+
+def test_state_dict_has_the_48_reference_keys():
+    pol = _policy()
+    keys = list(pol.state_dict().keys())
+    assert len(keys) == 48
+    assert sum(k.startswith("_actor_critic.actor.") for k in keys) == 10
+    assert sum(k.startswith("_actor_critic.critic.") for k in keys) == 10
+    assert sum(k.startswith("shared_net.") for k in keys) == 8
+    assert pol.state_dict()["actor.pnet.out_fc.weight"].shape == (256, 1152)
+    assert pol.state_dict()["critic.vnet.out_fc.weight"].shape == (1, 1152)
+    assert pol.state_dict()["shared_net.x_enc.weight_ih_l0"].shape == (1536, 402)
+    # a checkpoint written in the reference layout round-trips
+    pol2 = _policy(seed=1)
+    pol2.load_state_dict({"model": pol.state_dict()}["model"])
+    assert torch.equal(pol2.actor.pnet.out_fc.weight, pol.actor.pnet.out_fc.weight)
+
+
+def test_minibatch_loss_matches_oracle_restatement():
+    pol = _policy()
+    b = RolloutBatch(2, 8, "cpu")
+    _fill(b, 3)
+    obs = b.obs_flat()
+    N = 16
+    loss, terms = pol.minibatch_loss(obs, b.act.reshape(N, 128), b.adv.reshape(N), b.returns.reshape(N), b.logp_old.reshape(N))
+    hx = pol.shared_net(obs)
+    (mu, lv), _ = pol.actor(hx)
+    ref, rterms = oppo.ppo_loss(mu, lv, pol.critic(hx), b.act.reshape(N, 128), b.adv.reshape(N), b.returns.reshape(N), b.logp_old.reshape(N))
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    for k in ("loss/clip", "loss/vf", "loss/ent", "loss/kld"):
+        assert abs(float(terms[k]) - float(rterms[k])) <= 1e-5 * max(1.0, abs(float(rterms[k]))), k
+
+
+def test_grad_clip_covers_actor_and_critic_only():
+    """clip_grad_norm_(max 0.1) sees actor+critic, NOT shared_net."""
+    pol = _policy()
+    b = RolloutBatch(2, 8, "cpu")
+    _fill(b, 4)
+    pol.learn(b, 16, 1)
+    ac_norm = torch.sqrt(sum((p.grad ** 2).sum() for p in pol._actor_critic.parameters()))
+    assert float(ac_norm) <= 0.1 + 1e-5
+    assert not any(k.startswith("shared_net") for k, _ in pol._actor_critic.named_parameters())
+
+
+def test_gae_oracle_handcase():
+    # two envs, three steps, env 1 terminates at t=1
+    v = np.array([[1.0, 2.0, 3.0, 4.0], [0.5, 0.5, 0.5, 0.5]])   # values of obs_0..obs_3 per env
+    rew = np.array([[1.0, 1.0, 1.0], [0.0, 2.0, 0.0]])
+    term = np.array([[0, 0, 0], [0, 1, 0]], bool)
+    ret, adv = oppo.gae_returns(v[:, :3], v[:, 1:], rew, term, np.zeros_like(term), gamma=0.9, gae_lambda=0.5)
+    d2 = 1 + 0.9 * 4 - 3
+    d1 = 1 + 0.9 * 3 - 2
+    d0 = 1 + 0.9 * 2 - 1
+    a2 = d2
+    a1 = d1 + 0.45 * a2
+    a0 = d0 + 0.45 * a1
+    np.testing.assert_allclose(adv[0], [a0, a1, a2], rtol=1e-12)
+    e1 = 2 + 0 - 0.5       # terminated: no bootstrap, scan cut
+    e0 = 0 + 0.9 * 0.5 - 0.5 + 0.45 * e1
+    e2 = 0 + 0.9 * 0.5 - 0.5
+    np.testing.assert_allclose(adv[1], [e0, e1, e2], rtol=1e-12)
+    np.testing.assert_allclose(ret, adv + v[:, :3])
+
+
+def _dp_worker(rank, world, port, n_local, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    pol = _policy(seed=0)
+    assert pol.world_size == world
+    b = RolloutBatch(1, n_local, "cpu")
+    _fill(b, 100 + rank)
+    _set_logp(pol, b, 200 + rank)
+    pol.learn(b, n_local * world, 1)          # one global minibatch holding every transition
+    if rank == 0:
+        torch.save({"grad": pol._flat_grad.clone(), "sd": {k: v.clone() for k, v in pol.state_dict().items()}}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_update_equals_single_process(tmp_path):
+    world, n_local = 2, 6
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_worker, args=(world, 29000 + os.getpid() % 2000, n_local, out), nprocs=world, join=True)
+    dp = torch.load(out)
+    # single process on the concatenated data
+    pol = _policy(seed=0)
+    parts = []
+    for r in range(world):
+        b = RolloutBatch(1, n_local, "cpu")
+        _fill(b, 100 + r)
+        _set_logp(pol, b, 200 + r)
+        parts.append(b)
+    big = RolloutBatch(1, n_local * world, "cpu")
+    for name in ("state", "ego", "dist", "time", "act", "adv", "returns", "logp_old"):
+        getattr(big, name).copy_(torch.cat([getattr(p, name) for p in parts], dim=1))
+    pol.learn(big, n_local * world, 1)
+    # the all-reduced, clipped gradient of the global minibatch is the quantity that must agree (the AdamW step on
+    # it is sign-like at step 1 and would amplify round-off of near-zero entries)
+    g_ref, g_dp = pol._flat_grad, dp["grad"]
+    assert float((g_ref - g_dp).abs().max()) <= 2e-5 * float(g_ref.abs().max())
+    assert float(g_ref.abs().max()) > 0
+    # and the parameters moved by the same amount almost everywhere
+    moved = sum(int((v - dp["sd"][k]).abs().gt(1e-4).sum()) for k, v in pol.state_dict().items())
+    assert moved < 2000, moved

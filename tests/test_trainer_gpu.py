@@ -1,0 +1,125 @@
+"""GPU tests of the PPO rollout glue (action sampling, GAE), the collector/trainer loop and the drop-in entry point."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_world, max_abs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Args:
+    seed = 0; lr = 3e-4; gamma = 0.99; gae_lambda = 0.95; max_grad_norm = 0.1; vf_coef = 1.0; ent_coef = 0.01
+    weight_kld = 0; rew_norm = False; eps_clip = 0.1; value_clip = 0; dual_clip = None; norm_adv = 1; recompute_adv = 0
+    deterministic_eval = False
+
+
+def test_gae_kernel_matches_oracle():
+    import ctypes as C
+    from egogen_amd import _lib
+    from oracle import ppo as oppo
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    n, A = 7, 37
+    v = torch.randn(n + 1, A, generator=g)
+    rew = torch.randn(n, A, generator=g)
+    term = (torch.rand(n, A, generator=g) < 0.2).to(torch.int32)
+    ret, adv = torch.empty(n, A, device="cuda"), torch.empty(n, A, device="cuda")
+    vc, rc_, tc = v.cuda(), rew.cuda(), term.cuda()
+    _lib.check(lib.egx_gae(_lib.ptr(vc), _lib.ptr(rc_), _lib.ptr(tc), n, A, 0.99, 0.95, _lib.ptr(ret), _lib.ptr(adv),
+                           _lib.current_stream_ptr()), "gae")
+    oret, oadv = oppo.gae_returns(v[:n].T.numpy(), v[1:].T.numpy(), rew.T.numpy(), term.T.numpy().astype(bool),
+                                  np.zeros((A, n), bool), 0.99, 0.95)
+    assert max_abs(adv.cpu().T, oadv) < 1e-5 and max_abs(ret.cpu().T, oret) < 1e-5
+
+
+def test_sample_action_kernel():
+    import ctypes as C
+    from egogen_amd import _lib
+    from oracle import ppo as oppo
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    n = 19
+    mu, lv, eps = torch.randn(n, 128, generator=g), torch.randn(n, 128, generator=g) * 3, torch.randn(n, 128, generator=g)
+    muc, lvc, epsc = mu.cuda(), lv.clone().cuda(), eps.cuda()
+    act, logp = torch.empty(n, 128, device="cuda"), torch.empty(n, device="cuda")
+    _lib.check(lib.egx_sample_action(_lib.ptr(muc), _lib.ptr(lvc), _lib.ptr(epsc), -2.5, 2.5, 0, n, _lib.ptr(act), _lib.ptr(logp),
+                                     _lib.current_stream_ptr()), "sample")
+    m, s = oppo.action_dist(mu, lv)
+    ref_act = m + s * eps
+    assert max_abs(lvc.cpu(), lv.clamp(-2.5, 2.5)) == 0
+    assert max_abs(act.cpu(), ref_act) < 1e-5
+    assert max_abs(logp.cpu(), oppo.log_prob(m, s, ref_act)) < 1e-3
+    # deterministic eval: act = mu
+    _lib.check(lib.egx_sample_action(_lib.ptr(muc), _lib.ptr(lvc), None, -2.5, 2.5, 1, n, _lib.ptr(act), _lib.ptr(logp),
+                                     _lib.current_stream_ptr()), "sample")
+    assert torch.equal(act, muc)
+
+
+@pytest.mark.parametrize("kind", ["sdf", "box"])
+def test_collect_and_update_loop(kind):
+    from egogen_amd import setup_world as sw
+    from egogen_amd.trainer import Collector, onpolicy_trainer
+    w = build_world(V=1024, A=16, scene_kind=kind, sdf_res=32, n_pairs=64, n_scenes=4)
+    env = w["env"]
+    policy = sw.build_policy(_Args())
+    before = policy.actor.pnet.out_fc.weight.clone()
+    col = Collector(policy, env)
+    res = onpolicy_trainer(policy, col, None, max_epoch=1, step_per_epoch=64, repeat_per_collect=1, episode_per_test=0,
+                           batch_size=8, step_per_collect=32, verbose=False)
+    assert res["train_step"] == 64 and res["gradient_step"] == 8
+    assert not torch.equal(before, policy.actor.pnet.out_fc.weight)
+    for p in policy.parameters():
+        assert torch.isfinite(p).all()
+    b = col._batches[2]
+    assert torch.isfinite(b.rew).all() and torch.isfinite(b.adv).all() and torch.isfinite(b.returns).all()
+    # the rollout log-probs equal the update path's log-probs before any parameter change (same function, two code paths)
+    policy2 = sw.build_policy(_Args())
+    col2 = Collector(policy2, env)
+    bb = col2.collect(2)
+    with torch.no_grad():
+        _, mu, sigma = policy2._dist_params(bb.obs_flat())
+        lp = policy2.log_prob(mu, sigma, bb.act.reshape(-1, 128))
+    assert max_abs(lp.cpu(), bb.logp_old.reshape(-1).cpu()) < 2e-3
+
+
+def test_main_ppo_entry_point_writes_reference_layout(tmp_path):
+    """crowd_ppo/main_ppo.py drop-in: CLI, checkpoint_{epoch}.pth / policy.pth with {"model","optim"}, 48 state_dict keys,
+    results/ directory tree and log/eval_results/*.pkl in the reference's format (utils.py:14-46)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "crowd_ppo", "main_ppo.py"), "--training-num", "8", "--test-num", "4", "--epoch", "2",
+           "--step-per-epoch", "32", "--step-per-collect", "16", "--batch-size", "8", "--num-verts", "1024", "--sdf-res", "32",
+           "--scene", "single_box", "--logdir", str(tmp_path / "log"), "--save-interval", "1", "--save-rollout", "1"]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "Final reward:" in r.stdout
+    run_dirs = []
+    for dp, dn, fn in os.walk(tmp_path / "log" / "collision-avoidance" / "ppo" / "0"):
+        if "checkpoint_1.pth" in fn:
+            run_dirs.append(dp)
+    assert len(run_dirs) == 1
+    ck = torch.load(os.path.join(run_dirs[0], "checkpoint_2.pth"), map_location="cpu")
+    assert set(ck.keys()) == {"model", "optim"} and len(ck["model"]) == 48
+    assert os.path.exists(os.path.join(run_dirs[0], "policy.pth"))
+    assert os.path.isdir(tmp_path / "results" / "crowd_ppo" / "MPVAEPolicy_samp_collision" / "collision_test" / "checkpoints")
+    pk = sorted((tmp_path / "log" / "eval_results").glob("motion_*.pkl"))
+    assert pk, "no rollout pickles written"
+    d = pickle.load(open(pk[0], "rb"))
+    assert set(d.keys()) >= {"motion", "wpath", "navmesh_path"} and d["wpath"].shape == (2, 3)
+    mp = d["motion"][0]
+    assert mp["blended_marker"].shape == (20, 67, 3) and mp["smplx_params"].shape == (1, 20, 93) and mp["betas"].shape == (10,)
+    assert mp["transf_rotmat"].shape == (3, 3) and mp["transf_transl"].shape == (1, 3) and mp["pelvis_loc"].shape == (20, 3)
+    assert mp["gender"] == "male" and mp["mp_type"] == "2-frame"
+    # resume + watch with deterministic eval
+    cmd2 = [sys.executable, os.path.join(ROOT, "crowd_ppo", "main_ppo.py"), "--watch", "--deterministic-eval", "--resume-path",
+            os.path.join(run_dirs[0], "checkpoint_2.pth"), "--test-num", "4", "--num-verts", "1024", "--sdf-res", "32",
+            "--scene", "single_box", "--logdir", str(tmp_path / "log2")]
+    r2 = subprocess.run(cmd2, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    assert "Loaded agent from" in r2.stdout and "Final reward:" in r2.stdout
