@@ -76,7 +76,7 @@ class PolicyArgs:
     deterministic_eval = False
 
 
-def cpu_baseline(args, scene, n_agent_steps):
+def cpu_baseline(args, scene, n_agent_steps, budget_s=20.0):
     """Reference-structured CPU path (oracle): one agent at a time, batch replicated x4 (crowd_env_2f.py:29-32), host ray
     casting, plus the CPU cost of the PPO update per transition."""
     from egogen_amd import synth
@@ -85,7 +85,7 @@ def cpu_baseline(args, scene, n_agent_steps):
     from oracle.env import OracleCrowdEnv
     from oracle.smplx_lbs import BodyModel
     from oracle import nets as onets, ppo as oppo
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)   # more threads only add fork/join overhead at these tensor sizes
     torch.set_num_threads(cores)
     V = args.num_verts
     bm = synth.make_body_model(0, num_verts=V)
@@ -112,7 +112,12 @@ def cpu_baseline(args, scene, n_agent_steps):
     t_env = 0.0
     g = torch.Generator().manual_seed(0)
     with torch.no_grad():
+        t_begin = time.perf_counter()
+        done = 0
         for i in range(n_agent_steps):
+            if done >= 2 and time.perf_counter() - t_begin > budget_s:
+                break
+            done += 1
             st = torch.as_tensor(pairs[i:i + 1, 0]).repeat(rep, 1)
             tg = torch.as_tensor(pairs[i:i + 1, 1]).repeat(rep, 1)
             t0 = time.perf_counter()
@@ -127,6 +132,7 @@ def cpu_baseline(args, scene, n_agent_steps):
             z = mu + torch.exp(lv.clamp(-2.5, 2.5)) ** 0.5 * torch.randn(rep, 128, generator=g)
             o.step(z)
             t_env += time.perf_counter() - t0 + t_reset / 11.0   # one reset per ~max_depth steps
+    n_agent_steps = done
     per_step = t_env / n_agent_steps
     # PPO update cost per transition: one minibatch of 256 forward+backward+AdamW on the CPU
     ac.train()
@@ -148,7 +154,14 @@ def cpu_baseline(args, scene, n_agent_steps):
                       f"{per_step * 1e3:.0f} ms each) + one 256-sample PPO minibatch on CPU ({per_trans_update * 1e3:.2f} ms/transition)"}
 
 
+def _log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
     args = get_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -171,7 +184,9 @@ def main():
     prior = sw.build_motion_prior(seed=0)
     vposer = sw.build_vposer(seed=0)
     scene = sw.build_scene(args.scene, sdf_res=args.sdf_res, seed=0)
+    _log("assets built")
     env = sw.build_env(A, scene, body, prior, vposer, seed=rank, use_graph=bool(args.graph))
+    _log(f"env built ({'%d valid start pairs' % env.valid_pairs.shape[0] if env.valid_pairs is not None else 'box scenes'})")
     policy = sw.build_policy(pa)
     policy.train()
     collector = Collector(policy, env)
@@ -184,8 +199,10 @@ def main():
         policy.process_fn(batch)
         return policy.learn(batch, global_bs, 1)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         one_step()
+        torch.cuda.synchronize()
+        _log(f"warmup step {i} done")
 
     # HIP events around the fused LBS kernel of every vector step in the timed region
     n_ev = args.steps * n_vec
@@ -219,6 +236,7 @@ def main():
         ms_list.append(ms.value)
         lib.egx_event_destroy(e0)
         lib.egx_event_destroy(e1)
+    _log(f"timed region done: {elapsed:.3f}s")
     lbs_ms = float(np.mean(ms_list))
     bodies = A * 20
     achieved = FLOP_PER_BODY * bodies / (lbs_ms * 1e-3) / 1e12
@@ -248,6 +266,7 @@ def main():
                      "flop_per_body": FLOP_PER_BODY},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        _log("cpu baseline ...")
         try:
             result["cpu_baseline"] = cpu_baseline(args, scene, args.cpu_agent_steps)
         except Exception as e:  # the baseline is a report, never a reason to lose the measurement

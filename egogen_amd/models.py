@@ -187,7 +187,9 @@ class MLPBlock(nn.Module):
 
 def positional_encoding(x: torch.Tensor, L: int = 32) -> torch.Tensor:
     """models_policy_ppo.py:276-285: x[b,1] -> [b,2L], [sin(x 2^k), cos(x 2^k)] interleaved per k."""
-    freqs = 2.0 ** torch.arange(L, dtype=x.dtype, device=x.device)
+    # exact powers of two built on the host (a device-side pow() is not exact for 2^31, and sin/cos of
+    # x * 2^k are extremely sensitive to the last bit of the argument)
+    freqs = torch.ldexp(torch.ones(L, dtype=torch.float32), torch.arange(L)).to(device=x.device, dtype=x.dtype)
     xf = x * freqs  # [b,L]
     return torch.stack([torch.sin(xf), torch.cos(xf)], dim=-1).reshape(x.shape[0], 2 * L)
 
