@@ -44,10 +44,10 @@ def test_smplx_oracle_invariants():
     assert (v32.double() - v64).abs().max() < 5e-6 and (j32.double() - j64).abs().max() < 5e-6
     assert j32.shape == (6, 127, 3) and v32.shape == (6, 1500, 3)
     # translation equivariance
-    xb2 = xb.clone()
-    xb2[:, :3] += torch.tensor([1.0, -2.0, 0.5])
-    v2, j2 = smplx_forward(ob64, xb2.double(), betas.double())
-    assert (v2 - v64 - torch.tensor([1.0, -2.0, 0.5])).abs().max() < 1e-12
+    xb2 = xb.double().clone()
+    xb2[:, :3] += torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64)
+    v2, j2 = smplx_forward(ob64, xb2, betas.double())
+    assert (v2 - v64 - torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64)).abs().max() < 1e-12
     # zero pose and zero hand means -> v_shaped + transl
     bm0 = dict(bm)
     bm0["hand_mean_l"] = np.zeros(45, np.float32)
