@@ -55,6 +55,7 @@ def get_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-agent-steps", type=int, default=6)
     p.add_argument("--graph", type=int, default=0, help="capture the env step into a HIP graph")
+    p.add_argument("--update-graph", type=int, default=1, help="replay the PPO minibatch update as HIP graphs")
     return p.parse_args()
 
 
@@ -179,6 +180,7 @@ def main():
 
     A = args.agents
     pa = PolicyArgs()
+    pa.update_graph = bool(args.update_graph)
     bm, _ = sw.load_body_model("male", seed=0, num_verts=args.num_verts)
     body = BodyModelHandle(bm, synth.marker_ids(args.num_verts), synth.feet_vids(args.num_verts))
     prior = sw.build_motion_prior(seed=0)
@@ -259,7 +261,8 @@ def main():
                                f"{'' if args.scene == 'box' else f' SDF {args.sdf_res}^3'}, synthetic SMPL-X body V={args.num_verts}, "
                                f"{n_vec} vector steps/collect ({n_vec * A} transitions/GPU), minibatch {args.batch_size}/GPU, repeat 1",
                    "agents_per_gpu": A, "scene": args.scene, "vec_steps_per_collect": n_vec, "minibatch_per_gpu": args.batch_size,
-                   "parallelism": f"dp{world}" if world > 1 else "single", "hip_graph": bool(args.graph)},
+                   "parallelism": f"dp{world}" if world > 1 else "single", "hip_graph_env": bool(args.graph),
+                   "hip_graph_update": bool(args.update_graph) and not any(v.get("failed") for v in policy._graph_cache.values())},
         "roofline": {"bound": "mfma", "kernel": "egx_lbs_fused_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,

@@ -14,3 +14,11 @@ int egx_launch_gru_pointwise(hipStream_t st, const float* gi, const float* gh, c
                              int ldo, int M, int H);
 int egx_launch_cont6d_to_aa(hipStream_t st, const float* xb6, int n, float* out, int ldo);
 int egx_launch_posenc(hipStream_t st, const float* dist, const float* time, int A, float* out);
+
+struct RegWeights {
+  const float* in_w; const float* in_b;
+  const float* blk_w[20]; const float* blk_b[20];
+  const float* out_w; const float* out_b;
+};
+int egx_launch_regressor_fused(hipStream_t st, const RegWeights& w, const float* Y, const float* betas, int A, int M,
+                               float* out_Yb);

@@ -93,18 +93,39 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // groups of PF chunks (8 k each), double buffered: the 2*PF loads of the next group are in flight while the
+  // 4*PF MFMAs (64 cycles each) of the current group execute, which covers the global-load latency.
+  constexpr int PF = 4;
   if (c0 < c1) {
-    f32x4 xa = load_x4(a, row, c0 * 8 + 4 * h), wb = load_w4(a, col, c0 * 8 + 4 * h);
-    for (int c = c0; c < c1; ++c) {
-      f32x4 xn = xa, wn = wb;
-      if (c + 1 < c1) {
-        xn = load_x4(a, row, (c + 1) * 8 + 4 * h);
-        wn = load_w4(a, col, (c + 1) * 8 + 4 * h);
+    f32x4 xa[PF], wb[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int c = min(c0 + u, c1 - 1);
+      xa[u] = load_x4(a, row, c * 8 + 4 * h);
+      wb[u] = load_w4(a, col, c * 8 + 4 * h);
+    }
+    for (int cg = c0; cg < c1; cg += PF) {
+      f32x4 xn[PF], wn[PF];
+      const bool more = cg + PF < c1;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int c = min(cg + PF + u, c1 - 1);
+          xn[u] = load_x4(a, row, c * 8 + 4 * h);
+          wn[u] = load_w4(a, col, c * 8 + 4 * h);
+        }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
-      xa = xn;
-      wb = wn;
+      for (int u = 0; u < PF; ++u) {
+        if (cg + u < c1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][e], wb[u][e], acc, 0, 0, 0);
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { xa[u] = xn[u]; wb[u] = wn[u]; }
+      }
     }
   }
   if (wave > 0) {
@@ -144,14 +165,9 @@ __global__ void egx_gru_pointwise_kernel(const float* __restrict__ gi, const flo
   hout[(size_t)m * ldo + c] = (1.f - z) * nn + z * hp;
 }
 
-// MoshRegressor tail (models_GAMMA_primitive.py:208-219 + baseops.py:119-162): xb6[n,159] ->
-// xb[n,93] = transl3 | 22 x (6D -> Gram-Schmidt rotmat -> axis-angle) | hands 24.  One thread per (row, joint).
-__global__ void egx_cont6d_to_aa_kernel(const float* __restrict__ xb6, int n, float* __restrict__ out, int ldo) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n * 23) return;
-  const int row = idx / 23, j = idx % 23;
-  const float* src = xb6 + (size_t)row * 159;
-  float* dst = out + (size_t)row * ldo;
+// MoshRegressor tail (models_GAMMA_primitive.py:208-219 + baseops.py:119-162): xb6[159] -> xb[93] =
+// transl3 | 22 x (6D -> Gram-Schmidt rotmat -> axis-angle) | hands 24.  One call per (row, item j in 0..22).
+__device__ void egx_cont6d_item(const float* src, float* dst, int j) {
   if (j == 22) {  // transl + hands copied through
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
     for (int e = 0; e < 24; ++e) dst[69 + e] = src[135 + e];
@@ -170,6 +186,163 @@ __global__ void egx_cont6d_to_aa_kernel(const float* __restrict__ xb6, int n, fl
   float aa[3];
   egx_tgm_rotmat_to_aa(R, aa);
   dst[3 + 3 * j + 0] = aa[0]; dst[3 + 3 * j + 1] = aa[1]; dst[3 + 3 * j + 2] = aa[2];
+}
+
+__global__ void egx_cont6d_to_aa_kernel(const float* __restrict__ xb6, int n, float* __restrict__ out, int ldo) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * 23) return;
+  const int row = idx / 23, j = idx % 23;
+  egx_cont6d_item(xb6 + (size_t)row * 159, out + (size_t)row * ldo, j);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused body regressor: MoshRegressor.forward (models_GAMMA_primitive.py:222-301) for a tile of 32 rows per
+// workgroup, all 3 recurrences x (in_fc + 10 residual blocks + out_fc) = 66 dense layers in ONE launch.
+// Activations live in LDS (input [mk|xb|betas] 32x376, h and t 32x132 each); the 398 k weights (1.6 MB) are
+// read straight from L2 in MFMA B-operand order; each wave owns one 32x32 output tile per 128-wide layer and
+// prefetches the next layer's weight fragments into registers while the current layer's MFMAs run.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int RG_RT = 32, RG_LDX = 376, RG_LDH = 132, RG_KIN = 370, RG_NOUT = 159;
+typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ void rg_load_w128(const float* W, int col, int h, f32x4 (&wf)[16]) {
+  const float* p = W + (size_t)col * 128 + 4 * h;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) wf[c] = *reinterpret_cast<const f32x4a*>(p + c * 8);
+}
+__device__ __forceinline__ f32x16 rg_mma128(const float* xs, int i, int h, const f32x4 (&wf)[16]) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* xr = xs + i * RG_LDH + 4 * h;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const f32x4 xa = *reinterpret_cast<const f32x4*>(xr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wf[c][e], acc, 0, 0, 0);
+  }
+  return acc;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void egx_regressor_fused_kernel(RegWeights w, const float* __restrict__ Y,
+                                                                     const float* __restrict__ betas, int A, int M,
+                                                                     float* __restrict__ out_Yb) {
+  extern __shared__ __attribute__((aligned(16))) float rg_smem[];
+  float* xin = rg_smem;                       // [32][376]: markers 201 | xb 159 | betas 10 | zero pad 6
+  float* hb = xin + RG_RT * RG_LDX;           // [32][132]
+  float* tb = hb + RG_RT * RG_LDH;            // [32][132]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * RG_RT;
+  // ---- load the input tile
+  for (int idx = tid; idx < RG_RT * RG_LDX; idx += 256) {
+    const int r = idx / RG_LDX, c = idx % RG_LDX;
+    const int m = min(m0 + r, M - 1);
+    float v = 0.f;
+    if (c < 201) v = Y[(size_t)m * 201 + c];
+    else if (c >= 360 && c < 370) v = betas[(size_t)(m % A) * 10 + (c - 360)];
+    xin[idx] = v;
+  }
+  __syncthreads();
+  const int n0 = wave * 32;
+  f32x4 wcur[16], wnext[16];
+  for (int rc = 0; rc < 3; ++rc) {
+    // prefetch the first block layer's weights; they are independent of the activations
+    rg_load_w128(w.blk_w[0], n0 + i, h, wcur);
+    // ---- in_fc: [32,370] x [128,370]^T, streamed in groups of 4 chunks
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* wrow = w.in_w + (size_t)(n0 + i) * RG_KIN + 4 * h;
+      const float* xr = xin + i * RG_LDX + 4 * h;
+      constexpr int NCH = 46;  // full 8-wide chunks; k = 368,369 handled below
+      f32x4 wf[2][2];
+      wf[0][0] = *reinterpret_cast<const f32x4a*>(wrow);
+      wf[0][1] = *reinterpret_cast<const f32x4a*>(wrow + 8);
+      for (int c = 0; c < NCH; c += 2) {
+        const int cn = (c + 2 < NCH) ? c + 2 : c;
+        wf[1][0] = *reinterpret_cast<const f32x4a*>(wrow + cn * 8);
+        wf[1][1] = *reinterpret_cast<const f32x4a*>(wrow + (cn + 1) * 8);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(xr + (c + u) * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wf[0][u][e], acc, 0, 0, 0);
+        }
+        wf[0][0] = wf[1][0];
+        wf[0][1] = wf[1][1];
+      }
+      {  // tail: k = 368 + 4h + e, valid only for h == 0, e < 2
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(xr + NCH * 8);
+        f32x4 wt = {0.f, 0.f, 0.f, 0.f};
+        if (h == 0) { wt[0] = wrow[NCH * 8]; wt[1] = wrow[NCH * 8 + 1]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wt[e], acc, 0, 0, 0);
+      }
+      const float b = w.in_b[n0 + i];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hb[((r & 3) + 8 * (r >> 2) + 4 * h) * RG_LDH + n0 + i] = acc[r] + b;
+    }
+    __syncthreads();
+    // ---- 10 residual blocks
+    for (int l = 0; l < 20; ++l) {
+      // next layer's weights (or out_fc tile `wave`) while this layer computes
+      const float* Wn = (l + 1 < 20) ? w.blk_w[l + 1] : w.out_w;
+      rg_load_w128(Wn, n0 + i, h, wnext);
+      const float* src = (l & 1) ? tb : hb;
+      f32x16 acc = rg_mma128(src, i, h, wcur);
+      const float b = w.blk_b[l][n0 + i];
+      if ((l & 1) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * h) * RG_LDH + n0 + i] = fmaxf(acc[r] + b, 0.f);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* hp = hb + ((r & 3) + 8 * (r >> 2) + 4 * h) * RG_LDH + n0 + i;
+          *hp = fmaxf(acc[r] + b, 0.f) + *hp;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) wcur[c] = wnext[c];
+      __syncthreads();
+    }
+    // ---- out_fc: N = 159 -> tiles 0..4; wave w owns tile w (weights already in wcur), wave 0 also tile 4
+    for (int tI = wave; tI < 5; tI += 4) {
+      const int nn = tI * 32 + i;
+      if (tI >= 4) rg_load_w128(w.out_w, min(nn, RG_NOUT - 1), h, wcur);
+      f32x16 acc = rg_mma128(hb, i, h, wcur);
+      if (nn < RG_NOUT) {
+        const float b = w.out_b[nn];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* xp = xin + ((r & 3) + 8 * (r >> 2) + 4 * h) * RG_LDX + 201 + nn;
+          *xp = *xp + (acc[r] + b);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- 6D -> axis-angle tail straight from LDS
+  for (int idx = tid; idx < RG_RT * 23; idx += 256) {
+    const int r = idx / 23, j = idx % 23;
+    if (m0 + r < M) egx_cont6d_item(xin + r * RG_LDX + 201, out_Yb + (size_t)(m0 + r) * 93, j);
+  }
+}
+
+int egx_launch_regressor_fused(hipStream_t st, const RegWeights& w, const float* Y, const float* betas, int A, int M,
+                               float* out_Yb) {
+  const size_t lds = (size_t)(RG_RT * RG_LDX + 2 * RG_RT * RG_LDH) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {  // 80 KiB of dynamic LDS: above the 64 KiB default cap
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(egx_regressor_fused_kernel, dim3(egx_ceil_div(M, RG_RT)), dim3(256), lds, st, w, Y, betas, A, M, out_Yb);
+  return EGX_OK;
 }
 
 // positional_encoding (models_policy_ppo.py:276-285) of dist and time: out[b, 0:64] / out[b, 64:128]

@@ -25,7 +25,8 @@ size_t carve_bytes(std::initializer_list<size_t> nfloats) {
 extern "C" size_t egx_sample_prior_workspace_bytes(int A) {
   if (A <= 0) return 0;
   const size_t a = A, m = (size_t)A * T_PRED;
-  return carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 512, a * H, m * 128, m * 128, m * 159});
+  (void)m;
+  return carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 512, a * H});
 }
 
 extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, const float* x1, int x_ld,
@@ -47,9 +48,6 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
   float* gh = cv.take((size_t)A * 3 * H);
   float* t512 = cv.take((size_t)A * 512);
   float* t256 = cv.take((size_t)A * H);
-  float* rh = cv.take((size_t)M * 128);
-  float* rt = cv.take((size_t)M * 128);
-  float* xb6 = cv.take((size_t)M * 159);
 
   // ---- x_enc GRU over the 2 history frames (zero initial state) -> hx
   {
@@ -95,28 +93,15 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
     egx_launch_linear(st, A, MK, &s3, 1, w->d_out_w, w->d_out_b, 0, 0.f, yp, yp_ld, out_Y + (size_t)i * A * MK, MK);
     float* tmp = hcur; hcur = hnext; hnext = tmp;
   }
-  // ---- regressor on all 18*A frames: rows ordered [t][a] like Y_gen.view(nt*nb,-1); betas row = a
-  // (betas.repeat(t_pred, b, 1) in the reference = same betas for every frame of an agent)
-  EGX_HIP_CHECK(hipMemsetAsync(xb6, 0, (size_t)M * 159 * sizeof(float), st));
-  // betas are [A,10] shared by the 18 frames of an agent: expand once into the (now free) gi buffer
-  // (A*768 floats >= 18*A*10)
-  float* betas_rep = gi;  // [M,10]
-  for (int t = 0; t < T_PRED; ++t)
-    EGX_HIP_CHECK(hipMemcpyAsync(betas_rep + (size_t)t * A * 10, betas, (size_t)A * 10 * sizeof(float),
-                                 hipMemcpyDeviceToDevice, st));
-  for (int rcr = 0; rcr < 3; ++rcr) {
-    EgxSeg in[3] = {{out_Y, MK, MK}, {xb6, 159, 159}, {betas_rep, 10, 10}};
-    egx_launch_linear(st, M, 128, in, 3, w->reg_in_w, w->reg_in_b, 0, 0.f, nullptr, 0, rh, 128);
-    for (int b = 0; b < 10; ++b) {
-      EgxSeg s1{rh, 128, 128};
-      egx_launch_linear(st, M, 128, &s1, 1, w->reg_blk_w[2 * b], w->reg_blk_b[2 * b], 2, 0.f, nullptr, 0, rt, 128);
-      EgxSeg s2{rt, 128, 128};
-      egx_launch_linear(st, M, 128, &s2, 1, w->reg_blk_w[2 * b + 1], w->reg_blk_b[2 * b + 1], 2, 0.f, rh, 128, rh, 128);
-    }
-    EgxSeg so{rh, 128, 128};
-    egx_launch_linear(st, M, 159, &so, 1, w->reg_out_w, w->reg_out_b, 0, 0.f, xb6, 159, xb6, 159);
+  // ---- regressor on all 18*A frames (rows ordered [t][a] like Y_gen.view(nt*nb,-1); betas row = a):
+  // one fused launch, 66 dense layers + the 6D -> axis-angle tail
+  {
+    RegWeights rw;
+    rw.in_w = w->reg_in_w; rw.in_b = w->reg_in_b; rw.out_w = w->reg_out_w; rw.out_b = w->reg_out_b;
+    for (int l = 0; l < 20; ++l) { rw.blk_w[l] = w->reg_blk_w[l]; rw.blk_b[l] = w->reg_blk_b[l]; }
+    int rc = egx_launch_regressor_fused(st, rw, out_Y, betas, A, M, out_Yb);
+    if (rc) return rc;
   }
-  egx_launch_cont6d_to_aa(st, xb6, M, out_Yb, 93);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

@@ -82,6 +82,8 @@ class GAMMAPPOPolicy(nn.Module):
         self._seed = seed
         self._perm_gen = torch.Generator().manual_seed(seed)
         self._flat_grad: Optional[torch.Tensor] = None
+        self._graph_cache: dict = {}
+        self.use_update_graph = bool(_ignored.get("use_update_graph", False))
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     # ---- rollout side (HIP) -------------------------------------------------------------------------
@@ -178,50 +180,142 @@ class GAMMAPPOPolicy(nn.Module):
         return loss, {"loss": loss, "loss/clip": clip_loss, "loss/vf": vf_loss, "loss/ent": ent_loss, "loss/kld": kld_loss,
                       "approx_kl": (logp_old - lp).sum() * scale}
 
+    # ---- one optimiser step, eager or as replayed HIP graphs --------------------------------------------
+    def _gather(self, batch: RolloutBatch, idx: torch.Tensor):
+        N = batch.n * batch.A
+        obs_all = batch.obs_flat()
+        obs = {k: v.index_select(0, idx) for k, v in obs_all.items()}
+        return (obs, batch.act.reshape(N, 128).index_select(0, idx), batch.adv.reshape(N).index_select(0, idx),
+                batch.returns.reshape(N).index_select(0, idx), batch.logp_old.reshape(N).index_select(0, idx))
+
+    def _fwd_bwd(self, batch, idx, gstats, log_out):
+        obs, act, adv, ret, lpo = self._gather(batch, idx)
+        loss, terms = self.minibatch_loss(obs, act, adv, ret, lpo, gstats)
+        self._flat_grad.zero_()
+        loss.backward()
+        log_out.copy_(torch.stack([terms[k].detach() for k in ("loss", "loss/clip", "loss/vf", "loss/ent", "loss/kld", "approx_kl")]))
+
+    def _clip_and_step(self):
+        if self._grad_norm:
+            nn.utils.clip_grad_norm_(self._actor_critic.parameters(), max_norm=self._grad_norm)
+        self.optim.step()
+
+    def _adv_moments(self, batch, idx, out):
+        adv = batch.adv.reshape(-1).index_select(0, idx).double()
+        out.copy_(torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), dtype=torch.float64, device=adv.device)]))
+
+    def _graphs_for(self, batch: RolloutBatch, local_bs: int):
+        """Capture (gather + forward + loss + backward) and (clip + AdamW) for a fixed minibatch size.  With one rank
+        both halves live in one graph; with several, the RCCL all-reduces run eagerly between the two replays."""
+        key = (id(batch), local_bs)
+        g = self._graph_cache.get(key)
+        if g is not None:
+            return g
+        dev = batch.act.device
+        st = {"idx": torch.zeros(local_bs, dtype=torch.long, device=dev), "log": torch.zeros(6, device=dev),
+              "gstats": torch.zeros(3, device=dev), "use_gstats": self.world_size > 1}
+        gs = (lambda: (st["gstats"][0], st["gstats"][1], st["gstats"][2])) if st["use_gstats"] else (lambda: None)
+        try:
+            # warm-up on a side stream (lazy library init, allocator pools) - it performs real optimiser steps on a
+            # throw-away copy of the state, which is restored afterwards
+            snap = {k: v.clone() for k, v in self.state_dict().items()}
+            params = [p_ for g_ in self.optim.param_groups for p_ in g_["params"]]
+            osnap = {id(p_): {k: v.clone() for k, v in self.optim.state.get(p_, {}).items() if torch.is_tensor(v)} for p_ in params}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._fwd_bwd(batch, st["idx"], gs(), st["log"])
+                    self._clip_and_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            g2 = None
+            if self.world_size == 1:
+                with torch.cuda.graph(g1):
+                    self._fwd_bwd(batch, st["idx"], gs(), st["log"])
+                    self._clip_and_step()
+            else:
+                with torch.cuda.graph(g1):
+                    self._fwd_bwd(batch, st["idx"], gs(), st["log"])
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self._clip_and_step()
+            # capture does not execute, but the warm-up steps did: restore parameters and optimiser state IN PLACE
+            # (the graphs hold the addresses of the live tensors)
+            self.load_state_dict(snap)
+            for p_ in params:
+                for k, v in self.optim.state.get(p_, {}).items():
+                    if torch.is_tensor(v):
+                        old_v = osnap[id(p_)].get(k)
+                        v.copy_(old_v) if old_v is not None else v.zero_()
+            st["g1"], st["g2"] = g1, g2
+        except Exception as e:  # capture unsupported for some op on this stack: run the same ops eagerly
+            import warnings
+            warnings.warn(f"PPO update graph capture failed ({type(e).__name__}: {e}); running the update eagerly")
+            st["g1"] = st["g2"] = None
+            st["failed"] = True
+        self._graph_cache[key] = st
+        return st
+
     def learn(self, batch: RolloutBatch, batch_size: int, repeat: int) -> Dict[str, List[float]]:
         """ppo_policy.py:182-265.  `batch_size` is the GLOBAL minibatch size; each rank contributes batch_size/world."""
         self.train()
         self._ensure_flat_grads()
         ws = self.world_size
         N = batch.n * batch.A
+        dev = batch.act.device
         local_bs = max(1, batch_size // ws)
-        obs_all = batch.obs_flat()
-        act_all = batch.act.reshape(N, 128)
-        adv_all, ret_all, lpo_all = batch.adv.reshape(N), batch.returns.reshape(N), batch.logp_old.reshape(N)
-        stats = {k: [] for k in ("loss", "loss/clip", "loss/vf", "loss/ent", "loss/kld")}
+        names = ("loss", "loss/clip", "loss/vf", "loss/ent", "loss/kld")
+        stats = {k: [] for k in names}
         logs = []
+        use_graph = self.use_update_graph and dev.type == "cuda"
         for _ in range(repeat):
-            perm = torch.randperm(N, generator=self._perm_gen).to(act_all.device)
+            perm = torch.randperm(N, generator=self._perm_gen).to(dev)
             # Batch.split(size, shuffle=True, merge_last=True)
             bounds = list(range(0, N, local_bs))
             if len(bounds) > 1 and N - bounds[-1] < local_bs:
                 bounds.pop()
-            kl = None
+            last_log = None
             for i, s in enumerate(bounds):
                 e = bounds[i + 1] if i + 1 < len(bounds) else N
                 idx = perm[s:e]
-                obs = {k: v[idx] for k, v in obs_all.items()}
-                adv = adv_all[idx]
-                gstats = None
-                if ws > 1:
-                    mom = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device)]).double()
-                    dist.all_reduce(mom)
-                    ng = mom[2]
-                    mean = mom[0] / ng
-                    var = (mom[1] - ng * mean * mean) / (ng - 1)       # unbiased, like Tensor.std()
-                    gstats = (mean.float(), var.clamp(min=0).sqrt().float(), ng.float())
-                loss, terms = self.minibatch_loss(obs, act_all[idx], adv, ret_all[idx], lpo_all[idx], gstats)
-                self._flat_grad.zero_()
-                loss.backward()
-                if ws > 1:
-                    dist.all_reduce(self._flat_grad)
-                if self._grad_norm:
-                    nn.utils.clip_grad_norm_(self._actor_critic.parameters(), max_norm=self._grad_norm)
-                self.optim.step()
-                logs.append(torch.stack([terms[k].detach() for k in stats]))
-                kl = terms["approx_kl"].detach()
+                st = self._graphs_for(batch, local_bs) if (use_graph and e - s == local_bs) else None
+                if st is not None and st.get("g1") is not None:
+                    st["idx"].copy_(idx)
+                    if ws > 1:
+                        mom = torch.zeros(3, dtype=torch.float64, device=dev)
+                        self._adv_moments(batch, st["idx"], mom)
+                        dist.all_reduce(mom)
+                        ng = mom[2]
+                        mean = mom[0] / ng
+                        var = (mom[1] - ng * mean * mean) / (ng - 1)
+                        st["gstats"].copy_(torch.stack([mean, var.clamp(min=0).sqrt(), ng]).float())
+                    st["g1"].replay()
+                    if ws > 1:
+                        dist.all_reduce(self._flat_grad)
+                        st["g2"].replay()
+                    last_log = st["log"].clone()
+                else:
+                    gstats = None
+                    if ws > 1:
+                        mom = torch.zeros(3, dtype=torch.float64, device=dev)
+                        self._adv_moments(batch, idx, mom)
+                        dist.all_reduce(mom)
+                        ng = mom[2]
+                        mean = mom[0] / ng
+                        var = (mom[1] - ng * mean * mean) / (ng - 1)       # unbiased, like Tensor.std()
+                        gstats = (mean.float(), var.clamp(min=0).sqrt().float(), ng.float())
+                    log = torch.zeros(6, device=dev)
+                    self._fwd_bwd(batch, idx, gstats, log)
+                    if ws > 1:
+                        dist.all_reduce(self._flat_grad)
+                    self._clip_and_step()
+                    last_log = log
+                logs.append(last_log[:5])
             # early stop on the last minibatch's approximate KL (ppo_policy.py:252-257); inert at repeat=1
-            if repeat > 1 and kl is not None:
+            if repeat > 1 and last_log is not None:
+                kl = last_log[5].clone()
                 if ws > 1:
                     dist.all_reduce(kl)
                 if float(kl.item()) >= 0.02:
@@ -230,8 +324,7 @@ class GAMMAPPOPolicy(nn.Module):
             L = torch.stack(logs)
             if ws > 1:
                 dist.all_reduce(L)
-            L = L.cpu().tolist()
-            for row in L:
-                for k, v in zip(stats, row):
+            for row in L.cpu().tolist():
+                for k, v in zip(names, row):
                     stats[k].append(v)
         return stats

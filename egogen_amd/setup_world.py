@@ -126,12 +126,14 @@ def build_policy(args, device="cuda") -> GAMMAPPOPolicy:
             torch.nn.init.zeros_(m.bias)
             m.weight.data.copy_(0.01 * m.weight.data)
     actor_critic.to(device)
-    optim = torch.optim.AdamW(actor_critic.parameters(), lr=args.lr, weight_decay=0.01)
+    graph = bool(getattr(args, "update_graph", False))
+    optim = torch.optim.AdamW(actor_critic.parameters(), lr=args.lr, weight_decay=0.01, capturable=graph, foreach=True if graph else None)
     policy = GAMMAPPOPolicy(actor, critic, shared_net, optim, None, discount_factor=args.gamma, gae_lambda=args.gae_lambda,
                             max_grad_norm=args.max_grad_norm, vf_coef=args.vf_coef, ent_coef=args.ent_coef,
                             weight_kld=args.weight_kld, reward_normalization=args.rew_norm, eps_clip=args.eps_clip,
                             value_clip=args.value_clip, dual_clip=args.dual_clip, advantage_normalization=args.norm_adv,
-                            recompute_advantage=args.recompute_adv, deterministic_eval=args.deterministic_eval, seed=args.seed)
+                            recompute_advantage=args.recompute_adv, deterministic_eval=args.deterministic_eval, seed=args.seed,
+                            use_update_graph=graph)
     return policy
 
 
