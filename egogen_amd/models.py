@@ -185,12 +185,24 @@ class MLPBlock(nn.Module):
         return self.out_fc(h)
 
 
+_FREQ_CACHE: dict = {}
+
+
+def _exact_freqs(L: int, device, dtype) -> torch.Tensor:
+    """2^0..2^(L-1), built exactly on the host once per (device, dtype): a device-side pow() is not exact for 2^31 and
+    sin/cos of x * 2^k are extremely sensitive to the last bit of the argument.  Cached so that no host-to-device copy
+    happens inside a captured HIP graph."""
+    key = (L, str(device), dtype)
+    f = _FREQ_CACHE.get(key)
+    if f is None:
+        f = torch.ldexp(torch.ones(L, dtype=torch.float32), torch.arange(L)).to(device=device, dtype=dtype)
+        _FREQ_CACHE[key] = f
+    return f
+
+
 def positional_encoding(x: torch.Tensor, L: int = 32) -> torch.Tensor:
     """models_policy_ppo.py:276-285: x[b,1] -> [b,2L], [sin(x 2^k), cos(x 2^k)] interleaved per k."""
-    # exact powers of two built on the host (a device-side pow() is not exact for 2^31, and sin/cos of
-    # x * 2^k are extremely sensitive to the last bit of the argument)
-    freqs = torch.ldexp(torch.ones(L, dtype=torch.float32), torch.arange(L)).to(device=x.device, dtype=x.dtype)
-    xf = x * freqs  # [b,L]
+    xf = x * _exact_freqs(L, x.device, x.dtype)  # [b,L]
     return torch.stack([torch.sin(xf), torch.cos(xf)], dim=-1).reshape(x.shape[0], 2 * L)
 
 

@@ -202,7 +202,9 @@ class GAMMAPPOPolicy(nn.Module):
 
     def _adv_moments(self, batch, idx, out):
         adv = batch.adv.reshape(-1).index_select(0, idx).double()
-        out.copy_(torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), dtype=torch.float64, device=adv.device)]))
+        out[0] = adv.sum()
+        out[1] = (adv * adv).sum()
+        out[2] = float(adv.numel())
 
     def _graphs_for(self, batch: RolloutBatch, local_bs: int):
         """Capture (gather + forward + loss + backward) and (clip + AdamW) for a fixed minibatch size.  With one rank
