@@ -34,7 +34,7 @@ class BodyModelHost(C.Structure):
 
 class SdfGrid(C.Structure):
     _fields_ = [("grid", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("d2", C.c_int),
-                ("center", C.c_float * 3), ("scale", C.c_float)]
+                ("center", C.c_float * 3), ("scale", C.c_float), ("coarse_minmax", C.c_void_p)]
 
 
 class LinearDesc(C.Structure):
@@ -108,6 +108,8 @@ SIGNATURES = {
                                   C.c_void_p, C.POINTER(SdfGrid), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "egx_sdf_sample": (C.c_int, [C.POINTER(SdfGrid), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "egx_sdf_coarse_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "egx_sdf_build_coarse": (C.c_int, [C.POINTER(SdfGrid), C.c_void_p, C.c_void_p]),
     "egx_linear": (C.c_int, [C.POINTER(LinearDesc), C.c_void_p]),
     "egx_gru_pointwise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egx_cont6d_to_aa": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

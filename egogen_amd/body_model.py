@@ -47,6 +47,14 @@ class SdfScene:
         c = c.reshape(-1).astype(np.float32)
         self.desc.center[0], self.desc.center[1], self.desc.center[2] = float(c[0]), float(c[1]), float(c[2])
         self.desc.scale = s
+        self.desc.coarse_minmax = None
+        if self.grid.is_cuda:
+            lib = _lib.load()
+            nbytes = lib.egx_sdf_coarse_bytes(self.desc.d0, self.desc.d1, self.desc.d2)
+            self.coarse = torch.empty(nbytes, dtype=torch.uint8, device=self.grid.device)
+            _lib.check(lib.egx_sdf_build_coarse(C.byref(self.desc), _lib.ptr(self.coarse), _lib.current_stream_ptr()),
+                       "egx_sdf_build_coarse")
+            self.desc.coarse_minmax = self.coarse.data_ptr()
 
 
 class BodyModelHandle:

@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
           const float wx = Rw[q][0] * ox + Rw[q][1] * oy + Rw[q][2] * oz + Tw[q][0];
           const float wy = Rw[q][3] * ox + Rw[q][4] * oy + Rw[q][5] * oz + Tw[q][1];
           const float wz = Rw[q][6] * ox + Rw[q][7] * oy + Rw[q][8] * oz + Tw[q][2];
-          cnt[q] += (egx_sdf_neg_trilinear(p.sdf, wx, wy, wz) < 0.f) ? 1 : 0;
+          int sg = p.sdf.coarse ? egx_sdf_coarse_sign(p.sdf, wx, wy, wz) : 0;
+          if (sg == 0) sg = (egx_sdf_neg_trilinear(p.sdf, wx, wy, wz) < 0.f) ? 1 : -1;
+          cnt[q] += (sg > 0) ? 1 : 0;
         }
       }
       if (p.picked) {
@@ -595,6 +597,8 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     if (sdf) {
       p.sdf.grid = sdf->grid; p.sdf.d0 = sdf->d0; p.sdf.d1 = sdf->d1; p.sdf.d2 = sdf->d2;
       p.sdf.cx = sdf->center[0]; p.sdf.cy = sdf->center[1]; p.sdf.cz = sdf->center[2]; p.sdf.scale = sdf->scale;
+      p.sdf.coarse = static_cast<const float2*>(sdf->coarse_minmax);
+      p.sdf.c0 = egx_ceil_div(sdf->d0, 4); p.sdf.c1 = egx_ceil_div(sdf->d1, 4); p.sdf.c2 = egx_ceil_div(sdf->d2, 4);
       EGX_HIP_CHECK(hipMemsetAsync(out_pene_count, 0, (size_t)B * sizeof(int32_t), stream));
     }
     const int per = (p.nbg + 7) / 8;

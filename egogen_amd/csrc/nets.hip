@@ -10,15 +10,12 @@
 
 namespace {
 
-struct Seg {
-  const float* p;
-  int w;   // width (columns)
-  int ld;  // leading dimension (floats)
-};
-
+// NOTE: no arrays inside the kernel-argument struct - a runtime-indexed member array makes hipcc copy the whole
+// struct to scratch and turns every operand load into scratch + flat traffic (measured: 5x slower).
 struct LinArgs {
-  Seg x[4];
-  int nseg;
+  const float *xp0, *xp1, *xp2, *xp3;  // up to 4 concatenated input segments
+  int xw0, xw1, xw2, xw3;              // widths (0 = unused)
+  int xl0, xl1, xl2, xl3;              // leading dimensions
   const float* W;   // [N,K], ld = ldw
   int ldw;
   const float* bias;  // [N] or null
@@ -33,32 +30,37 @@ struct LinArgs {
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-__device__ __forceinline__ float seg_load1(const LinArgs& a, int row, int k) {
-  int kk = k;
+// 4 consecutive k of the concatenated input starting at local offset kk of segment (p,w,l); elements past the end of
+// the segment come from the next segment (pn,wn,ln) or are zero.  Segment widths are >= 4, so two segments suffice.
+__device__ __forceinline__ f32x4 load_straddle(const float* p, int w, int l, const float* pn, int wn, int ln, int row, int kk) {
+  f32x4 v;
+  const float* r0 = p + (size_t)row * l;
+  const float* r1 = pn ? pn + (size_t)row * ln : nullptr;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (s < a.nseg) {
-      if (kk < a.x[s].w) return a.x[s].p[(size_t)row * a.x[s].ld + kk];
-      kk -= a.x[s].w;
-    }
+  for (int e = 0; e < 4; ++e) {
+    const int idx = kk + e;
+    float x = 0.f;
+    if (idx < w) x = r0[idx];
+    else if (r1 && idx - w < wn) x = r1[idx - w];
+    v[e] = x;
   }
-  return 0.f;
+  return v;
 }
 
 __device__ __forceinline__ f32x4 load_x4(const LinArgs& a, int row, int k) {
   int kk = k;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (s < a.nseg) {
-      if (kk + 3 < a.x[s].w) return *reinterpret_cast<const f32x4u*>(a.x[s].p + (size_t)row * a.x[s].ld + kk);
-      if (kk < a.x[s].w) break;  // straddles the end of this segment
-      kk -= a.x[s].w;
-    }
-  }
-  f32x4 v;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = (k + e < a.K) ? seg_load1(a, row, k + e) : 0.f;
-  return v;
+  if (kk + 3 < a.xw0) return *reinterpret_cast<const f32x4u*>(a.xp0 + (size_t)row * a.xl0 + kk);
+  if (kk < a.xw0) return load_straddle(a.xp0, a.xw0, a.xl0, a.xp1, a.xw1, a.xl1, row, kk);
+  kk -= a.xw0;
+  if (kk + 3 < a.xw1) return *reinterpret_cast<const f32x4u*>(a.xp1 + (size_t)row * a.xl1 + kk);
+  if (kk < a.xw1) return load_straddle(a.xp1, a.xw1, a.xl1, a.xp2, a.xw2, a.xl2, row, kk);
+  kk -= a.xw1;
+  if (kk + 3 < a.xw2) return *reinterpret_cast<const f32x4u*>(a.xp2 + (size_t)row * a.xl2 + kk);
+  if (kk < a.xw2) return load_straddle(a.xp2, a.xw2, a.xl2, a.xp3, a.xw3, a.xl3, row, kk);
+  kk -= a.xw2;
+  if (kk + 3 < a.xw3) return *reinterpret_cast<const f32x4u*>(a.xp3 + (size_t)row * a.xl3 + kk);
+  if (kk < a.xw3) return load_straddle(a.xp3, a.xw3, a.xl3, nullptr, 0, 0, row, kk);
+  return f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 __device__ __forceinline__ f32x4 load_w4(const LinArgs& a, int col, int k) {
@@ -82,64 +84,96 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 }  // namespace
 
 __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs a) {
-  __shared__ float red[3][16 * 64];
+  // Each wave owns a quarter of K and walks it in blocks of 32: the 32x32 X block and the 32x32 W block are fetched
+  // with row-contiguous 16-byte loads (8 lanes cover one 128-byte row segment: every cache line is requested once and
+  // used completely), parked in a wave-private LDS strip with a 36-float row pitch, and read back as MFMA operand
+  // fragments with conflict-free ds_read_b128.  The next block's global loads are in flight during the 16 MFMAs.
+  __shared__ __attribute__((aligned(16))) float stage[4][2][32 * 36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-  const int row = min(m0 + i, a.M - 1), col = min(n0 + i, a.N - 1);
-  const int nchunk = (a.K + 7) >> 3;
-  const int per = (nchunk + 3) >> 2;
-  const int c0 = wave * per, c1 = min(nchunk, c0 + per);
+  // XCD-aware tile map (blocks are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2): every XCD gets a
+  // contiguous chunk of tiles along the LONGER tile axis and sweeps the other axis, so it touches 1/8 of one operand
+  // and all of the other instead of everything.
+  int mt, nt;
+  {
+    const int MT = (a.M + 31) >> 5, NT = (a.N + 31) >> 5;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    if (NT >= MT) {
+      const int per = (NT + 7) >> 3;
+      nt = xcd * per + local / MT;
+      mt = local % MT;
+      if (local >= per * MT || nt >= NT) return;
+    } else {
+      const int per = (MT + 7) >> 3;
+      mt = xcd * per + local / NT;
+      nt = local % NT;
+      if (local >= per * NT || mt >= MT) return;
+    }
+  }
+  const int m0 = mt * 32, n0 = nt * 32;
+  const int nblk = (a.K + 31) >> 5;
+  const int per = (nblk + 3) >> 2;
+  const int b0 = wave * per, b1 = min(nblk, b0 + per);
+  const int lr = lane >> 3, lc = (lane & 7) * 4;  // loader role: row lr (+8q), k offset lc
+  float* xs = stage[wave][0];
+  float* ws = stage[wave][1];
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // groups of PF chunks (8 k each), double buffered: the 2*PF loads of the next group are in flight while the
-  // 4*PF MFMAs (64 cycles each) of the current group execute, which covers the global-load latency.
-  constexpr int PF = 4;
-  if (c0 < c1) {
-    f32x4 xa[PF], wb[PF];
+  if (b0 < b1) {
+    // two K-blocks of global loads stay in flight (registers) while the current block is multiplied out of LDS
+    f32x4 gx[2][4], gw[2][4];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int c = min(c0 + u, c1 - 1);
-      xa[u] = load_x4(a, row, c * 8 + 4 * h);
-      wb[u] = load_w4(a, col, c * 8 + 4 * h);
+    for (int u = 0; u < 2; ++u) {
+      const int bb = min(b0 + u, b1 - 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        gx[u][q] = load_x4(a, min(m0 + q * 8 + lr, a.M - 1), bb * 32 + lc);
+        gw[u][q] = load_w4(a, min(n0 + q * 8 + lr, a.N - 1), bb * 32 + lc);
+      }
     }
-    for (int cg = c0; cg < c1; cg += PF) {
-      f32x4 xn[PF], wn[PF];
-      const bool more = cg + PF < c1;
-      if (more) {
+    for (int b = b0; b < b1; b += 2) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          const int c = min(cg + PF + u, c1 - 1);
-          xn[u] = load_x4(a, row, c * 8 + 4 * h);
-          wn[u] = load_w4(a, col, c * 8 + 4 * h);
+      for (int u = 0; u < 2; ++u) {
+        if (b + u < b1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<f32x4*>(xs + (q * 8 + lr) * 36 + lc) = gx[u][q];
+            *reinterpret_cast<f32x4*>(ws + (q * 8 + lr) * 36 + lc) = gw[u][q];
+          }
+          if (b + u + 2 < b1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              gx[u][q] = load_x4(a, min(m0 + q * 8 + lr, a.M - 1), (b + u + 2) * 32 + lc);
+              gw[u][q] = load_w4(a, min(n0 + q * 8 + lr, a.N - 1), (b + u + 2) * 32 + lc);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
+          }
         }
-      }
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        if (cg + u < c1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][e], wb[u][e], acc, 0, 0, 0);
-        }
-      }
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) { xa[u] = xn[u]; wb[u] = wn[u]; }
       }
     }
   }
+  // split-K reduction through the (now idle) staging strips
+  __syncthreads();
+  float* red = &stage[0][0][0];
   if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave - 1][r * 64 + lane] = acc[r];
+    for (int r = 0; r < 16; ++r) red[wave * 2304 + r * 64 + lane] = acc[r];
   }
   __syncthreads();
   if (wave == 0) {
     const int n = n0 + i;
-    const float b = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+    const float bsv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      float v = acc[r] + red[0][r * 64 + lane] + red[1][r * 64 + lane] + red[2][r * 64 + lane] + b;
+      float v = acc[r] + red[2304 + r * 64 + lane] + red[2 * 2304 + r * 64 + lane] + red[3 * 2304 + r * 64 + lane] + bsv;
       v = apply_act(v, a.act, a.slope);
       if (m < a.M && n < a.N) {
         if (a.res) v += a.res[(size_t)m * a.ldr + n];
@@ -406,18 +440,21 @@ __global__ void egx_gae_kernel(const float* __restrict__ v, const float* __restr
 int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg, const float* W, const float* b,
                       int act, float slope, const float* res, int ldr, float* out, int ldo) {
   LinArgs a;
-  a.nseg = nseg;
+  const float* ps[4] = {nullptr, nullptr, nullptr, nullptr};
+  int ws[4] = {0, 0, 0, 0}, ls[4] = {0, 0, 0, 0};
   int K = 0;
-  for (int s = 0; s < 4; ++s) {
-    a.x[s].p = s < nseg ? segs[s].p : nullptr;
-    a.x[s].w = s < nseg ? segs[s].w : 0;
-    a.x[s].ld = s < nseg ? segs[s].ld : 0;
-    if (s < nseg) K += segs[s].w;
+  for (int s = 0; s < nseg; ++s) {
+    ps[s] = segs[s].p; ws[s] = segs[s].w; ls[s] = segs[s].ld;
+    K += segs[s].w;
   }
+  a.xp0 = ps[0]; a.xp1 = ps[1]; a.xp2 = ps[2]; a.xp3 = ps[3];
+  a.xw0 = ws[0]; a.xw1 = ws[1]; a.xw2 = ws[2]; a.xw3 = ws[3];
+  a.xl0 = ls[0]; a.xl1 = ls[1]; a.xl2 = ls[2]; a.xl3 = ls[3];
   a.W = W; a.ldw = K; a.bias = b; a.res = res; a.ldr = ldr; a.y = out; a.ldy = ldo;
   a.M = M; a.N = N; a.K = K; a.act = act; a.slope = slope;
-  dim3 grid(egx_ceil_div(M, 32), egx_ceil_div(N, 32));
-  hipLaunchKernelGGL(egx_linear_kernel, grid, dim3(256), 0, st, a);
+  const int MT = egx_ceil_div(M, 32), NT = egx_ceil_div(N, 32);
+  const int grid = (NT >= MT) ? 8 * egx_ceil_div(NT, 8) * MT : 8 * egx_ceil_div(MT, 8) * NT;
+  hipLaunchKernelGGL(egx_linear_kernel, dim3(grid), dim3(256), 0, st, a);
   return EGX_OK;
 }
 
@@ -448,6 +485,7 @@ extern "C" int egx_linear(const egx_linear_desc* d, void* stream_) {
   for (int s = 0; s < d->num_segments; ++s) {
     segs[s] = {d->seg_ptr[s], d->seg_width[s], d->seg_ld[s]};
     EGX_REQUIRE(segs[s].p && segs[s].w > 0 && segs[s].ld >= segs[s].w, "bad input segment");
+    EGX_REQUIRE(segs[s].w >= 4 || s == d->num_segments - 1, "only the last input segment may be narrower than 4 columns");
     K += segs[s].w;
   }
   EGX_REQUIRE(d->weight_ld == 0 || d->weight_ld == K, "weight_ld other than K is not supported");

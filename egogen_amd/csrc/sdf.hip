@@ -9,11 +9,43 @@ __global__ __launch_bounds__(256) void egx_sdf_sample_kernel(SdfDev s, const flo
   }
 }
 
+// {min,max} over the fine samples a point inside coarse block (bx,by,bz) can touch: indices [4b, 4b+4] per axis
+__global__ void egx_sdf_build_coarse_kernel(const float* __restrict__ grid, int d0, int d1, int d2, int c0, int c1, int c2,
+                                            float2* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= c0 * c1 * c2) return;
+  const int bz = idx % c2, by = (idx / c2) % c1, bx = idx / (c1 * c2);
+  float mn = 3.4e38f, mx = -3.4e38f;
+  for (int x = 4 * bx; x <= min(4 * bx + 4, d0 - 1); ++x)
+    for (int y = 4 * by; y <= min(4 * by + 4, d1 - 1); ++y)
+      for (int z = 4 * bz; z <= min(4 * bz + 4, d2 - 1); ++z) {
+        const float v = grid[((size_t)x * d1 + y) * d2 + z];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+      }
+  out[idx] = make_float2(mn, mx);
+}
+
+extern "C" size_t egx_sdf_coarse_bytes(int d0, int d1, int d2) {
+  if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
+  return (size_t)egx_ceil_div(d0, 4) * egx_ceil_div(d1, 4) * egx_ceil_div(d2, 4) * sizeof(float2);
+}
+
+extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream_) {
+  EGX_REQUIRE(sdf && sdf->grid && coarse_out && sdf->d0 > 0 && sdf->d1 > 0 && sdf->d2 > 0, "bad arguments");
+  const int c0 = egx_ceil_div(sdf->d0, 4), c1 = egx_ceil_div(sdf->d1, 4), c2 = egx_ceil_div(sdf->d2, 4);
+  const int n = c0 * c1 * c2;
+  hipLaunchKernelGGL(egx_sdf_build_coarse_kernel, dim3(egx_ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     sdf->grid, sdf->d0, sdf->d1, sdf->d2, c0, c1, c2, static_cast<float2*>(coarse_out));
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
 extern "C" int egx_sdf_sample(const egx_sdf_grid* sdf, const float* pts, int64_t n, float* out, void* stream_) {
   EGX_REQUIRE(sdf && sdf->grid && sdf->d0 > 0 && sdf->d1 > 0 && sdf->d2 > 0, "bad sdf grid");
   if (n == 0) return EGX_OK;  // empty input is legal
   EGX_REQUIRE(pts && out && n > 0, "null points / output");
-  SdfDev s{sdf->grid, sdf->d0, sdf->d1, sdf->d2, sdf->center[0], sdf->center[1], sdf->center[2], sdf->scale};
+  SdfDev s{sdf->grid, sdf->d0, sdf->d1, sdf->d2, sdf->center[0], sdf->center[1], sdf->center[2], sdf->scale, nullptr, 0, 0, 0};
   const int64_t blocks = (n + 255) / 256;
   const int grid = (int)(blocks < 4096 ? blocks : 4096);
   hipLaunchKernelGGL(egx_sdf_sample_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), s, pts, n, out);

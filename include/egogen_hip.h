@@ -76,7 +76,14 @@ typedef struct egx_sdf_grid {
   int d0, d1, d2;
   float center[3];
   float scale;
+  const void* coarse_minmax; /* optional device table from egx_sdf_build_coarse (NULL = always sample the fine grid) */
 } egx_sdf_grid;
+
+/* Acceleration table for the penetration COUNT of egx_lbs_forward: {min,max} of the fine samples each 4x4x4 block's
+ * interpolation footprint can touch.  Trilinear interpolation is a convex combination, so a block whose bracket does not
+ * contain 0 decides `calc_sdf < 0` exactly without gathering from the 64 MiB grid. */
+size_t egx_sdf_coarse_bytes(int d0, int d1, int d2);
+int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream);
 
 /* Bytes of scratch egx_lbs_forward needs for `num_bodies` bodies. */
 size_t egx_lbs_workspace_bytes(const egx_body_model* m, int num_bodies);
