@@ -60,6 +60,7 @@ constexpr int KSTEPS = KDIM / 2;       // 248 MFMA k-steps (32x32x2)
 constexpr int KGROUPS = KSTEPS / 4;    // 62 float4 groups
 constexpr int NLMK = 51, NEXTRA = 21;
 constexpr int BODY_PAD = 256;          // bodies per workgroup of the fused kernel
+constexpr int LBS_NW_MAX = 16;         // skinning weights per vertex held in LDS (ELL width, multiple of 4)
 
 struct PoseConsts {
   int parents[NJ];
@@ -242,6 +243,23 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
   }
   const int bt0 = bg * 8 + wave * NB;  // first 32-body tile of this wave
   const int num_bt = (p.B + 31) >> 5;
+  // per-vertex metadata of this tile (shared by the 4 waves): skinning weights, template, pick slot, flags
+  __shared__ int s_widx[32][LBS_NW_MAX];
+  __shared__ float s_wval[32][LBS_NW_MAX];
+  __shared__ float s_vt[3][32];
+  __shared__ int s_slot[32];
+  __shared__ int s_flag[32];
+  for (int idx = threadIdx.x; idx < 32 * p.NW; idx += 256) {
+    const int row = idx / p.NW, k = idx % p.NW;
+    s_widx[row][k] = p.widx[(size_t)(vt * 32 + row) * p.NW + k];
+    s_wval[row][k] = p.wval[(size_t)(vt * 32 + row) * p.NW + k];
+  }
+  if (threadIdx.x < 96) s_vt[threadIdx.x >> 5][threadIdx.x & 31] = p.vtemp[(vt * 3 + (threadIdx.x >> 5)) * 32 + (threadIdx.x & 31)];
+  if (threadIdx.x >= 128 && threadIdx.x < 160) {
+    s_slot[threadIdx.x - 128] = p.pick_slot[vt * 32 + threadIdx.x - 128];
+    s_flag[threadIdx.x - 128] = p.vflags[vt * 32 + threadIdx.x - 128];
+  }
+  __syncthreads();
 
   f32x16 acc[3][NB];
 #pragma unroll
@@ -283,7 +301,9 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
   }
 
   // ---- epilogue: each lane owns 16 vertices (rows) x NB bodies (col n of tiles bt0+q) ----------
-  float tr[NB][3], Rw[NB][9], Tw[NB][3];
+  // Organised in passes with many independent loads in flight (the first version walked the vertices one dependent
+  // global round trip after the other and spent more cycles here than in the 1488 MFMAs).
+  float tr[NB][3];
   int body[NB];
   bool bvalid[NB];
 #pragma unroll
@@ -294,53 +314,59 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
     tr[q][0] = p.xb[(size_t)bb * EGX_XB_DIM + 0];
     tr[q][1] = p.xb[(size_t)bb * EGX_XB_DIM + 1];
     tr[q][2] = p.xb[(size_t)bb * EGX_XB_DIM + 2];
-    if (DO_SDF) {
-      const int ag = bb / p.fpa;
-#pragma unroll
-      for (int e = 0; e < 9; ++e) Rw[q][e] = p.R0 ? p.R0[(size_t)ag * 9 + e] : ((e % 4 == 0) ? 1.f : 0.f);
-#pragma unroll
-      for (int e = 0; e < 3; ++e) Tw[q][e] = p.T0 ? p.T0[(size_t)ag * 3 + e] : 0.f;
-    }
   }
-  int cnt[NB];
-#pragma unroll
-  for (int q = 0; q < NB; ++q) cnt[q] = 0;
+  // One pass per (body tile, vertex): all per-vertex metadata comes from LDS, the 12 transform rows of a vertex are
+  // fetched together, and the only dependent global access left is the SDF bracket lookup.
   float* lds = reinterpret_cast<float*>(smem_raw) + wave * (32 * 97);
-
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
-    const int btq = min(bt0 + q, num_bt - 1);
-    const f32x4* Aq = p.A4 + (size_t)btq * NJ * 3 * 32 + n;
+    const f32x4* Aq = p.A4 + (size_t)min(bt0 + q, num_bt - 1) * NJ * 3 * 32 + n;
+    float Rw[9], Tw[3];
+    if (DO_SDF) {
+      const int ag = (bvalid[q] ? body[q] : p.B - 1) / p.fpa;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rw[e] = p.R0 ? p.R0[(size_t)ag * 9 + e] : ((e % 4 == 0) ? 1.f : 0.f);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Tw[e] = p.T0 ? p.T0[(size_t)ag * 3 + e] : 0.f;
+    }
+    int cnt = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int vslot = vt * 32 + row;
-      const uint8_t fl = p.vflags[vslot];
-      const float vx = acc[0][q][r] + p.vtemp[(vt * 3 + 0) * 32 + row];
-      const float vy = acc[1][q][r] + p.vtemp[(vt * 3 + 1) * 32 + row];
-      const float vz = acc[2][q][r] + p.vtemp[(vt * 3 + 2) * 32 + row];
       f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
-      for (int k = 0; k < p.NW; ++k) {
-        const int jn = p.widx[(size_t)vslot * p.NW + k];
-        const float wv = p.wval[(size_t)vslot * p.NW + k];
-        const f32x4 r0 = Aq[(jn * 3 + 0) * 32], r1 = Aq[(jn * 3 + 1) * 32], r2 = Aq[(jn * 3 + 2) * 32];
-        t0 += wv * r0; t1 += wv * r1; t2 += wv * r2;
+      for (int k0 = 0; k0 < p.NW; k0 += 4) {  // NW is padded to a multiple of 4 at load time (zero weights)
+        f32x4 ld[4][3];
+        float wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // 12 independent 16-byte loads in flight
+          const int jn = s_widx[row][k0 + k];
+          wv[k] = s_wval[row][k0 + k];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) ld[k][c] = Aq[(jn * 3 + c) * 32];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          t0 += wv[k] * ld[k][0];
+          t1 += wv[k] * ld[k][1];
+          t2 += wv[k] * ld[k][2];
+        }
       }
+      const float vx = acc[0][q][r] + s_vt[0][row], vy = acc[1][q][r] + s_vt[1][row], vz = acc[2][q][r] + s_vt[2][row];
       const float ox = t0[0] * vx + t0[1] * vy + t0[2] * vz + t0[3] + tr[q][0];
       const float oy = t1[0] * vx + t1[1] * vy + t1[2] * vz + t1[3] + tr[q][1];
       const float oz = t2[0] * vx + t2[1] * vy + t2[2] * vz + t2[3] + tr[q][2];
       if (DO_SDF) {
-        if ((fl & 3) == 2) {  // valid, not a feet vertex
-          const float wx = Rw[q][0] * ox + Rw[q][1] * oy + Rw[q][2] * oz + Tw[q][0];
-          const float wy = Rw[q][3] * ox + Rw[q][4] * oy + Rw[q][5] * oz + Tw[q][1];
-          const float wz = Rw[q][6] * ox + Rw[q][7] * oy + Rw[q][8] * oz + Tw[q][2];
+        if ((s_flag[row] & 3) == 2) {  // valid, not a feet vertex
+          const float wx = Rw[0] * ox + Rw[1] * oy + Rw[2] * oz + Tw[0];
+          const float wy = Rw[3] * ox + Rw[4] * oy + Rw[5] * oz + Tw[1];
+          const float wz = Rw[6] * ox + Rw[7] * oy + Rw[8] * oz + Tw[2];
           int sg = p.sdf.coarse ? egx_sdf_coarse_sign(p.sdf, wx, wy, wz) : 0;
           if (sg == 0) sg = (egx_sdf_neg_trilinear(p.sdf, wx, wy, wz) < 0.f) ? 1 : -1;
-          cnt[q] += (sg > 0) ? 1 : 0;
+          cnt += (sg > 0) ? 1 : 0;
         }
       }
       if (p.picked) {
-        const int slot = p.pick_slot[vslot];
+        const int slot = s_slot[row];
         if (slot >= 0 && bvalid[q]) {
           float* o = p.picked + ((size_t)body[q] * p.NP + slot) * 3;
           o[0] = ox; o[1] = oy; o[2] = oz;
@@ -351,10 +377,15 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
         lds[n * 97 + row * 3 + 1] = oy;
         lds[n * 97 + row * 3 + 2] = oz;
       }
+      asm volatile("" ::: "memory");
+    }
+    if (DO_SDF) {
+      const int c2 = cnt + __shfl_xor(cnt, 32);
+      if (half == 0 && bvalid[q] && c2 != 0) atomicAdd(p.pene + body[q], c2);
     }
     if (WRITE_VERTS) {
       // transpose through LDS: every body row is 32 vertices x 3 = 96 contiguous floats in HBM
-      // wave-private LDS region: DS ops of one wave execute in order, no barrier needed
+      // (wave-private LDS region: DS ops of one wave execute in order, no barrier needed)
       const int vbase = vt * 32;
       const int nv = min(32, p.V - vbase);
       for (int bi = 0; bi < 32; ++bi) {
@@ -363,13 +394,6 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
         float* o = p.verts + ((size_t)bd * p.V + vbase) * 3;
         for (int f = lane; f < nv * 3; f += 64) o[f] = lds[bi * 97 + f];
       }
-    }
-  }
-  if (DO_SDF) {
-#pragma unroll
-    for (int q = 0; q < NB; ++q) {
-      int c = cnt[q] + __shfl_xor(cnt[q], 32);
-      if (half == 0 && bvalid[q] && c != 0) atomicAdd(p.pene + body[q], c);
     }
   }
 }
@@ -456,6 +480,12 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
     int c = 0;
     for (int j = 0; j < NJ; ++j) c += d->lbs_weights_host[(size_t)v * NJ + j] != 0.f;
     NW = std::max(NW, c);
+  }
+  NW = (NW + 3) / 4 * 4;  // zero-weight padding: the skinning loop works in groups of 4
+  if (NW > LBS_NW_MAX) {
+    delete m;
+    egx_set_error("more than 16 non-zero skinning weights on one vertex are not supported");
+    return EGX_ERR_ARG;
   }
   m->NW = NW;
   std::vector<int> widx((size_t)VP * NW, 0);

@@ -43,6 +43,19 @@ struct SdfDev {
   int c0, c1, c2;
 };
 
+__device__ __forceinline__ float2 egx_sdf_coarse_fetch(const SdfDev& s, float x, float y, float z) {
+  const float nx = __fmul_rn(__fsub_rn(x, s.cx), s.scale), ny = __fmul_rn(__fsub_rn(y, s.cy), s.scale),
+              nz = __fmul_rn(__fsub_rn(z, s.cz), s.scale);
+  float px = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.f), (float)s.d0), 1.f), 0.5f);
+  float py = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.f), (float)s.d1), 1.f), 0.5f);
+  float pz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nz, 1.f), (float)s.d2), 1.f), 0.5f);
+  px = fminf(fmaxf(px, 0.f), (float)(s.d0 - 1));
+  py = fminf(fmaxf(py, 0.f), (float)(s.d1 - 1));
+  pz = fminf(fmaxf(pz, 0.f), (float)(s.d2 - 1));
+  const int ix = (int)floorf(px) >> 2, iy = (int)floorf(py) >> 2, iz = (int)floorf(pz) >> 2;
+  return s.coarse[((size_t)ix * s.c1 + iy) * s.c2 + iz];
+}
+
 // Sign of calc_sdf at a point without touching the fine grid when the coarse {min,max} brackets decide it:
 // trilinear interpolation is a convex combination of the 8 corners, so if every value the footprint can touch is
 // negative (free space) the result is negative and -result > 0: not penetrating; if all are positive: penetrating.
