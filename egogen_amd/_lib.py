@@ -129,6 +129,9 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p]),
     "egx_gae": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p,
                           C.c_void_p, C.c_void_p]),
+    "egx_ppo_loss": (C.c_int, [C.c_void_p] * 9 + [C.c_float] * 6 + [C.c_int] + [C.c_void_p] * 5),
+    "egx_gru_pointwise_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "egx_profile_next_lbs": (C.c_int, [C.c_void_p, C.c_void_p]),
     "egx_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "egx_event_destroy": (C.c_int, [C.c_void_p]),

@@ -1,0 +1,71 @@
+"""Custom autograd nodes backed by libegogen_hip.so for the PPO update: GRU gate math (forward + backward) and the
+fused clipped-PPO loss with its gradients.  Dense-layer forward/backward stay on torch (rocBLAS) this round."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class GRUPointwiseFn(torch.autograd.Function):
+    """h = (1-z) n + z h_prev with r,z,n from gi = x W_ih^T + b_ih, gh = h_prev W_hh^T + b_hh (gate order r,z,n)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, hprev):
+        lib = _lib.load()
+        gi, gh, hprev = gi.contiguous(), gh.contiguous(), hprev.contiguous()
+        M, H = hprev.shape
+        h = torch.empty_like(hprev)
+        _lib.check(lib.egx_gru_pointwise(_lib.ptr(gi), _lib.ptr(gh), _lib.ptr(hprev), H, _lib.ptr(h), H, M, H,
+                                         _lib.current_stream_ptr()), "egx_gru_pointwise")
+        ctx.save_for_backward(gi, gh, hprev)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        gi, gh, hprev = ctx.saved_tensors
+        M, H = hprev.shape
+        dh = dh.contiguous()
+        dgi, dgh, dhp = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(hprev)
+        _lib.check(lib.egx_gru_pointwise_bwd(_lib.ptr(gi), _lib.ptr(gh), _lib.ptr(hprev), _lib.ptr(dh), M, H, _lib.ptr(dgi),
+                                             _lib.ptr(dgh), _lib.ptr(dhp), _lib.current_stream_ptr()), "egx_gru_pointwise_bwd")
+        return dgi, dgh, dhp
+
+
+class PPOLossFn(torch.autograd.Function):
+    """loss, terms[6] = egx_ppo_loss(...); gradients w.r.t. mu, raw logvar and value are produced by the same kernel."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, value, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_lv, max_lv, eps_clip, vf_coef,
+                ent_coef):
+        lib = _lib.load()
+        mu, logvar, value = mu.contiguous(), logvar.contiguous(), value.contiguous().reshape(-1)
+        n = mu.shape[0]
+        g_mu, g_lv, g_v = torch.empty_like(mu), torch.empty_like(logvar), torch.empty_like(value)
+        terms = torch.empty(6, dtype=torch.float32, device=mu.device)
+        rc = lib.egx_ppo_loss(_lib.ptr(mu), _lib.ptr(logvar), _lib.ptr(value), _lib.ptr(act.contiguous()), _lib.ptr(adv.contiguous()),
+                              _lib.ptr(ret.contiguous()), _lib.ptr(logp_old.contiguous()),
+                              _lib.ptr(adv_stats) if adv_stats is not None else None, _lib.ptr(scale), float(adv_eps),
+                              float(min_lv), float(max_lv), float(eps_clip), float(vf_coef), float(ent_coef), n,
+                              _lib.ptr(g_mu), _lib.ptr(g_lv), _lib.ptr(g_v), _lib.ptr(terms), _lib.current_stream_ptr())
+        _lib.check(rc, "egx_ppo_loss")
+        ctx.save_for_backward(g_mu, g_lv, g_v)
+        ctx.value_shape = value.shape
+        ctx.mark_non_differentiable(terms)
+        return terms[0].clone(), terms
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_terms):
+        g_mu, g_lv, g_v = ctx.saved_tensors
+        return (grad_loss * g_mu, grad_loss * g_lv, (grad_loss * g_v).reshape(ctx.value_shape)) + (None,) * 12
+
+
+def posenc_dist_time(dist: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
+    """[n] , [n] -> [n,128] = [posenc(dist) | posenc(time)] (no gradient: both are observations)."""
+    lib = _lib.load()
+    n = dist.shape[0]
+    out = torch.empty(n, 128, dtype=torch.float32, device=dist.device)
+    _lib.check(lib.egx_posenc(_lib.ptr(dist.contiguous()), _lib.ptr(time.contiguous()), n, _lib.ptr(out), _lib.current_stream_ptr()),
+               "egx_posenc")
+    return out

@@ -24,6 +24,8 @@ from torch import nn
 
 from . import _lib
 
+FUSED_UPDATE_OPS = True  # HIP-backed autograd nodes for GRU gates / posenc on the GPU (tests flip it to compare)
+
 _ACT = {"tanh": torch.tanh, "relu": torch.relu, "lrelu": lambda x: F.leaky_relu(x, 0.01)}
 
 
@@ -223,9 +225,14 @@ class GAMMAPolicyBase(nn.Module):
         that the autograd path does not depend on the vendor RNN kernel; returns the last hidden state."""
         H = gru.hidden_size
         h = x_seq.new_zeros(x_seq.shape[1], H)
+        fused = x_seq.is_cuda and FUSED_UPDATE_OPS
         for t in range(x_seq.shape[0]):
             gi = F.linear(x_seq[t], gru.weight_ih_l0, gru.bias_ih_l0)
             gh = F.linear(h, gru.weight_hh_l0, gru.bias_hh_l0)
+            if fused:  # one HIP kernel forward, one backward, instead of ~15 + ~30 elementwise torch kernels
+                from .fused_ops import GRUPointwiseFn
+                h = GRUPointwiseFn.apply(gi, gh, h)
+                continue
             r = torch.sigmoid(gi[:, :H] + gh[:, :H])
             z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
             n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
@@ -237,6 +244,10 @@ class GAMMAPolicyBase(nn.Module):
         nb = obs["state"].shape[0]
         hx = self._gru_last(self.x_enc, obs["state"].permute(1, 0, 2))
         he = self._gru_last(self.ego_enc, obs["egosensing"].permute(1, 0, 2))
+        if obs["dist"].is_cuda and FUSED_UPDATE_OPS:
+            from .fused_ops import posenc_dist_time
+            pe = posenc_dist_time(obs["dist"].reshape(nb).float(), obs["time"].reshape(nb).float())
+            return torch.cat([hx, he, pe], dim=-1)
         d = positional_encoding(obs["dist"].reshape(nb, 1))
         t = positional_encoding(obs["time"].reshape(nb, 1))
         return torch.cat([hx, he, d, t], dim=-1)

@@ -84,6 +84,7 @@ class GAMMAPPOPolicy(nn.Module):
         self._flat_grad: Optional[torch.Tensor] = None
         self._graph_cache: dict = {}
         self.use_update_graph = bool(_ignored.get("use_update_graph", False))
+        self.use_fused_loss = bool(_ignored.get("use_fused_loss", True))
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     # ---- rollout side (HIP) -------------------------------------------------------------------------
@@ -158,8 +159,10 @@ class GAMMAPPOPolicy(nn.Module):
     def minibatch_loss(self, obs, act, adv, returns, logp_old, global_stats=None):
         """ppo_policy.py:189-241 for one minibatch.  With data parallelism `global_stats` = (mean, std, n_global):
         the advantage statistics and the loss normaliser of the GLOBAL minibatch."""
-        hx, mu, sigma = self._dist_params(obs)
         n_local = adv.shape[0]
+        if adv.is_cuda and self.use_fused_loss:
+            return self._minibatch_loss_fused(obs, act, adv, returns, logp_old, global_stats)
+        hx, mu, sigma = self._dist_params(obs)
         if self._norm_adv:
             if global_stats is None:
                 mean, std = adv.mean(), adv.std()
@@ -259,6 +262,30 @@ class GAMMAPPOPolicy(nn.Module):
             st["failed"] = True
         self._graph_cache[key] = st
         return st
+
+    def _minibatch_loss_fused(self, obs, act, adv, returns, logp_old, global_stats):
+        """Same function as the torch expression above, with the loss and its gradients w.r.t. (mu, logvar, value)
+        computed by one HIP kernel (egx_ppo_loss)."""
+        from .fused_ops import PPOLossFn
+        hx = self.shared_net(obs)
+        (mu, logvar), _ = self.actor(hx)
+        value = self.critic(hx).flatten()
+        n_local = adv.shape[0]
+        dev = adv.device
+        stats = None
+        if self._norm_adv:
+            if global_stats is None:
+                stats = torch.stack([adv.mean(), adv.std()])
+            else:
+                stats = torch.stack([global_stats[0], global_stats[1]]).float()
+        if global_stats is None:
+            scale = torch.full((1,), 1.0 / n_local, dtype=torch.float32, device=dev)
+        else:
+            scale = (1.0 / global_stats[2]).reshape(1).float()
+        loss, terms = PPOLossFn.apply(mu, logvar, value, act, adv, returns, logp_old, stats, scale, _EPS, self.actor.min_logvar,
+                                      self.actor.max_logvar, self._eps_clip, self._weight_vf, self._weight_ent)
+        return loss, {"loss": terms[0], "loss/clip": terms[1], "loss/vf": terms[2], "loss/ent": terms[3], "loss/kld": terms[4],
+                      "approx_kl": terms[5]}
 
     def learn(self, batch: RolloutBatch, batch_size: int, repeat: int) -> Dict[str, List[float]]:
         """ppo_policy.py:182-265.  `batch_size` is the GLOBAL minibatch size; each rank contributes batch_size/world."""

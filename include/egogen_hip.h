@@ -326,6 +326,24 @@ int egx_event_create(void** out_event);
 int egx_event_destroy(void* event);
 int egx_event_elapsed_ms(void* start_event, void* stop_event, float* out_ms); /* synchronises on stop_event */
 
+/* ---------------------------------------------------------------------------------------------
+ * PPO update: fused loss + gradient of one minibatch (crowd_ppo/ppo_policy.py:189-241) and the backward of the
+ * GRU gate math.  Used as custom autograd nodes by the host; dense-layer backward stays on rocBLAS this round.
+ *   loss = scale * sum_rows [ -min(r A, clamp(r,1-e,1+e) A) + vf_coef (ret - V)^2 - ent_coef H ],  r = exp(logp - logp_old),
+ *   A = (adv - adv_stats[0]) / (adv_stats[1] + adv_eps) when adv_stats != NULL (per-minibatch normalisation, :192-195)
+ *   logvar is the RAW actor output; the clamp to [min,max] (ppo_policy.py:169) and its gradient mask are applied inside.
+ *   out_terms[6] = loss, loss/clip, loss/vf, loss/ent, loss/kld, mean(logp_old - logp)   (each x scale)
+ * ------------------------------------------------------------------------------------------- */
+int egx_ppo_loss(const float* mu, const float* logvar, const float* value, const float* act, const float* adv,
+                 const float* ret, const float* logp_old, const float* adv_stats, const float* scale, float adv_eps,
+                 float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef, int num_rows,
+                 float* g_mu, float* g_logvar, float* g_value, float* out_terms, void* stream);
+
+/* Backward of egx_gru_pointwise: (gi, gh, h_prev, dh) -> d gi, d gh [M,3H], d h_prev [M,H] (NULL to skip).
+ * Tensors are dense (row strides H / 3H). */
+int egx_gru_pointwise_bwd(const float* gi, const float* gh, const float* h_prev, const float* dh, int num_rows, int hidden,
+                          float* dgi, float* dgh, float* dh_prev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

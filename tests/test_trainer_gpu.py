@@ -160,3 +160,51 @@ def test_graph_replayed_update_equals_eager():
     # second call replays the cached graph
     le2, lg2 = pe.learn(b, 16, 1), pg.learn(b, 16, 1)
     np.testing.assert_allclose(le2["loss"], lg2["loss"], rtol=5e-3, atol=1e-4)
+
+
+def test_fused_update_ops_match_torch_autograd():
+    """egx_ppo_loss / egx_gru_pointwise(_bwd) / egx_posenc as autograd nodes give the same loss and parameter gradients as the
+    plain torch expression of ppo_policy.py:189-241 (which tests/test_ppo_cpu.py pins to the oracle restatement)."""
+    from egogen_amd import models, setup_world as sw
+    from egogen_amd.ppo_policy import RolloutBatch
+    pol = sw.build_policy(_Args())
+    g = torch.Generator().manual_seed(0)
+    N = 48
+    b = RolloutBatch(1, N, "cuda")
+    b.state.copy_(torch.randn(b.state.shape, generator=g) * 0.3)
+    b.ego.copy_(torch.rand(b.ego.shape, generator=g) * 2 - 1)
+    b.dist.copy_(torch.rand(b.dist.shape, generator=g)); b.time.copy_(torch.rand(b.time.shape, generator=g))
+    b.act.copy_(torch.randn(b.act.shape, generator=g) * 2.5)   # some ratios leave the clip range
+    b.adv.copy_(torch.randn(b.adv.shape, generator=g)); b.returns.copy_(torch.randn(b.returns.shape, generator=g))
+    # push some raw logvars outside [-2.5, 2.5] so the clamp mask is exercised
+    with torch.no_grad():
+        pol.actor.pnet.out_fc.bias[128:160] += 4.0
+        pol.actor.pnet.out_fc.bias[160:192] -= 4.0
+        _, mu, sigma = pol._dist_params(b.obs_flat())
+        b.logp_old.copy_((pol.log_prob(mu, sigma, b.act.reshape(-1, 128)) + 0.2 * torch.randn(N, generator=g).cuda()).reshape(1, N))
+    args = (b.obs_flat(), b.act.reshape(N, 128), b.adv.reshape(N), b.returns.reshape(N), b.logp_old.reshape(N))
+
+    def grads(fused):
+        models.FUSED_UPDATE_OPS = fused
+        pol.use_fused_loss = fused
+        pol.zero_grad(set_to_none=True)
+        loss, terms = pol.minibatch_loss(*args)
+        loss.backward()
+        return float(loss), {k: float(v) for k, v in terms.items()}, torch.cat([p.grad.flatten() for p in pol.parameters()])
+
+    try:
+        l0, t0, g0 = grads(False)
+        l1, t1, g1 = grads(True)
+    finally:
+        models.FUSED_UPDATE_OPS = True
+    assert abs(l0 - l1) <= 2e-5 * max(1.0, abs(l0))
+    for k in ("loss/clip", "loss/vf", "loss/ent", "loss/kld", "approx_kl"):
+        assert abs(t0[k] - t1[k]) <= 5e-5 * max(1.0, abs(t0[k])), k
+    assert float((g0 - g1).abs().max()) <= 2e-4 * float(g0.abs().max())
+    # with externally supplied (global) advantage statistics, as in the data-parallel path
+    gs = (torch.tensor(0.1, device="cuda"), torch.tensor(1.3, device="cuda"), torch.tensor(96.0, device="cuda"))
+    models.FUSED_UPDATE_OPS = False; pol.use_fused_loss = False
+    la, _ = pol.minibatch_loss(*args, gs)
+    models.FUSED_UPDATE_OPS = True; pol.use_fused_loss = True
+    lb, _ = pol.minibatch_loss(*args, gs)
+    assert abs(float(la) - float(lb)) <= 2e-5 * max(1.0, abs(float(la)))
