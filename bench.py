@@ -18,7 +18,7 @@ advantage-moment all-reduce (3 doubles) and one flat 52.7 MB gradient all-reduce
 
 Extra objects on the JSON line:
   roofline      dominant kernel = egx_lbs_fused_kernel (fp32-MFMA blend GEMM + skinning + SDF epilogue);
-                achieved = 2*496*31425 FLOP/body * bodies per launch / average launch duration measured with HIP events
+                achieved = 2*469*31425 FLOP/body * bodies per launch / average launch duration measured with HIP events
                 recorded around that kernel inside the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md)
   cpu_baseline  the CPU oracle (port of the reference's per-agent, x4-replicated structure) timed on the host cores
                 on a bounded sample (rank 0, N = 1 only)
@@ -37,7 +37,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_BODY = 2.0 * 496 * 31425          # blend GEMM only (K = 10 betas + 486 pose features)
+FLOP_PER_BODY = 2.0 * 469 * 31425          # blend GEMM only: K = 10 betas + 9 x 51 movable joints (jaw/eye columns are exactly 0)
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 
@@ -168,10 +168,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # test knobs (never set by the driver): run several ranks on ONE device over gloo to exercise the multi-rank code path
+    backend = os.environ.get("EGX_DIST_BACKEND", "nccl")
+    if os.environ.get("EGX_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from egogen_amd import _lib, setup_world as sw, synth
     from egogen_amd.body_model import BodyModelHandle
@@ -245,7 +252,7 @@ def main():
 
     transitions = args.steps * n_vec * A * world
     result = {
-        "metric": "PPO env-steps/sec (512 parallel SMPL-X agents per GPU)",
+        "metric": f"PPO env-steps/sec ({A} parallel SMPL-X agents per GPU)",
         "value": transitions / elapsed,
         "unit": "env-steps/s",
         "n_gpus": world,

@@ -75,7 +75,9 @@ class EnvConfig(C.Structure):
 
 class EnvScenes(C.Structure):
     _fields_ = [("edges", C.c_void_p), ("edge_off", C.c_void_p), ("tris", C.c_void_p), ("tri_off", C.c_void_p),
-                ("floor_height", C.c_void_p), ("map_lin", C.c_void_p), ("map_res", C.c_int)]
+                ("floor_height", C.c_void_p), ("map_lin", C.c_void_p), ("map_res", C.c_int),
+                ("crowd_bbox", C.c_void_p), ("crowd_group", C.c_int), ("crowd_scenes", C.c_int), ("crowd_member", C.c_int),
+                ("crowd_floor_half", C.c_float)]
 
 
 class EnvState(C.Structure):

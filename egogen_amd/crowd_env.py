@@ -48,7 +48,8 @@ class VecCrowdEnv:
                  pairs: Optional[np.ndarray] = None, box_scenes: Optional[List[dict]] = None,
                  motion_seed: Optional[dict] = None, cfg: Optional[dict] = None, finetuning: bool = False,
                  seed: int = 0, num_candidates: Optional[int] = None, use_graph: bool = False,
-                 keep_rollout: bool = False, device: str = "cuda"):
+                 keep_rollout: bool = False, device: str = "cuda", crowd_bbox: Optional[torch.Tensor] = None,
+                 crowd_member: int = 0, crowd_pairs=None, crowd_floor_half: float = 4.0):
         if not torch.cuda.is_available():
             raise _lib.EgxError("VecCrowdEnv needs a HIP device (no CPU fallback)")
         self.lib = _lib.load()
@@ -57,6 +58,7 @@ class VecCrowdEnv:
         self.bm, self.prior, self.vposer = body_model, prior, vposer
         self.scene_kind = scene_kind
         self.cfg = dict(cfg or (BOX_CFG if scene_kind == "box" else DEFAULT_CFG))
+        self.crowd_bbox, self.crowd_member = crowd_bbox, int(crowd_member)
         self.finetuning = finetuning
         self.use_graph = use_graph
         self.keep_rollout = keep_rollout
@@ -90,10 +92,12 @@ class VecCrowdEnv:
 
         # ---- motion seed (data/locomotion/subseq_00343.npz in the reference) ----
         ms = motion_seed or {k: synth.load_assets()[f"seed_{k}"] for k in ("poses", "trans", "betas")}
-        self.motion_seed = {k: np.asarray(v, np.float64) for k, v in ms.items()}
+        self.motion_seed = {k: np.asarray(v, np.float64) for k, v in ms.items() if k in ("poses", "trans", "betas")}
         self.betas = torch.tensor(self.motion_seed["betas"], **f32).reshape(1, 10).repeat(A, 1).contiguous()
         if scene_kind == "sdf":
             starts = [5]                                           # environments.py:193 fixed start frame
+        elif scene_kind == "crowd" and motion_seed is not None and motion_seed.get("fixed_start") is not None:
+            starts = [int(motion_seed["fixed_start"])]
         else:
             starts = list(range(len(self.motion_seed["poses"]) - 1))  # environments.py:483 random start frame
         self.variant_starts = starts
@@ -119,6 +123,14 @@ class VecCrowdEnv:
             P = min(len(s["pairs"]) for s in box_scenes)
             self.box_pairs = torch.tensor(np.stack([np.asarray(s["pairs"][:P], np.float32) for s in box_scenes]), **f32)
             self.K = int(num_candidates or 8)
+        elif scene_kind == "crowd":
+            # main_crowd_eval.py: every scene holds G members; the walkable polygon of a member is the 8x8 m floor minus
+            # the marker boxes of the others (dummy_vector_env.py:34-39, crowd_env_crowd_eval.py:796-822)
+            if crowd_bbox is None or crowd_pairs is None or crowd_bbox.shape[1] != A or crowd_bbox.shape[2] != 4:
+                raise ValueError("crowd scene kind needs crowd_bbox[G,A,4] and crowd_pairs[A,2,3]")
+            edges, tris, floor = [np.zeros((1, 4), np.float32)], [np.zeros((0, 6), np.float32)], [0.0]
+            self.crowd_pairs = torch.tensor(np.asarray(crowd_pairs, np.float32), **f32).reshape(A, 1, 2, 3)
+            self.K = 1
         else:
             raise ValueError(f"unknown scene_kind {scene_kind!r}")
         self.num_scenes = len(edges)
@@ -148,17 +160,23 @@ class VecCrowdEnv:
         if scene_kind == "sdf":
             ec.weight_pene = 0.1 if finetuning else 1.0          # crowd_env_2f.py:268-271
             ec.terminate_on_penetration = 1 if finetuning else 0  # :299-302
+        elif scene_kind == "crowd":
+            ec.weight_pene = c["weight_pene"]
+            ec.terminate_on_penetration = 0                      # crowd_env_crowd_eval.py:367
         else:
             ec.weight_pene = c["weight_pene"]                    # crowd_env_2f_box.py:303
             ec.terminate_on_penetration = 1                      # :325
         ec.max_depth = int(c["max_depth"])
-        ec.scene_kind = 0 if scene_kind == "sdf" else 1
+        ec.scene_kind = {"sdf": 0, "box": 1, "crowd": 2}[scene_kind]
         ec.pene_type_body = 1 if c["pene_type"] == "body" else 0
         ec.ray_len = float(c["ray_len"])
         self._ec = ec
         sc = _lib.EnvScenes()
         sc.edges, sc.edge_off, sc.tris, sc.tri_off = self.edges.data_ptr(), self.edge_off.data_ptr(), self.tris.data_ptr(), self.tri_off.data_ptr()
         sc.floor_height, sc.map_lin, sc.map_res = self.floor_h.data_ptr(), self.map_lin.data_ptr(), int(c["map_res"])
+        if scene_kind == "crowd":
+            sc.crowd_bbox, sc.crowd_group, sc.crowd_scenes = crowd_bbox.data_ptr(), int(crowd_bbox.shape[0]), A
+            sc.crowd_member, sc.crowd_floor_half = self.crowd_member, float(crowd_floor_half)
         self._sc = sc
         self._st = self._make_state_struct(self.state, self.seed, self.R0, self.T0, self.dist, self.steps, self.wpath, self.scene_idx)
         io = _lib.EnvStepIO()
@@ -268,6 +286,11 @@ class VecCrowdEnv:
         if self.scene_kind == "sdf":
             idx = torch.randint(0, self.valid_pairs.shape[0], (A * K,), generator=g, device=self.dev)
             self.cand_pairs.copy_(self.valid_pairs[idx].reshape(A, K, 2, 3))
+        elif self.scene_kind == "crowd":
+            self.cand_pairs.copy_(self.crowd_pairs)
+            self.cand_variant.copy_(torch.randint(0, len(self.variant_starts), (A, K), generator=g, device=self.dev).to(torch.int32))
+            u = torch.rand(A, K, generator=g, device=self.dev) * 2 - 1
+            self.cand_yaw.copy_(u * (2 * np.pi * 0.2))           # environments.py:1100-1101 (CrowdMotion.gen_init_body)
         else:
             sc = torch.randint(0, self.num_scenes, (A * K,), generator=g, device=self.dev)
             pi = torch.randint(0, self.box_pairs.shape[1], (A * K,), generator=g, device=self.dev)
@@ -289,9 +312,9 @@ class VecCrowdEnv:
         self._injected = True
 
     def _launch_reset(self, mask):
-        box = self.scene_kind == "box"
+        box = self.scene_kind in ("box", "crowd")
         io = self._reset_io(self.A, self.K, mask, self.cand_pairs, self.cand_yaw if box else None,
-                            self.cand_variant if box else None, self.cand_scene if box else None, None,
+                            self.cand_variant if box else None, self.cand_scene if self.scene_kind == "box" else None, None,
                             self.obs_ego, self.obs_dist, self.obs_time, self.choice)
         _lib.check(self.lib.egx_env_reset(C.byref(self._ec), C.byref(self._sc), C.byref(self._st), C.byref(io), self.A,
                                           _lib.current_stream_ptr()), "egx_env_reset")
@@ -378,3 +401,48 @@ class CrowdEnv:
         a = torch.as_tensor(action_z, dtype=torch.float32, device=self.vec.dev).reshape(1, 128)
         _, rew, term = self.vec.step(a, auto_reset=False)
         return self._obs0(), float(rew[0].item()), bool(term[0].item()), False, {}
+
+
+class CrowdGroupEnv:
+    """G interacting members per scene, S independent scenes (the reference's main_crowd_eval.py runs S = 1, G = 4 with
+    `DummyCrowdVectorEnv`).  Member k of every scene lives in sub-environment k; all share one table of world-space
+    marker boxes.  `step` walks the members in order, so member k sees the boxes members 0..k-1 published in THIS round
+    and those of k+1.. from the previous round - the ordering of dummy_vector_env.py:81-84."""
+
+    def __init__(self, num_scenes: int, start_target, body_model, prior, vposer, cfg=None, seed=0, keep_rollout=False,
+                 motion_seed=None, floor_half: float = 4.0, device="cuda"):
+        st = np.asarray(start_target, np.float32)          # [G,S,2,3]
+        self.G, self.S = int(st.shape[0]), int(num_scenes)
+        assert st.shape[1] == self.S
+        self.bbox = torch.zeros(self.G, self.S, 4, dtype=torch.float32, device=device)
+        self.members = [VecCrowdEnv(self.S, body_model, prior, vposer, scene_kind="crowd", cfg=cfg, seed=seed + 17 * k,
+                                    keep_rollout=keep_rollout, motion_seed=motion_seed, crowd_bbox=self.bbox, crowd_member=k,
+                                    crowd_pairs=st[k], crowd_floor_half=floor_half, device=device) for k in range(self.G)]
+
+    def reset(self):
+        """Every member publishes its initial box (constructor of crowd_env_crowd_eval.CrowdEnv, :54-75) before anyone
+        builds its first observation (DummyCrowdVectorEnv.__init__ -> update_holes_for_each_agent)."""
+        for m in self.members:
+            m.sample_candidates()
+            m._injected = True
+            m._launch_reset(None)
+        obs = []
+        for m in self.members:
+            m._launch_reset(None)        # same candidates: identical state, observation now sees all boxes
+            m._injected = False
+            obs.append(m.obs())
+        return obs
+
+    def step(self, actions, reset_done: bool = True):
+        """actions: list of G tensors [S,128].  Returns per-member (obs, reward, terminated)."""
+        out = []
+        for k, m in enumerate(self.members):
+            o, r, t = m.step(actions[k], auto_reset=False)
+            r, t = r.clone(), t.clone()
+            if reset_done:                # a finished member restarts from its own fixed start (collector reset)
+                m.sample_candidates()
+                m._injected = True
+                m._launch_reset(m.terminated)
+                m._injected = False
+            out.append((m.obs(), r, t))
+        return out

@@ -55,9 +55,13 @@ extern "C" int egx_profile_next_lbs(void* start_event, void* stop_event) {
 namespace {
 
 constexpr int NJ = EGX_NUM_JOINTS;
-constexpr int KDIM = EGX_BLEND_K;      // 496
-constexpr int KSTEPS = KDIM / 2;       // 248 MFMA k-steps (32x32x2)
-constexpr int KGROUPS = KSTEPS / 4;    // 62 float4 groups
+// GEMM K axis: 10 betas + 9 rotation features of the 51 joints that can move through this API (global orient is not a
+// blend feature; jaw and both eyes have no field in xb[93], their R - I is exactly 0 and their 27 columns are dropped)
+constexpr int KACT = 10 + 51 * 9;      // 469 live columns
+constexpr int KDIM = EGX_BLEND_K;      // 472 = 469 padded to a multiple of 8
+constexpr int KSTEPS = KDIM / 2;       // 236 MFMA k-steps (32x32x2)
+constexpr int KGROUPS = KSTEPS / 4;    // 59 float4 groups
+__host__ __device__ inline int egx_compact_joint(int j) { return (j - 1) - (j > 24 ? 3 : 0); }  // j in 1..54, j != 22..24
 constexpr int NLMK = 51, NEXTRA = 21;
 constexpr int BODY_PAD = 256;          // bodies per workgroup of the fused kernel
 constexpr int LBS_NW_MAX = 16;         // skinning weights per vertex held in LDS (ELL width, multiple of 4)
@@ -148,10 +152,11 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
     for (int e = 0; e < 9; ++e) sR[w][j][e] = R[e];
     if (live) {
       if (j < 10) feat_store(j, be[j]);
-      if (j >= 1) {
-        const int k0 = 10 + (j - 1) * 9;
+      if (j >= 1 && (j < 22 || j > 24)) {
+        const int k0 = 10 + egx_compact_joint(j) * 9;
         for (int e = 0; e < 9; ++e) feat_store(k0 + e, R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f));
       }
+      if (j >= 22 && j <= 24) feat_store(KACT + (j - 22), 0.f);  // zero padding columns 469..471
     }
   }
   __syncthreads();
@@ -210,6 +215,8 @@ struct LbsParams {
   const float* xb;     // transl = xb[b*93 + 0..2]
   int B, V, NVT, NW, NP, fpa;
   int nbg;             // body groups (256 bodies each)
+  int stagger_lo, stagger_hi;  // block-id range delayed at start (second residency slot of every CU)
+  long long stagger_cycles;
   float* verts;        // [B][V][3] or null
   float* picked;       // [B][NP][3] or null
   SdfDev sdf;
@@ -243,6 +250,14 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
   }
   const int bt0 = bg * 8 + wave * NB;  // first 32-body tile of this wave
   const int num_bt = (p.B + 31) >> 5;
+  // Phase stagger: two workgroups share each CU (2 waves per SIMD).  Launched together they run their MFMA loops at the
+  // same time (sharing the matrix pipe) and then their epilogues at the same time (matrix pipe idle).  Delaying the
+  // second-slot workgroups of the FIRST generation by about half a tile puts the pairs in anti-phase - one wave's
+  // epilogue under the other's MFMA loop - and the offset persists because successors start when a slot frees up.
+  if (p.stagger_cycles > 0 && blockIdx.x >= (unsigned)p.stagger_lo && blockIdx.x < (unsigned)p.stagger_hi) {
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < p.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+  }
   // per-vertex metadata of this tile (shared by the 4 waves): skinning weights, template, pick slot, flags
   __shared__ int s_widx[32][LBS_NW_MAX];
   __shared__ float s_wval[32][LBS_NW_MAX];
@@ -465,8 +480,13 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
           if (v < V)
             for (int e = 0; e < 4; ++e) {
               const int k = 2 * (4 * g + e) + (l >> 5);
-              val[e] = (k < 10) ? d->shapedirs_host[((size_t)v * 3 + c) * 10 + k]
-                                : d->posedirs_host[(size_t)(k - 10) * 3 * V + (size_t)v * 3 + c];
+              if (k < 10) {
+                val[e] = d->shapedirs_host[((size_t)v * 3 + c) * 10 + k];
+              } else if (k < KACT) {
+                const int jc = (k - 10) / 9, e9 = (k - 10) % 9;
+                const int j = jc + 1 + (jc >= 21 ? 3 : 0);        // inverse of egx_compact_joint
+                val[e] = d->posedirs_host[(size_t)((j - 1) * 9 + e9) * 3 * V + (size_t)v * 3 + c];
+              }
             }
           dirs[(((size_t)vt * KGROUPS + g) * 3 + c) * 64 + l] = val;
         }
@@ -622,6 +642,20 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     p.vflags = m->vflags; p.feat = reinterpret_cast<const f32x4*>(feat); p.A4 = A4; p.xb = xb;
     p.B = B; p.V = m->V; p.NVT = m->NVT; p.NW = m->NW; p.NP = m->NP; p.fpa = fpa;
     p.nbg = egx_ceil_div(B, BODY_PAD);
+    {
+      static int num_cu = 0;
+      static long long stagger = -1;
+      if (num_cu == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        EGX_HIP_CHECK(hipGetDevice(&dev));
+        EGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        num_cu = prop.multiProcessorCount;
+        const char* e = getenv("EGX_LBS_STAGGER_CYCLES");
+        stagger = e ? atoll(e) : 40000;  // ~ half of one tile's MFMA loop (in s_memtime / 100 MHz-or-core ticks: see DESIGN.md)
+      }
+      p.stagger_lo = num_cu; p.stagger_hi = 2 * num_cu; p.stagger_cycles = stagger;
+    }
     p.verts = out_verts; p.picked = picked; p.R0 = R0; p.T0 = T0; p.pene = out_pene_count;
     std::memset(&p.sdf, 0, sizeof(p.sdf));
     if (sdf) {

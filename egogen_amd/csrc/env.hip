@@ -78,7 +78,39 @@ struct SceneDev {
   const float* floor_h; // [S]
   const float* map_lin; // [res]
   int map_res;
+  // crowd scenes (main_crowd_eval): walkable = square floor minus the world-space marker boxes of the OTHER members
+  float* crowd_bbox;    // [G][S][4] (minx,miny,maxx,maxy) or null
+  int crowd_G, crowd_S, crowd_k;
+  float crowd_half;     // floor is [-half, half]^2 (crowd_env_crowd_eval.py:391)
 };
+
+// number of boundary edges of scene `sc_i` and the e-th edge (x0,y0,x1,y1) in float64
+__device__ __forceinline__ int scene_num_edges(const SceneDev& sc, int sc_i) {
+  if (sc.crowd_bbox) return 4 + 4 * (sc.crowd_G - 1);
+  return sc.edge_off[sc_i + 1] - sc.edge_off[sc_i];
+}
+__device__ __forceinline__ void scene_edge(const SceneDev& sc, int sc_i, int e, double& x0, double& y0, double& x1, double& y1) {
+  if (!sc.crowd_bbox) {
+    const float* p = sc.edges + (size_t)(sc.edge_off[sc_i] + e) * 4;
+    x0 = p[0]; y0 = p[1]; x1 = p[2]; y1 = p[3];
+    return;
+  }
+  float lo[2], hi[2];
+  int q;
+  if (e < 4) {
+    lo[0] = lo[1] = -sc.crowd_half; hi[0] = hi[1] = sc.crowd_half;
+    q = e;
+  } else {
+    int other = (e - 4) >> 2;
+    if (other >= sc.crowd_k) ++other;  // skip this member's own box
+    const float* b = sc.crowd_bbox + ((size_t)other * sc.crowd_S + sc_i) * 4;
+    lo[0] = b[0]; lo[1] = b[1]; hi[0] = b[2]; hi[1] = b[3];
+    q = (e - 4) & 3;
+  }
+  // rectangle corners c0=(lo,lo) c1=(hi,lo) c2=(hi,hi) c3=(lo,hi); edge q = c_q -> c_{q+1}
+  const double cx[4] = {lo[0], hi[0], hi[0], lo[0]}, cy[4] = {lo[1], lo[1], hi[1], hi[1]};
+  x0 = cx[q]; y0 = cy[q]; x1 = cx[(q + 1) & 3]; y1 = cy[(q + 1) & 3];
+}
 
 // even-odd containment + first exit along 32 rays, float64 like the reference's numpy/shapely path.
 // eye/look are computed in float32 first (joint.detach().cpu().numpy() is float32), then promoted.
@@ -91,11 +123,12 @@ __device__ void egosensing_frame(const SceneDev& sc, int scene, const float* j23
   la0 /= ln; la1 /= ln;
   const float exf = (j23[0] + j24[0]) / 2.f, eyf = (j23[1] + j24[1]) / 2.f;
   const double ox = (double)exf, oy = (double)eyf;
-  const int e0 = sc.edge_off[scene], e1 = sc.edge_off[scene + 1];
+  const int ne = scene_num_edges(sc, scene);
   // containment (every thread computes it redundantly; E is small)
   int crossings = 0;
-  for (int e = e0; e < e1; ++e) {
-    const double x0 = sc.edges[e * 4 + 0], y0 = sc.edges[e * 4 + 1], x1 = sc.edges[e * 4 + 2], y1 = sc.edges[e * 4 + 3];
+  for (int e = 0; e < ne; ++e) {
+    double x0, y0, x1, y1;
+    scene_edge(sc, scene, e, x0, y0, x1, y1);
     if ((y0 > oy) != (y1 > oy)) {
       const double xint = x0 + (oy - y0) * (x1 - x0) / (y1 - y0);
       if (ox < xint) ++crossings;
@@ -111,9 +144,10 @@ __device__ void egosensing_frame(const SceneDev& sc, int scene, const float* j23
       const double ca = cos(ang), sa = sin(ang);
       const double dx = la0 * ca - la1 * sa, dy = la1 * ca + la0 * sa;
       d = ray_len;
-      for (int e = e0; e < e1; ++e) {
-        const double ex0 = sc.edges[e * 4 + 0], ey0 = sc.edges[e * 4 + 1];
-        const double edx = (double)sc.edges[e * 4 + 2] - ex0, edy = (double)sc.edges[e * 4 + 3] - ey0;
+      for (int e = 0; e < ne; ++e) {
+        double ex0, ey0, ex1, ey1;
+        scene_edge(sc, scene, e, ex0, ey0, ex1, ey1);
+        const double edx = ex1 - ex0, edy = ey1 - ey0;
         const double den = dx * edy - dy * edx;
         if (fabs(den) > 0.0) {
           const double tt = ((ex0 - ox) * edy - (ey0 - oy) * edx) / den;
@@ -132,7 +166,7 @@ __device__ void egosensing_frame(const SceneDev& sc, int scene, const float* j23
 __device__ float walk_map_penalty(const SceneDev& sc, int scene, const float* R0, const float* T0, float bminx, float bminy,
                                   float bmaxx, float bmaxy, float* sh) {
   const int res = sc.map_res;
-  const int f0 = sc.tri_off[scene], f1 = sc.tri_off[scene + 1];
+  const int f0 = sc.crowd_bbox ? 0 : sc.tri_off[scene], f1 = sc.crowd_bbox ? 0 : sc.tri_off[scene + 1];
   float cnt = 0.f;
   for (int p = threadIdx.x; p < res * res; p += BLK) {
     const float lx = sc.map_lin[p / res], ly = sc.map_lin[p % res];
@@ -140,6 +174,14 @@ __device__ float walk_map_penalty(const SceneDev& sc, int scene, const float* R0
     const float px = (R0[0] * lx + R0[1] * ly + R0[2] * 0.f) + T0[0];
     const float py = (R0[3] * lx + R0[4] * ly + R0[5] * 0.f) + T0[1];
     bool walk = false;
+    if (sc.crowd_bbox) {  // crowd_env_crowd_eval.py:742-764: polygon(floor, holes).contains(point), z forced to 0
+      walk = (fabsf(px) < sc.crowd_half) && (fabsf(py) < sc.crowd_half);
+      for (int o = 0; o < sc.crowd_G && walk; ++o) {
+        if (o == sc.crowd_k) continue;
+        const float* b = sc.crowd_bbox + ((size_t)o * sc.crowd_S + scene) * 4;
+        if (px >= b[0] && px <= b[2] && py >= b[1] && py <= b[3]) walk = false;
+      }
+    }
     for (int f = f0; f < f1 && !walk; ++f) {
       const float* t = sc.tris + (size_t)f * 6;
       const float d1 = (px - t[2]) * (t[1] - t[3]) - (t[0] - t[2]) * (py - t[3]);
@@ -383,16 +425,17 @@ __global__ __launch_bounds__(BLK) void egx_env_step_post_kernel(StepArgs p) {
     p.seed[((size_t)a * 2 + t) * XB + d] = (d < 6) ? s_newseed[t][d] : PP[(18 + t) * XB + d];
   }
   // ---- 7. box env: walkability map penalty -------------------------------------------------------------------
-  if (c.scene_kind == 1) {
+  if (c.scene_kind >= 1) {
     bminx = block_reduce(bminx, s_red, 1); bminy = block_reduce(bminy, s_red, 1);
     bmaxx = block_reduce(bmaxx, s_red, 2); bmaxy = block_reduce(bmaxy, s_red, 2);
-    const float num_pene = walk_map_penalty(p.sc, p.scene_idx[a], R0n, T0n, bminx, bminy, bmaxx, bmaxy, s_red);
+    const int sc_i = p.sc.crowd_bbox ? a : p.scene_idx[a];
+    const float num_pene = walk_map_penalty(p.sc, sc_i, R0n, T0n, bminx, bminy, bmaxx, bmaxy, s_red);
     penetration = num_pene > c.pene_thres;
     r_pene = penetration ? 0.f : 0.05f;
   }
   // ---- 8. egosensing from the world-frame eye joints of frames 18,19 -------------------------------------------
   {
-    const int scene = p.scene_idx ? p.scene_idx[a] : 0;
+    const int scene = p.sc.crowd_bbox ? a : (p.scene_idx ? p.scene_idx[a] : 0);
     for (int t = 0; t < THIS; ++t) {
       const float* jt = J + (size_t)(18 + t) * NJO * 3;
       float w23[3], w24[3], w56[3], w57[3];
@@ -403,6 +446,23 @@ __global__ __launch_bounds__(BLK) void egx_env_step_post_kernel(StepArgs p) {
         outs[q][0] += T0o[0]; outs[q][1] += T0o[1]; outs[q][2] += T0o[2];
       }
       egosensing_frame(p.sc, scene, w23, w24, w56, w57, (double)c.ray_len, p.obs_ego + ((size_t)a * 2 + t) * NRAY, tid, BLK);
+    }
+  }
+  // ---- 8b. crowd scenes: publish this member's world-space marker box for the others ----------------------------
+  if (p.sc.crowd_bbox) {
+    __syncthreads();  // all rays of this agent are cast before its own box changes
+    float wminx = 3.4e38f, wminy = 3.4e38f, wmaxx = -3.4e38f, wmaxy = -3.4e38f;
+    for (int i = tid; i < THIS * NM; i += BLK) {
+      const float* st = p.state + ((size_t)a * 2 + i / NM) * SD + (i % NM) * 3;
+      const float wx = (R0n[0] * st[0] + R0n[1] * st[1] + R0n[2] * st[2]) + T0n[0];
+      const float wy = (R0n[3] * st[0] + R0n[4] * st[1] + R0n[5] * st[2]) + T0n[1];
+      wminx = fminf(wminx, wx); wminy = fminf(wminy, wy); wmaxx = fmaxf(wmaxx, wx); wmaxy = fmaxf(wmaxy, wy);
+    }
+    wminx = block_reduce(wminx, s_red, 1); wminy = block_reduce(wminy, s_red, 1);
+    wmaxx = block_reduce(wmaxx, s_red, 2); wmaxy = block_reduce(wmaxy, s_red, 2);
+    if (tid == 0) {
+      float* b = p.sc.crowd_bbox + ((size_t)p.sc.crowd_k * p.sc.crowd_S + a) * 4;
+      b[0] = wminx; b[1] = wminy; b[2] = wmaxx; b[3] = wmaxy;
     }
   }
   // ---- 9. reward, termination, scalars ------------------------------------------------------------------------
@@ -468,7 +528,7 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
   if (p.mask && p.mask[a] == 0) return;
   const EnvCfg& c = p.cfg;
   for (int k = 0; k < p.K; ++k) {
-    const int scene = p.cand_scene ? p.cand_scene[(size_t)a * p.K + k] : (p.scene_idx ? p.scene_idx[a] : 0);
+    const int scene = p.sc.crowd_bbox ? a : (p.cand_scene ? p.cand_scene[(size_t)a * p.K + k] : (p.scene_idx ? p.scene_idx[a] : 0));
     const int v = p.cand_variant ? p.cand_variant[(size_t)a * p.K + k] : 0;
     const float* TJ = p.tab_joints + (size_t)v * 2 * NJO * 3;
     const float* TM = p.tab_markers + (size_t)v * 2 * NM * 3;
@@ -590,6 +650,8 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
       bminx = block_reduce(bminx, s_red, 1); bminy = block_reduce(bminy, s_red, 1);
       bmaxx = block_reduce(bmaxx, s_red, 2); bmaxy = block_reduce(bmaxy, s_red, 2);
       accept = walk_map_penalty(p.sc, scene, R0n, T0n, bminx, bminy, bmaxx, bmaxy, s_red) == 0.f;
+    } else if (c.scene_kind == 2) {
+      accept = true;  // fixed start/target, no rejection loop (crowd_env_crowd_eval.py:388-435)
     } else if (p.cand_valid) {
       accept = p.cand_valid[(size_t)a * p.K + k] != 0;
     }
@@ -636,6 +698,23 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
       }
       egosensing_frame(p.sc, scene, w[0], w[1], w[2], w[3], (double)c.ray_len, p.obs_ego + ((size_t)a * 2 + t) * NRAY, tid, BLK);
     }
+    if (p.sc.crowd_bbox) {  // world box of the two seed frames' markers (crowd_env_crowd_eval.py:59-75)
+      __syncthreads();
+      float wminx = 3.4e38f, wminy = 3.4e38f, wmaxx = -3.4e38f, wmaxy = -3.4e38f;
+      for (int i = tid; i < 2 * NM; i += BLK) {
+        float ms[3];
+        to_canonical(i / NM, TM + (size_t)i * 3, ms);
+        const float wx = (R0n[0] * ms[0] + R0n[1] * ms[1] + R0n[2] * ms[2]) + T0n[0];
+        const float wy = (R0n[3] * ms[0] + R0n[4] * ms[1] + R0n[5] * ms[2]) + T0n[1];
+        wminx = fminf(wminx, wx); wminy = fminf(wminy, wy); wmaxx = fmaxf(wmaxx, wx); wmaxy = fmaxf(wmaxy, wy);
+      }
+      wminx = block_reduce(wminx, s_red, 1); wminy = block_reduce(wminy, s_red, 1);
+      wmaxx = block_reduce(wmaxx, s_red, 2); wmaxy = block_reduce(wmaxy, s_red, 2);
+      if (tid == 0) {
+        float* b = p.sc.crowd_bbox + ((size_t)p.sc.crowd_k * p.sc.crowd_S + a) * 4;
+        b[0] = wminx; b[1] = wminy; b[2] = wmaxx; b[3] = wmaxy;
+      }
+    }
     if (tid == 0) {
       float pel[3];
       to_canonical(0, TJ, pel);
@@ -672,6 +751,8 @@ static SceneDev to_scene(const egx_env_scenes* s) {
   SceneDev o;
   o.edges = s->edges; o.edge_off = s->edge_off; o.tris = s->tris; o.tri_off = s->tri_off; o.floor_h = s->floor_height;
   o.map_lin = s->map_lin; o.map_res = s->map_res;
+  o.crowd_bbox = s->crowd_bbox; o.crowd_G = s->crowd_group; o.crowd_S = s->crowd_scenes; o.crowd_k = s->crowd_member;
+  o.crowd_half = s->crowd_floor_half;
   return o;
 }
 
@@ -689,8 +770,12 @@ extern "C" int egx_env_step_post(const egx_env_config* cfg, const egx_env_scenes
   EGX_REQUIRE(st->state && st->seed && st->R0 && st->T0 && st->dist && st->steps && st->wpath, "null state array");
   EGX_REQUIRE(io->Y_gen && io->pred_params && io->joints && io->markers_proj && io->vp_emb && io->feet_marker_idx &&
                   io->reward && io->terminated && io->obs_ego && io->obs_dist && io->obs_time, "null io array");
-  EGX_REQUIRE(scenes->edges && scenes->edge_off, "scene edges missing");
-  EGX_REQUIRE(cfg->scene_kind == 0 ? (io->pene_count != nullptr) : (scenes->tris && scenes->tri_off && scenes->map_lin && st->scene_idx),
+  EGX_REQUIRE(cfg->scene_kind == 2 ? (scenes->crowd_bbox && scenes->crowd_group >= 2 && scenes->crowd_scenes == A &&
+                                      scenes->crowd_member >= 0 && scenes->crowd_member < scenes->crowd_group && scenes->map_lin)
+                                   : (scenes->edges && scenes->edge_off),
+              "scene tables missing");
+  EGX_REQUIRE(cfg->scene_kind == 0 ? (io->pene_count != nullptr)
+                                   : (cfg->scene_kind == 2 || (scenes->tris && scenes->tri_off && scenes->map_lin && st->scene_idx)),
               "scene-kind specific inputs missing");
   StepArgs p;
   p.cfg = to_cfg(cfg); p.sc = to_scene(scenes); p.A = A;
@@ -710,7 +795,8 @@ extern "C" int egx_env_reset(const egx_env_config* cfg, const egx_env_scenes* sc
   EGX_REQUIRE(cfg && scenes && st && io && A > 0, "bad arguments");
   EGX_REQUIRE(io->num_candidates >= 1 && io->cand_pairs && io->tab_joints && io->tab_markers && io->tab_glorot &&
                   io->tab_transl && io->tab_pose && io->obs_ego && io->obs_dist && io->obs_time, "null reset io array");
-  EGX_REQUIRE(scenes->edges && scenes->edge_off, "scene edges missing");
+  EGX_REQUIRE(cfg->scene_kind == 2 ? (scenes->crowd_bbox != nullptr && scenes->crowd_scenes == A) : (scenes->edges && scenes->edge_off),
+              "scene tables missing");
   ResetArgs p;
   p.cfg = to_cfg(cfg); p.sc = to_scene(scenes); p.A = A; p.K = io->num_candidates; p.mask = io->mask;
   p.cand_pairs = io->cand_pairs; p.cand_yaw = io->cand_yaw; p.cand_variant = io->cand_variant; p.cand_scene = io->cand_scene; p.cand_valid = io->cand_valid;

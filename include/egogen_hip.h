@@ -34,7 +34,7 @@ extern "C" {
 #define EGX_XB_DIM 93          /* transl3 glorot3 body63 lhand12 rhand12 */
 #define EGX_NUM_BETAS 10
 #define EGX_POSE_FEAT 486
-#define EGX_BLEND_K 496        /* 10 betas + 486 pose features = GEMM K  */
+#define EGX_BLEND_K 472        /* GEMM K: 10 betas + 9 x 51 movable joints = 469, padded to 8 (jaw/eyes are always identity here) */
 
 const char* egx_last_error(void);
 int egx_version(void);
@@ -232,7 +232,8 @@ typedef struct egx_env_config {   /* cfg_samp20/MPVAEPolicy_samp_collision(_2).y
   float weight_skate, weight_floor, weight_face_target, weight_look_target, weight_success, weight_target_dist,
       weight_pene, weight_vp;
   int max_depth;
-  int scene_kind;               /* 0: SDF scene (crowd_env_2f), 1: box scenes / walkability map (crowd_env_2f_box) */
+  int scene_kind;               /* 0: SDF scene (crowd_env_2f), 1: box scenes / walkability map (crowd_env_2f_box),
+                                   2: dynamic crowd, boxes of the other members as holes (crowd_env_crowd_eval)    */
   int terminate_on_penetration; /* finetuning (crowd_env_2f.py:299-300) or box env (crowd_env_2f_box.py:325)       */
   int pene_type_body;           /* lossconfig.pene_type == 'body'                                                 */
   float ray_len;                /* 7 (2 when rendering), crowd_env_2f.py:556-558                                   */
@@ -246,6 +247,13 @@ typedef struct egx_env_scenes { /* static scene tables, device pointers */
   const float* floor_height; /* [S] */
   const float* map_lin;    /* [map_res] = torch.linspace(-extent, extent, res)                            */
   int map_res;
+  /* scene_kind 2 (main_crowd_eval.py / crowd_env_crowd_eval.py): G members per scene; walkable polygon of member k =
+   * square floor [-half,half]^2 minus the world-space marker boxes of the other members ("holes", dummy_vector_env.py:34-39) */
+  float* crowd_bbox;       /* [G][S][4] minx,miny,maxx,maxy; read for the others, written for member k        */
+  int crowd_group;         /* G */
+  int crowd_scenes;        /* S = num_agents of the call                                                    */
+  int crowd_member;        /* k: which member the agents of this call are                                   */
+  float crowd_floor_half;  /* 4.0 (crowd_env_crowd_eval.py:391)                                             */
 } egx_env_scenes;
 
 typedef struct egx_env_state {  /* persistent per-agent state, device pointers, updated in place */

@@ -215,7 +215,51 @@ class OracleCrowdEnv:
         local_map[~m] = -1
         return pts_l, local_map
 
+    # ---- crowd scenes (crowd_env_crowd_eval.py) -------------------------------------------------------
+    def set_crowd_boxes(self, boxes, floor_half=4.0):
+        """boxes[A,G-1,4] = (minx,miny,maxx,maxy) of the OTHER members of each agent's scene (the `holes`)."""
+        self.crowd_boxes = np.asarray(boxes, np.float64)
+        self.floor_half = float(floor_half)
+
+    def own_bbox(self):
+        """world-space xy box of the two seed frames' markers (crowd_env_crowd_eval.py:345-352)."""
+        A = self.state.shape[0]
+        m = self.state[:, :, :201].reshape(A, 2, -1, 3)
+        w = torch.einsum("bij,btpj->btpi", self.R0, m) + self.T0[:, None, :, :]
+        xy = w[..., :2]
+        return torch.cat([xy.amin(dim=(1, 2)), xy.amax(dim=(1, 2))], dim=-1)
+
+    def _crowd_edges(self, a):
+        h = self.floor_half
+        rects = [(-h, -h, h, h)] + [tuple(b) for b in self.crowd_boxes[a]]
+        es = []
+        for (x0, y0, x1, y1) in rects:
+            c = [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
+            for q in range(4):
+                es.append([c[q][0], c[q][1], c[(q + 1) % 4][0], c[(q + 1) % 4][1]])
+        return np.asarray(es, np.float64)
+
+    def _crowd_walk_map(self, R0, T0):
+        """_get_dynamic_map (crowd_env_crowd_eval.py:742-764): polygon(floor, holes).contains(point)."""
+        A = R0.shape[0]
+        res, ext = self.cfg["map_res"], self.cfg["map_extent"]
+        lin = torch.linspace(-ext, ext, res)
+        xv, yv = torch.meshgrid(lin, lin, indexing="ij")
+        pts = torch.stack([xv, yv, torch.zeros_like(xv)], dim=2).reshape(1, -1, 3).repeat(A, 1, 1).to(R0.dtype)
+        ps = torch.einsum("bij,bpj->bpi", R0, pts) + T0
+        px, py = ps[:, :, 0], ps[:, :, 1]
+        walk = (px.abs() < self.floor_half) & (py.abs() < self.floor_half)
+        for a in range(A):
+            for b in self.crowd_boxes[a]:
+                inside = (px[a] >= b[0]) & (px[a] <= b[2]) & (py[a] >= b[1]) & (py[a] <= b[3])
+                walk[a] &= ~inside
+        local_map = walk.to(R0.dtype)
+        local_map[~walk] = -1
+        return pts, local_map
+
     def _edges_for(self, a):
+        if self.scene_kind == "crowd":
+            return self._crowd_edges(a)
         if self.scene_kind == "box":
             return np.asarray(self.box_scenes[int(self.scene_idx[a])]["edges"], np.float64)
         return self.edges
@@ -315,8 +359,8 @@ class OracleCrowdEnv:
         new_state = torch.cat([marker_seed.reshape(A, T_HIS, -1), fea_marker], dim=-1)
 
         # ---- penetration (box env :279-295): marker bbox vs local walkability map ----
-        if self.scene_kind == "box":
-            pts_l, local_map = self._walk_map(self.R0, self.T0)
+        if self.scene_kind in ("box", "crowd"):
+            pts_l, local_map = self._walk_map(self.R0, self.T0) if self.scene_kind == "box" else self._crowd_walk_map(self.R0, self.T0)
             mxy = marker_seed[:, :, :, :2] if cfg["pene_type"] == "body" else marker_seed[:, :, self.feet_marker_idx, :2]
             bmin = mxy.amin(dim=(1, 2)).reshape(A, 1, 2)
             bmax = mxy.amax(dim=(1, 2)).reshape(A, 1, 2)
@@ -341,7 +385,9 @@ class OracleCrowdEnv:
         ego = torch.stack([calc_egosensing(jw[a], self._edges_for(a)) for a in range(A)]).to(dt)
 
         at_depth = self.steps == cfg["max_depth"]
-        if self.scene_kind == "box" or self.finetuning:
+        if self.scene_kind == "crowd":
+            terminated = (r_goal > 0) | at_depth                           # crowd_env_crowd_eval.py:367
+        elif self.scene_kind == "box" or self.finetuning:
             terminated = (r_goal > 0) | penetration | at_depth
         else:
             terminated = (r_goal > 0) | at_depth
@@ -439,6 +485,8 @@ class OracleCrowdEnv:
             sv = calc_sdf(vw.reshape(A * 2, -1, 3), self.sdf_dict).reshape(A, 2, -1)
             sv[:, :, self.feet_vids] = 0.0
             accept = sv.lt(0.0).sum(dim=(1, 2)) == 0
+        elif self.scene_kind == "crowd":
+            accept = torch.ones(A, dtype=torch.bool)
         else:
             self.scene_idx = torch.as_tensor(scene_idx).long()
             pts_l, local_map = self._walk_map(R0, T0)

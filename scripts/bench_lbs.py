@@ -29,6 +29,6 @@ for A in (64, 512):
             h.forward(xb, betas, T, out=out, **kw)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        flops = B * 31425 * 496 * 2
+        flops = B * 31425 * 469 * 2
         print(f"A={A} B={B} {name:10s} {ms:8.3f} ms  blend {flops/ms/1e9:7.1f} TFLOP/s  "
               f"{'verts %.1f GB/s' % (B*10475*12/ms/1e6) if 'verts' in name else ''}", flush=True)

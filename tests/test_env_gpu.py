@@ -197,3 +197,70 @@ def test_auto_reset_reinitialises_finished_agents():
     obs, rew, term = env.step(z)
     assert term.sum().item() == A
     assert env.steps.sum().item() == 0 and torch.all(obs["time"] == 1)
+
+
+def test_crowd_group_matches_oracle_with_sequential_hole_updates():
+    """BASELINE config 5 plumbing (main_crowd_eval.py): 4 members per scene, each member's walkable polygon has the world
+    marker boxes of the others as holes, and members step one after the other (dummy_vector_env.py:81-84)."""
+    from egogen_amd.crowd_env import CrowdGroupEnv, DEFAULT_CFG
+    from oracle.env import OracleCrowdEnv
+    from oracle.smplx_lbs import BodyModel
+    S, G = 3, 4
+    w = build_world(V=1536, A=2, scene_kind="sdf", n_pairs=4)   # only for the shared assets / operators
+    env0 = w["env"]
+    rng = np.random.default_rng(3)
+    pts = np.zeros((S, G, 3), np.float32)
+    for s in range(S):
+        t = np.linspace(rng.random(), rng.random() + 2 * np.pi, G, endpoint=False)
+        pts[s, :, 0], pts[s, :, 1] = 1.2 * np.cos(t), 1.2 * np.sin(t)   # close enough that rays see the others
+    st = np.zeros((G, S, 2, 3), np.float32)
+    for k in range(G):
+        st[k, :, 0], st[k, :, 1] = pts[:, k], pts[:, (k + 2) % G]
+    grp = CrowdGroupEnv(S, st, w["handle"], env0.prior, env0.vposer, seed=5)
+    variant = rng.integers(0, len(grp.members[0].variant_starts), (G, S))
+    yaw = (rng.uniform(-1, 1, (G, S)) * 2 * np.pi * 0.2).astype(np.float32)
+    for k, m in enumerate(grp.members):
+        m.set_candidates(st[k].reshape(S, 1, 2, 3), yaw[k], variant[k])
+        m._launch_reset(None)
+    for k, m in enumerate(grp.members):
+        m._launch_reset(None)
+    torch.cuda.synchronize()
+    # oracle members
+    oracles = []
+    for k in range(G):
+        o = OracleCrowdEnv(BodyModel(w["bm"]), w["prior_sd"], {kk: v.float() for kk, v in w["vposer_sd"].items()}, w["mk"], w["feet"],
+                           synth.feet_marker_idx(), scene_kind="crowd", cfg=dict(DEFAULT_CFG))
+        oracles.append(o)
+    boxes = np.zeros((G, S, 4))
+    for k, o in enumerate(oracles):
+        ww = dict(w, env=grp.members[k], oracle=o, A=S)
+        poses, trans, betas = _seed_inputs(grp.members[k], S, variant[k])
+        tr, go, bp, wp = o.next_body(torch.as_tensor(st[k, :, 0]), torch.as_tensor(st[k, :, 1]), poses, trans, betas,
+                                     yaw_jitter=torch.as_tensor(yaw[k]))
+        o.set_crowd_boxes(np.zeros((S, G - 1, 4)))
+        o.reset_from(tr, go, bp, betas, wp)
+        boxes[k] = o.own_bbox().numpy()
+    _close(grp.bbox, boxes, 1e-4, "initial boxes")
+
+    def others(k):
+        return np.stack([boxes[j] for j in range(G) if j != k], axis=1)   # [S,G-1,4]
+
+    g = torch.Generator().manual_seed(9)
+    for it in range(2):
+        for k in range(G):
+            m, o = grp.members[k], oracles[k]
+            # sync the oracle member from the GPU state, give it the CURRENT boxes of the others (sequential semantics)
+            o.set_state(m.state.cpu(), m.seed.cpu(), m.R0.cpu(), m.T0.cpu().reshape(-1, 1, 3), m.betas.cpu(), m.dist.cpu(),
+                        m.steps.cpu(), m.wpath.cpu(), None)
+            boxes = grp.bbox.cpu().numpy().astype(np.float64)
+            o.set_crowd_boxes(others(k))
+            z = torch.randn(S, 128, generator=g)
+            obs, rew, term = m.step(z.cuda(), auto_reset=False)
+            oobs, orew, oterm = o.step(z)
+            _close(m.rterms[:, 6], o.last["r_pene"], 1e-6, f"r_pene member {k}")
+            _close(rew, orew, 3e-4, f"reward member {k}")
+            assert term.cpu().bool().tolist() == oterm.tolist()
+            _close(obs["egosensing"], oobs["egosensing"], 2e-4, f"egosensing member {k}")
+            _close(grp.bbox[k], o.own_bbox(), 2e-4, f"published box member {k}")
+    # some rays must actually be shortened by another member's box in this layout
+    assert float(grp.members[0].obs_ego.min()) < 0.9
