@@ -209,3 +209,15 @@ def test_fused_update_ops_match_torch_autograd():
     models.FUSED_UPDATE_OPS = True; pol.use_fused_loss = True
     lb, _ = pol.minibatch_loss(*args, gs)
     assert abs(float(la) - float(lb)) <= 1e-4 * max(1.0, abs(float(la)))
+
+
+def test_main_crowd_eval_entry_point(tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "crowd_ppo", "main_crowd_eval.py"), "--test-num", "4", "--num-verts", "1024", "--seed", "1"]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "Final reward:" in r.stdout
+    pk = sorted((tmp_path / "log" / "eval_results" / "crowd-4human").glob("motion_crowd4_*.pkl"))
+    assert pk
+    d = pickle.load(open(pk[0], "rb"))
+    assert d["motion"][0]["blended_marker"].shape == (20, 67, 3) and d["wpath"].shape == (2, 3)
