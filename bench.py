@@ -247,6 +247,16 @@ def main():
         lib.egx_event_destroy(e1)
     _log(f"timed region done: {elapsed:.3f}s")
     lbs_ms = float(np.mean(ms_list))
+    # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (profiles/r01_lbs_pmc.json);
+    # it applies only to the configuration that pass was taken on
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lbs_pmc.json")))
+        c = pmc["config"]
+        if c["agents"] == A and c["num_verts"] == args.num_verts and args.scene == "single_box" and args.sdf_res == 256:
+            traffic = pmc["derived"]["hbm_side_bytes_per_launch"]
+    except Exception:
+        pass
     bodies = A * 20
     achieved = FLOP_PER_BODY * bodies / (lbs_ms * 1e-3) / 1e12
 
@@ -271,7 +281,7 @@ def main():
                    "parallelism": f"dp{world}" if world > 1 else "single", "hip_graph_env": bool(args.graph),
                    "hip_graph_update": bool(args.update_graph) and not any(v.get("failed") for v in policy._graph_cache.values())},
         "roofline": {"bound": "mfma", "kernel": "egx_lbs_fused_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
                      "flop_per_body": FLOP_PER_BODY},
     }
