@@ -10,8 +10,25 @@ struct EgxSeg {
 // out = act(cat(segs) W^T + b) + res      (W: [N,K] torch layout)
 int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg, const float* W, const float* b,
                       int act, float slope, const float* res, int ldr, float* out, int ldo);
+// one GEMM description for the paired launcher; ldw = 0 means "K" (weights may also be a column block of a wider matrix)
+struct EgxLin {
+  int M, N;
+  EgxSeg segs[4];
+  int nseg;
+  const float* W;
+  int ldw;
+  const float* b;
+  int act;
+  float slope;
+  const float* res;
+  int ldr;
+  float* out;
+  int ldo;
+};
+int egx_launch_linear_pair(hipStream_t st, const EgxLin& A, const EgxLin& B);
 int egx_launch_gru_pointwise(hipStream_t st, const float* gi, const float* gh, const float* hprev, int ldh, float* hout,
                              int ldo, int M, int H);
+int egx_launch_gru_pointwise_first(hipStream_t st, const float* gi, const float* b_hh, float* hout, int ldo, int M, int H);
 int egx_launch_cont6d_to_aa(hipStream_t st, const float* xb6, int n, float* out, int ldo);
 int egx_launch_posenc(hipStream_t st, const float* dist, const float* time, int A, float* out);
 

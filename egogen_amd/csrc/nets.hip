@@ -83,7 +83,15 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs a) {
+struct LinArgs2 {
+  LinArgs p0, p1;
+  int blocks0;  // blocks [0, blocks0) work on p0, the rest on p1 (independent GEMMs sharing one launch)
+};
+
+__global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
+  const bool second = (int)blockIdx.x >= two.blocks0;
+  const LinArgs& a = second ? two.p1 : two.p0;
+  const int bid = second ? (int)blockIdx.x - two.blocks0 : (int)blockIdx.x;
   // Each wave owns a quarter of K and walks it in blocks of 32: the 32x32 X block and the 32x32 W block are fetched
   // with row-contiguous 16-byte loads (8 lanes cover one 128-byte row segment: every cache line is requested once and
   // used completely), parked in a wave-private LDS strip with a 36-float row pitch, and read back as MFMA operand
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs a) {
   int mt, nt;
   {
     const int MT = (a.M + 31) >> 5, NT = (a.N + 31) >> 5;
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int xcd = bid & 7, local = bid >> 3;
     if (NT >= MT) {
       const int per = (NT + 7) >> 3;
       nt = xcd * per + local / MT;
@@ -185,13 +193,13 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs a) {
 
 // GRU gate math (torch.nn.GRU / GRUCell, gate order r,z,n): gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh
 __global__ void egx_gru_pointwise_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
-                                         const float* __restrict__ hprev, int ldh, float* __restrict__ hout, int ldo,
-                                         int M, int H) {
+                                         const float* __restrict__ gh_bias, const float* __restrict__ hprev, int ldh,
+                                         float* __restrict__ hout, int ldo, int M, int H) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * H) return;
   const int m = idx / H, c = idx % H;
   const float* gim = gi + (size_t)m * 3 * H;
-  const float* ghm = gh + (size_t)m * 3 * H;
+  const float* ghm = gh ? gh + (size_t)m * 3 * H : gh_bias;  // zero previous state: h W_hh^T + b_hh = b_hh
   const float r = 1.f / (1.f + expf(-(gim[c] + ghm[c])));
   const float z = 1.f / (1.f + expf(-(gim[H + c] + ghm[H + c])));
   const float nn = tanhf(gim[2 * H + c] + r * ghm[2 * H + c]);
@@ -437,8 +445,8 @@ __global__ void egx_gae_kernel(const float* __restrict__ v, const float* __restr
 }
 
 // ---- internal launchers ---------------------------------------------------------------------------
-int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg, const float* W, const float* b,
-                      int act, float slope, const float* res, int ldr, float* out, int ldo) {
+static LinArgs make_lin_args(int M, int N, const EgxSeg* segs, int nseg, const float* W, int ldw, const float* b, int act,
+                             float slope, const float* res, int ldr, float* out, int ldo) {
   LinArgs a;
   const float* ps[4] = {nullptr, nullptr, nullptr, nullptr};
   int ws[4] = {0, 0, 0, 0}, ls[4] = {0, 0, 0, 0};
@@ -450,18 +458,46 @@ int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg
   a.xp0 = ps[0]; a.xp1 = ps[1]; a.xp2 = ps[2]; a.xp3 = ps[3];
   a.xw0 = ws[0]; a.xw1 = ws[1]; a.xw2 = ws[2]; a.xw3 = ws[3];
   a.xl0 = ls[0]; a.xl1 = ls[1]; a.xl2 = ls[2]; a.xl3 = ls[3];
-  a.W = W; a.ldw = K; a.bias = b; a.res = res; a.ldr = ldr; a.y = out; a.ldy = ldo;
+  a.W = W; a.ldw = ldw > 0 ? ldw : K; a.bias = b; a.res = res; a.ldr = ldr; a.y = out; a.ldy = ldo;
   a.M = M; a.N = N; a.K = K; a.act = act; a.slope = slope;
-  const int MT = egx_ceil_div(M, 32), NT = egx_ceil_div(N, 32);
-  const int grid = (NT >= MT) ? 8 * egx_ceil_div(NT, 8) * MT : 8 * egx_ceil_div(MT, 8) * NT;
-  hipLaunchKernelGGL(egx_linear_kernel, dim3(grid), dim3(256), 0, st, a);
+  return a;
+}
+static int lin_blocks(const LinArgs& a) {
+  const int MT = egx_ceil_div(a.M, 32), NT = egx_ceil_div(a.N, 32);
+  return (NT >= MT) ? 8 * egx_ceil_div(NT, 8) * MT : 8 * egx_ceil_div(MT, 8) * NT;
+}
+
+int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg, const float* W, const float* b,
+                      int act, float slope, const float* res, int ldr, float* out, int ldo) {
+  LinArgs2 two;
+  two.p0 = make_lin_args(M, N, segs, nseg, W, 0, b, act, slope, res, ldr, out, ldo);
+  two.p1 = two.p0;
+  two.blocks0 = lin_blocks(two.p0);
+  hipLaunchKernelGGL(egx_linear_kernel, dim3(two.blocks0), dim3(256), 0, st, two);
+  return EGX_OK;
+}
+
+// two independent GEMMs in one launch (e.g. the x-side and h-side products of a GRU cell)
+int egx_launch_linear_pair(hipStream_t st, const EgxLin& A, const EgxLin& B) {
+  LinArgs2 two;
+  two.p0 = make_lin_args(A.M, A.N, A.segs, A.nseg, A.W, A.ldw, A.b, A.act, A.slope, A.res, A.ldr, A.out, A.ldo);
+  two.p1 = make_lin_args(B.M, B.N, B.segs, B.nseg, B.W, B.ldw, B.b, B.act, B.slope, B.res, B.ldr, B.out, B.ldo);
+  two.blocks0 = lin_blocks(two.p0);
+  hipLaunchKernelGGL(egx_linear_kernel, dim3(two.blocks0 + lin_blocks(two.p1)), dim3(256), 0, st, two);
   return EGX_OK;
 }
 
 int egx_launch_gru_pointwise(hipStream_t st, const float* gi, const float* gh, const float* hprev, int ldh, float* hout,
                              int ldo, int M, int H) {
-  hipLaunchKernelGGL(egx_gru_pointwise_kernel, dim3(egx_ceil_div(M * H, 256)), dim3(256), 0, st, gi, gh, hprev, ldh, hout,
-                     ldo, M, H);
+  hipLaunchKernelGGL(egx_gru_pointwise_kernel, dim3(egx_ceil_div(M * H, 256)), dim3(256), 0, st, gi, gh, nullptr, hprev, ldh,
+                     hout, ldo, M, H);
+  return EGX_OK;
+}
+
+// first step of a sequence: zero previous state, so gh is just the bias b_hh (no GEMM, no state tensor)
+int egx_launch_gru_pointwise_first(hipStream_t st, const float* gi, const float* b_hh, float* hout, int ldo, int M, int H) {
+  hipLaunchKernelGGL(egx_gru_pointwise_kernel, dim3(egx_ceil_div(M * H, 256)), dim3(256), 0, st, gi, nullptr, b_hh, nullptr, 0,
+                     hout, ldo, M, H);
   return EGX_OK;
 }
 

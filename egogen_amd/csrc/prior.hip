@@ -26,7 +26,7 @@ extern "C" size_t egx_sample_prior_workspace_bytes(int A) {
   if (A <= 0) return 0;
   const size_t a = A, m = (size_t)A * T_PRED;
   (void)m;
-  return carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 512, a * H});
+  return carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 3 * H, a * 512, a * H});
 }
 
 extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, const float* x1, int x_ld,
@@ -46,43 +46,46 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
   float* hB = cv.take((size_t)A * H);
   float* gi = cv.take((size_t)A * 3 * H);
   float* gh = cv.take((size_t)A * 3 * H);
+  float* gconst = cv.take((size_t)A * 3 * H);
   float* t512 = cv.take((size_t)A * 512);
   float* t256 = cv.take((size_t)A * H);
 
+  auto lin = [](int M, int N, std::initializer_list<EgxSeg> segs, const float* W, int ldw, const float* b, int act,
+                const float* res, int ldr, float* out, int ldo) {
+    EgxLin l;
+    l.M = M; l.N = N; l.nseg = 0;
+    for (const EgxSeg& sg : segs) l.segs[l.nseg++] = sg;
+    l.W = W; l.ldw = ldw; l.b = b; l.act = act; l.slope = 0.f; l.res = res; l.ldr = ldr; l.out = out; l.ldo = ldo;
+    return l;
+  };
   // ---- x_enc GRU over the 2 history frames (zero initial state) -> hx
   {
     EgxSeg s0{x0, MK, x_ld};
     egx_launch_linear(st, A, 3 * H, &s0, 1, w->x_enc_w_ih, w->x_enc_b_ih, 0, 0.f, nullptr, 0, gi, 3 * H);
-    // zero initial state, kept explicit so both steps share one code path
-    EGX_HIP_CHECK(hipMemsetAsync(hA, 0, (size_t)A * H * sizeof(float), st));
-    EgxSeg sh{hA, H, H};
-    egx_launch_linear(st, A, 3 * H, &sh, 1, w->x_enc_w_hh, w->x_enc_b_hh, 0, 0.f, nullptr, 0, gh, 3 * H);
-    egx_launch_gru_pointwise(st, gi, gh, hA, H, hB, H, A, H);
-    EgxSeg s1{x1, MK, x_ld};
-    egx_launch_linear(st, A, 3 * H, &s1, 1, w->x_enc_w_ih, w->x_enc_b_ih, 0, 0.f, nullptr, 0, gi, 3 * H);
-    EgxSeg shb{hB, H, H};
-    egx_launch_linear(st, A, 3 * H, &shb, 1, w->x_enc_w_hh, w->x_enc_b_hh, 0, 0.f, nullptr, 0, gh, 3 * H);
+    egx_launch_gru_pointwise_first(st, gi, w->x_enc_b_hh, hB, H, A, H);
+    egx_launch_linear_pair(st, lin(A, 3 * H, {{x1, MK, x_ld}}, w->x_enc_w_ih, 0, w->x_enc_b_ih, 0, nullptr, 0, gi, 3 * H),
+                           lin(A, 3 * H, {{hB, H, H}}, w->x_enc_w_hh, 0, w->x_enc_b_hh, 0, nullptr, 0, gh, 3 * H));
     egx_launch_gru_pointwise(st, gi, gh, hB, H, hx, H, A, H);
   }
-  // ---- h_rnn = drnn_mlp(hx)  (tanh after every layer)
+  // ---- h_rnn = drnn_mlp(hx)  (tanh after every layer); in the same launches: the part of the decoder GRU's input
+  // product that does not change over the 18 steps, gconst = [hx | z] W_ih[:, :384]^T + b_ih   (rnn_in = [hx, z, y_p])
   float* hcur = hA;
   float* hnext = hB;
+  const int KIN = H + ZD + MK;  // 585
   {
-    EgxSeg s{hx, H, H};
-    egx_launch_linear(st, A, 512, &s, 1, w->drnn_w[0], w->drnn_b[0], 1, 0.f, nullptr, 0, t512, 512);
+    egx_launch_linear_pair(st, lin(A, 512, {{hx, H, H}}, w->drnn_w[0], 0, w->drnn_b[0], 1, nullptr, 0, t512, 512),
+                           lin(A, 3 * H, {{hx, H, H}, {z, ZD, ZD}}, w->d_rnn_w_ih, KIN, w->d_rnn_b_ih, 0, nullptr, 0, gconst, 3 * H));
     EgxSeg s2{t512, 512, 512};
     egx_launch_linear(st, A, H, &s2, 1, w->drnn_w[1], w->drnn_b[1], 1, 0.f, nullptr, 0, t256, H);
     EgxSeg s3{t256, H, H};
     egx_launch_linear(st, A, H, &s3, 1, w->drnn_w[2], w->drnn_b[2], 1, 0.f, nullptr, 0, hcur, H);
   }
-  // ---- 18 decode steps
+  // ---- 18 decode steps: one paired launch for the two GRU products, gate math, two MLP layers, output + residual
   for (int i = 0; i < T_PRED; ++i) {
     const float* yp = (i == 0) ? x1 : out_Y + (size_t)(i - 1) * A * MK;
     const int yp_ld = (i == 0) ? x_ld : MK;
-    EgxSeg in[3] = {{hx, H, H}, {z, ZD, ZD}, {yp, MK, yp_ld}};
-    egx_launch_linear(st, A, 3 * H, in, 3, w->d_rnn_w_ih, w->d_rnn_b_ih, 0, 0.f, nullptr, 0, gi, 3 * H);
-    EgxSeg sh{hcur, H, H};
-    egx_launch_linear(st, A, 3 * H, &sh, 1, w->d_rnn_w_hh, w->d_rnn_b_hh, 0, 0.f, nullptr, 0, gh, 3 * H);
+    egx_launch_linear_pair(st, lin(A, 3 * H, {{yp, MK, yp_ld}}, w->d_rnn_w_ih + (H + ZD), KIN, nullptr, 0, gconst, 3 * H, gi, 3 * H),
+                           lin(A, 3 * H, {{hcur, H, H}}, w->d_rnn_w_hh, 0, w->d_rnn_b_hh, 0, nullptr, 0, gh, 3 * H));
     egx_launch_gru_pointwise(st, gi, gh, hcur, H, hnext, H, A, H);
     EgxSeg s1{hnext, H, H};
     egx_launch_linear(st, A, 512, &s1, 1, w->d_mlp_w[0], w->d_mlp_b[0], 1, 0.f, nullptr, 0, t512, 512);
@@ -110,7 +113,8 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
 extern "C" size_t egx_policy_workspace_bytes(int n) {
   if (n <= 0) return 0;
   const size_t m = n;
-  return carve_bytes({m * 1536, m * 1536, m * 512, m * 512, m * 512, m * 128, m * 1152, m * 1152, m * 256});
+  return carve_bytes({m * 1536, m * 1536, m * 512, m * 512, m * 512, m * 128, m * 1152, m * 1152, m * 256,
+                      m * 1536, m * 1536, m * 512, m * 1152, m * 1152, m * 1152});
 }
 
 extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* state, const float* ego, const float* dist,
@@ -136,56 +140,58 @@ extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* stat
   float* a2 = cv.take(m * 1152);
   float* zp = cv.take(m * 256);
   constexpr int HD = 512;
-  EGX_HIP_CHECK(hipMemsetAsync(h0, 0, m * HD * sizeof(float), st));
-  auto gru2 = [&](const float* x, int in_dim, const float* wih, const float* whh, const float* bih, const float* bhh,
-                  float* hout, float* htmp) {
-    // sequence of 2 steps: x[n,2,in_dim]
-    EgxSeg s0{x, in_dim, 2 * in_dim};
-    egx_launch_linear(st, n, 3 * HD, &s0, 1, wih, bih, 0, 0.f, nullptr, 0, gi, 3 * HD);
-    EgxSeg sh{h0, HD, HD};
-    egx_launch_linear(st, n, 3 * HD, &sh, 1, whh, bhh, 0, 0.f, nullptr, 0, gh, 3 * HD);
-    egx_launch_gru_pointwise(st, gi, gh, h0, HD, htmp, HD, n, HD);
-    EgxSeg s1{x + in_dim, in_dim, 2 * in_dim};
-    egx_launch_linear(st, n, 3 * HD, &s1, 1, wih, bih, 0, 0.f, nullptr, 0, gi, 3 * HD);
-    EgxSeg sh1{htmp, HD, HD};
-    egx_launch_linear(st, n, 3 * HD, &sh1, 1, whh, bhh, 0, 0.f, nullptr, 0, gh, 3 * HD);
-    egx_launch_gru_pointwise(st, gi, gh, htmp, HD, hout, HD, n, HD);
+  auto lin = [](int M, int N, std::initializer_list<EgxSeg> segs, const float* W, const float* b, int act, float slope,
+                const float* res, int ldr, float* out, int ldo) {
+    EgxLin l;
+    l.M = M; l.N = N; l.nseg = 0;
+    for (const EgxSeg& sg : segs) l.segs[l.nseg++] = sg;
+    l.W = W; l.ldw = 0; l.b = b; l.act = act; l.slope = slope; l.res = res; l.ldr = ldr; l.out = out; l.ldo = ldo;
+    return l;
   };
-  gru2(state, 402, w->x_enc_w_ih, w->x_enc_w_hh, w->x_enc_b_ih, w->x_enc_b_hh, hxs, a1);
-  gru2(ego, 32, w->ego_enc_w_ih, w->ego_enc_w_hh, w->ego_enc_b_ih, w->ego_enc_b_hh, hes, a1);
+  // two independent 2-step GRUs (markers+features 402 -> 512, egosensing 32 -> 512): their products share launches
+  float* hx1 = h0;              // first-step hidden state of the marker encoder
+  float* egi = cv.take(m * 1536);
+  float* egh = cv.take(m * 1536);
+  float* eh1 = cv.take(m * 512);
+  egx_launch_linear_pair(st, lin(n, 3 * HD, {{state, 402, 804}}, w->x_enc_w_ih, w->x_enc_b_ih, 0, 0.f, nullptr, 0, gi, 3 * HD),
+                         lin(n, 3 * HD, {{ego, 32, 64}}, w->ego_enc_w_ih, w->ego_enc_b_ih, 0, 0.f, nullptr, 0, egi, 3 * HD));
+  egx_launch_gru_pointwise_first(st, gi, w->x_enc_b_hh, hx1, HD, n, HD);
+  egx_launch_gru_pointwise_first(st, egi, w->ego_enc_b_hh, eh1, HD, n, HD);
+  egx_launch_linear_pair(st, lin(n, 3 * HD, {{state + 402, 402, 804}}, w->x_enc_w_ih, w->x_enc_b_ih, 0, 0.f, nullptr, 0, gi, 3 * HD),
+                         lin(n, 3 * HD, {{ego + 32, 32, 64}}, w->ego_enc_w_ih, w->ego_enc_b_ih, 0, 0.f, nullptr, 0, egi, 3 * HD));
+  egx_launch_linear_pair(st, lin(n, 3 * HD, {{hx1, HD, HD}}, w->x_enc_w_hh, w->x_enc_b_hh, 0, 0.f, nullptr, 0, gh, 3 * HD),
+                         lin(n, 3 * HD, {{eh1, HD, HD}}, w->ego_enc_w_hh, w->ego_enc_b_hh, 0, 0.f, nullptr, 0, egh, 3 * HD));
+  egx_launch_gru_pointwise(st, gi, gh, hx1, HD, hxs, HD, n, HD);
+  egx_launch_gru_pointwise(st, egi, egh, eh1, HD, hes, HD, n, HD);
   egx_launch_posenc(st, dist, time, n, pe);
   const float slope = 0.01f;  // torch.nn.LeakyReLU() default (baseops.py:627-628)
-  auto mlp_block = [&](const float* const* W, const float* const* B, const float* Wo, const float* Bo, int nout,
-                       float* out, int ldo) {
-    // h = hx; for blk: h = lrelu(fc2(lrelu(fc1(h)))) + h ; y = out_fc(h)
-    EgxSeg hx4[4] = {{hxs, HD, HD}, {hes, HD, HD}, {pe, 64, 128}, {pe + 64, 64, 128}};
-    egx_launch_linear(st, n, 1152, hx4, 4, W[0], B[0], 3, slope, nullptr, 0, a1, 1152);
-    // the residual of block 0 is the concatenated hx: materialise it once as one [n,1152] buffer (a2)
-    EGX_HIP_CHECK(hipMemcpy2DAsync(a2, 1152 * sizeof(float), hxs, HD * sizeof(float),
-                                   HD * sizeof(float), n, hipMemcpyDeviceToDevice, st));
-    EGX_HIP_CHECK(hipMemcpy2DAsync(a2 + HD, 1152 * sizeof(float), hes, HD * sizeof(float), HD * sizeof(float), n,
-                                   hipMemcpyDeviceToDevice, st));
-    EGX_HIP_CHECK(hipMemcpy2DAsync(a2 + 2 * HD, 1152 * sizeof(float), pe, 128 * sizeof(float), 128 * sizeof(float), n,
-                                   hipMemcpyDeviceToDevice, st));
-    EgxSeg s1{a1, 1152, 1152};
-    egx_launch_linear(st, n, 1152, &s1, 1, W[1], B[1], 3, slope, a2, 1152, a2, 1152);
-    EgxSeg s2{a2, 1152, 1152};
-    egx_launch_linear(st, n, 1152, &s2, 1, W[2], B[2], 3, slope, nullptr, 0, a1, 1152);
-    egx_launch_linear(st, n, 1152, &s1, 1, W[3], B[3], 3, slope, a2, 1152, a2, 1152);
-    egx_launch_linear(st, n, nout, &s2, 1, Wo, Bo, 0, 0.f, nullptr, 0, out, ldo);
-    return EGX_OK;
+  // hx as one [n,1152] buffer: residual of the first block of both heads
+  float* hxcat = cv.take(m * 1152);
+  EGX_HIP_CHECK(hipMemcpy2DAsync(hxcat, 1152 * sizeof(float), hxs, HD * sizeof(float), HD * sizeof(float), n, hipMemcpyDeviceToDevice, st));
+  EGX_HIP_CHECK(hipMemcpy2DAsync(hxcat + HD, 1152 * sizeof(float), hes, HD * sizeof(float), HD * sizeof(float), n, hipMemcpyDeviceToDevice, st));
+  EGX_HIP_CHECK(hipMemcpy2DAsync(hxcat + 2 * HD, 1152 * sizeof(float), pe, 128 * sizeof(float), 128 * sizeof(float), n, hipMemcpyDeviceToDevice, st));
+  float* c1 = cv.take(m * 1152);  // critic activations (actor uses a1 / a2)
+  float* c2 = cv.take(m * 1152);
+  const bool do_a = out_mu != nullptr, do_c = out_value != nullptr;
+  auto layer = [&](const float* xin, const float* W, const float* B, int N, int act, const float* res, float* out, int ldo) {
+    return lin(n, N, {{xin, 1152, 1152}}, W, B, act, slope, res, res ? 1152 : 0, out, ldo);
   };
-  if (out_mu) {
-    int rc = mlp_block(w->actor_w, w->actor_b, w->actor_out_w, w->actor_out_b, 256, zp, 256);
-    if (rc) return rc;
+  // h = hx; for blk: h = lrelu(fc2(lrelu(fc1(h)))) + h ; y = out_fc(h)   - actor and critic layer i share a launch
+  auto run = [&](const EgxLin& la, const EgxLin& lc) {
+    if (do_a && do_c) egx_launch_linear_pair(st, la, lc);
+    else if (do_a) egx_launch_linear(st, la.M, la.N, la.segs, la.nseg, la.W, la.b, la.act, la.slope, la.res, la.ldr, la.out, la.ldo);
+    else egx_launch_linear(st, lc.M, lc.N, lc.segs, lc.nseg, lc.W, lc.b, lc.act, lc.slope, lc.res, lc.ldr, lc.out, lc.ldo);
+  };
+  run(layer(hxcat, w->actor_w[0], w->actor_b[0], 1152, 3, nullptr, a1, 1152), layer(hxcat, w->critic_w[0], w->critic_b[0], 1152, 3, nullptr, c1, 1152));
+  run(layer(a1, w->actor_w[1], w->actor_b[1], 1152, 3, hxcat, a2, 1152), layer(c1, w->critic_w[1], w->critic_b[1], 1152, 3, hxcat, c2, 1152));
+  run(layer(a2, w->actor_w[2], w->actor_b[2], 1152, 3, nullptr, a1, 1152), layer(c2, w->critic_w[2], w->critic_b[2], 1152, 3, nullptr, c1, 1152));
+  run(layer(a1, w->actor_w[3], w->actor_b[3], 1152, 3, a2, a2, 1152), layer(c1, w->critic_w[3], w->critic_b[3], 1152, 3, c2, c2, 1152));
+  run(layer(a2, w->actor_out_w, w->actor_out_b, 256, 0, nullptr, zp, 256), layer(c2, w->critic_out_w, w->critic_out_b, 1, 0, nullptr, out_value, 1));
+  if (do_a) {
     EGX_HIP_CHECK(hipMemcpy2DAsync(out_mu, 128 * sizeof(float), zp, 256 * sizeof(float), 128 * sizeof(float), n,
                                    hipMemcpyDeviceToDevice, st));
     EGX_HIP_CHECK(hipMemcpy2DAsync(out_logvar, 128 * sizeof(float), zp + 128, 256 * sizeof(float), 128 * sizeof(float), n,
                                    hipMemcpyDeviceToDevice, st));
-  }
-  if (out_value) {
-    int rc = mlp_block(w->critic_w, w->critic_b, w->critic_out_w, w->critic_out_b, 1, out_value, 1);
-    if (rc) return rc;
   }
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;

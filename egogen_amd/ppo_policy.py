@@ -121,8 +121,14 @@ class GAMMAPPOPolicy(nn.Module):
         """ppo_policy.py:93-140: values of obs / obs_next, GAE returns and advantages."""
         lib = _lib.load()
         n, A = batch.n, batch.A
-        v = self.values(batch.obs_flat(n + 1))
-        batch.values.copy_(v.reshape(n + 1, A))
+        if getattr(batch, "rollout_values_valid", False):
+            # V(obs_0..n-1) were produced by the rollout forward passes with the same weights (the reference re-evaluates
+            # them, ppo_policy.py:110-112, and gets the same numbers); only the observation after the last step is new
+            last = {k: v[n * A:(n + 1) * A] for k, v in batch.obs_flat(n + 1).items()}
+            batch.values[n].copy_(self.values(last))
+        else:
+            v = self.values(batch.obs_flat(n + 1))
+            batch.values.copy_(v.reshape(n + 1, A))
         rc = lib.egx_gae(_lib.ptr(batch.values), _lib.ptr(batch.rew), _lib.ptr(batch.term), n, A, float(self._gamma),
                          float(self._lambda), _lib.ptr(batch.returns), _lib.ptr(batch.adv), _lib.current_stream_ptr())
         _lib.check(rc, "egx_gae")

@@ -96,6 +96,7 @@ class Collector:
             b.mu[t].copy_(out["mu"])
             b.logvar[t].copy_(out["logvar"])
             b.logp_old[t].copy_(out["logp"])
+            b.values[t].copy_(out["value"])
             if self._episodes is not None:
                 self._wpath_before = self.env.wpath.cpu()
             if self._episodes is not None:
@@ -109,6 +110,7 @@ class Collector:
             self._track(rew, term)
             self.obs = obs
         b.store_obs(n_vec_steps, self.obs)
+        b.rollout_values_valid = True
         return b
 
     def collect_episodes(self, n_episode: int, max_steps: int = 64) -> Dict[str, float]:
