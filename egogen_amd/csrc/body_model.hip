@@ -61,10 +61,10 @@ constexpr int KACT = 10 + 51 * 9;      // 469 live columns
 constexpr int KDIM = EGX_BLEND_K;      // 472 = 469 padded to a multiple of 8
 constexpr int KSTEPS = KDIM / 2;       // 236 MFMA k-steps (32x32x2)
 constexpr int KGROUPS = KSTEPS / 4;    // 59 float4 groups
+static_assert(KGROUPS >= 2, "the operand ring preloads two k-groups");
 __host__ __device__ inline int egx_compact_joint(int j) { return (j - 1) - (j > 24 ? 3 : 0); }  // j in 1..54, j != 22..24
 constexpr int NLMK = 51, NEXTRA = 21;
 constexpr int BODY_PAD = 256;          // bodies per workgroup of the fused kernel
-constexpr int LBS_NW_MAX = 16;         // skinning weights per vertex held in LDS (ELL width, multiple of 4)
 
 struct PoseConsts {
   int parents[NJ];
@@ -81,9 +81,9 @@ struct PoseConsts {
 struct egx_body_model {
   int V = 0, NVT = 0, NW = 0, M = 0, NP = 0;
   f32x4* dirs = nullptr;       // [NVT][62][3][64] float4
-  float* vtemp = nullptr;      // [NVT][3][32]
-  int* widx = nullptr;         // [NVT*32][NW]
-  float* wval = nullptr;       // [NVT*32][NW]
+  int* tj_off = nullptr;       // [NVT+1] offsets into the per-tile joint lists
+  int* tj_idx = nullptr;       // [tj_off[NVT]] joints with a non-zero skinning weight on some vertex of the tile
+  float* tj_w = nullptr;       // [tj_off[NVT]][32] dense weights of the tile's 32 vertices for that joint
   int* pick_slot = nullptr;    // [NVT*32], -1 = not picked
   uint8_t* vflags = nullptr;   // [NVT*32] bit0 feet, bit1 valid
   PoseConsts* pc = nullptr;
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
         const int k0 = 10 + egx_compact_joint(j) * 9;
         for (int e = 0; e < 9; ++e) feat_store(k0 + e, R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f));
       }
-      if (j >= 22 && j <= 24) feat_store(KACT + (j - 22), 0.f);  // zero padding columns 469..471
+      // column 469 multiplies the template column of the bases (acc = v_template + offsets); 470, 471 are padding
+      if (j >= 22 && j <= 24) feat_store(KACT + (j - 22), j == 22 ? 1.f : 0.f);
     }
   }
   __syncthreads();
@@ -205,9 +206,9 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
 // ------------------------------------------------------------------------------------------------
 struct LbsParams {
   const f32x4* dirs;
-  const float* vtemp;
-  const int* widx;
-  const float* wval;
+  const int* tj_off;
+  const int* tj_idx;
+  const float* tj_w;
   const int* pick_slot;
   const uint8_t* vflags;
   const f32x4* feat;   // [bt][62][64] float4
@@ -215,8 +216,9 @@ struct LbsParams {
   const float* xb;     // transl = xb[b*93 + 0..2]
   int B, V, NVT, NW, NP, fpa;
   int nbg;             // body groups (256 bodies each)
-  int stagger_lo, stagger_hi;  // block-id range delayed at start (second residency slot of every CU)
-  long long stagger_cycles;
+  int set_mode;
+  long long phase_delay;  // shader cycles the second wave set waits before its first item (half an MFMA phase)
+  int dbg;             // development ablations (EGX_LBS_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop
   float* verts;        // [B][V][3] or null
   float* picked;       // [B][NP][3] or null
   SdfDev sdf;
@@ -225,56 +227,73 @@ struct LbsParams {
   int* pene;           // [B]
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(float a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(f32x2{a, a}, b, c); }
+
+// Persistent workgroups, one per CU, eight waves = two wave SETS that share the four SIMDs (wave w and w+4 sit on the
+// same SIMD).  Each set walks its own stream of work items (vertex tile x 256 bodies: 4 waves x 64 bodies); set 1 starts
+// half an MFMA phase late, so one wave of every SIMD is in its epilogue (skinning, SDF, picks: VALU + dependent loads,
+// matrix pipe untouched) while the other runs its MFMA loop.  Equal per-item work keeps the two sets in anti-phase for
+// the whole launch; nothing synchronises across waves (per-wave LDS metadata, no barriers).
+constexpr int LBS_META_BYTES = 7424;                 // s_W[55*32] f32, s_jl[56], s_slot[32], masks[4] (16-byte multiple)
+constexpr int LBS_VERT_BYTES = 32 * 97 * 4;          // per-wave transpose buffer of the vertex-writing variants
+constexpr int LBS_QCAP = 640;                        // entries of the per-wave queue of undecided SDF points (>= 512 + 64)
+constexpr int LBS_THREADS = 512;
+
 template <bool WRITE_VERTS, bool DO_SDF>
-__global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
+__global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams p) {
   constexpr int NB = 2;  // 32-body MFMA column tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // which waves share a SIMD is a property of the dispatcher; set_mode picks the pairing
+  const int set = (p.set_mode == 0) ? (wave >> 2) : (p.set_mode == 1) ? (wave & 1) : ((wave >> 1) & 1);
+  const int w4 = (p.set_mode == 0) ? (wave & 3) : (p.set_mode == 1) ? (wave >> 1) : ((wave & 1) | ((wave >> 2) << 1));
   const int n = lane & 31, half = lane >> 5;
-  // block -> (vertex tile, body group).  With >= 8 body groups each XCD (block id % 8) owns a
-  // contiguous chunk of body groups so their packed features / transforms stay in that XCD's L2
-  // while the 62 MB of blend bases stream through once per XCD.
-  int vt, bg;
-  {
-    const int id = blockIdx.x;
-    if (p.nbg >= 8) {
-      const int per = (p.nbg + 7) / 8;
-      const int xcd = id & 7, local = id >> 3;
-      bg = xcd * per + local % per;
-      vt = local / per;
-      if (bg >= p.nbg || vt >= p.NVT) return;
-    } else {
-      bg = id % p.nbg;
-      vt = id / p.nbg;
-    }
+  char* my = smem_raw + wave * (LBS_META_BYTES + (WRITE_VERTS ? LBS_VERT_BYTES : (DO_SDF ? LBS_QCAP * 16 : 0)));
+  float* s_W = reinterpret_cast<float*>(my);                        // [jj][row]
+  int* s_jl = reinterpret_cast<int*>(my + NJ * 32 * 4);             // [jj]
+  int* s_slot = s_jl + 56;                                          // [row]
+  unsigned* s_masks = reinterpret_cast<unsigned*>(s_slot + 32);     // [0] rows with a pick slot, [1] rows in the SDF count
+  float* lds = reinterpret_cast<float*>(my + LBS_META_BYTES);
+  f32x4* s_queue = reinterpret_cast<f32x4*>(my + LBS_META_BYTES);   // undecided SDF points (x, y, z, body)
+  // work streams.  With >= 8 body groups every XCD (block id % 8) owns a contiguous chunk of body groups, so their packed
+  // features / transforms stay in that XCD's L2 while the blend bases stream through once per XCD; the streams of an XCD
+  // walk its (vertex tile, body group) list vertex-tile-major, i.e. at any time they share a dozen consecutive tiles.
+  int bg_lo, nper, n_streams, stream;
+  if (p.nbg >= 8 && (gridDim.x & 7) == 0) {
+    const int per = (p.nbg + 7) / 8, xcd = blockIdx.x & 7;
+    bg_lo = xcd * per;
+    nper = max(0, min(per, p.nbg - bg_lo));
+    n_streams = (gridDim.x >> 3) * 2;
+    stream = (blockIdx.x >> 3) * 2 + set;
+  } else {
+    bg_lo = 0; nper = p.nbg;
+    n_streams = gridDim.x * 2;
+    stream = blockIdx.x * 2 + set;
   }
-  const int bt0 = bg * 8 + wave * NB;  // first 32-body tile of this wave
+  const int n_items = p.NVT * nper;
   const int num_bt = (p.B + 31) >> 5;
-  // Phase stagger: two workgroups share each CU (2 waves per SIMD).  Launched together they run their MFMA loops at the
-  // same time (sharing the matrix pipe) and then their epilogues at the same time (matrix pipe idle).  Delaying the
-  // second-slot workgroups of the FIRST generation by about half a tile puts the pairs in anti-phase - one wave's
-  // epilogue under the other's MFMA loop - and the offset persists because successors start when a slot frees up.
-  if (p.stagger_cycles > 0 && blockIdx.x >= (unsigned)p.stagger_lo && blockIdx.x < (unsigned)p.stagger_hi) {
+  if (set == 1 && p.phase_delay > 0 && stream < n_items) {
     const long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < p.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+    while (__builtin_readcyclecounter() - t0 < p.phase_delay) __builtin_amdgcn_s_sleep(16);
   }
-  // per-vertex metadata of this tile (shared by the 4 waves): skinning weights, template, pick slot, flags
-  __shared__ int s_widx[32][LBS_NW_MAX];
-  __shared__ float s_wval[32][LBS_NW_MAX];
-  __shared__ float s_vt[3][32];
-  __shared__ int s_slot[32];
-  __shared__ int s_flag[32];
-  for (int idx = threadIdx.x; idx < 32 * p.NW; idx += 256) {
-    const int row = idx / p.NW, k = idx % p.NW;
-    s_widx[row][k] = p.widx[(size_t)(vt * 32 + row) * p.NW + k];
-    s_wval[row][k] = p.wval[(size_t)(vt * 32 + row) * p.NW + k];
+  for (int item = stream; item < n_items; item += n_streams) {
+  const int vt = item / nper, bg = bg_lo + item % nper;
+  const int bt0 = bg * 8 + w4 * NB;  // first 32-body tile of this wave
+  // per-tile metadata, private to the wave (DS operations of one wave execute in order: no barrier)
+  const int j_lo = p.tj_off[vt];
+  const int JT = p.tj_off[vt + 1] - j_lo;
+  for (int idx = lane * 4; idx < JT * 32; idx += 256)
+    *reinterpret_cast<f32x4*>(&s_W[idx]) = *reinterpret_cast<const f32x4*>(&p.tj_w[(size_t)j_lo * 32 + idx]);
+  if (lane < JT) s_jl[lane] = p.tj_idx[j_lo + lane];
+  {
+    const int sl = (lane < 32) ? p.pick_slot[vt * 32 + lane] : -1;
+    const int fl = (lane < 32) ? p.vflags[vt * 32 + lane] : 0;
+    if (lane < 32) s_slot[lane] = sl;
+    const unsigned long long mp = __ballot(sl >= 0), ms = __ballot((fl & 3) == 2);
+    if (lane == 0) { s_masks[0] = (unsigned)mp; s_masks[1] = (unsigned)ms; }
   }
-  if (threadIdx.x < 96) s_vt[threadIdx.x >> 5][threadIdx.x & 31] = p.vtemp[(vt * 3 + (threadIdx.x >> 5)) * 32 + (threadIdx.x & 31)];
-  if (threadIdx.x >= 128 && threadIdx.x < 160) {
-    s_slot[threadIdx.x - 128] = p.pick_slot[vt * 32 + threadIdx.x - 128];
-    s_flag[threadIdx.x - 128] = p.vflags[vt * 32 + threadIdx.x - 128];
-  }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
 
   f32x16 acc[3][NB];
 #pragma unroll
@@ -289,35 +308,69 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
 #pragma unroll
   for (int q = 0; q < NB; ++q) fp[q] = p.feat + (size_t)min(bt0 + q, num_bt - 1) * KGROUPS * 64 + lane;
 
-  f32x4 a_cur[3], b_cur[NB];
+  // Operand bursts.  Measured on gfx950 (scripts/ubench/mfma_loads.hip): a wave that issues v_mfma_f32_32x32x2_f32
+  // while its own global loads are still in flight runs the matrix pipe at about half rate (72 vs 136 TFLOP/s
+  // chip-wide for this exact loop), whereas "load a burst, s_waitcnt vmcnt(0), then only MFMAs" keeps 98 % of the
+  // load-free rate - the exposed load latency is covered by the other wave of the SIMD, whose MFMAs are not affected
+  // by this wave's returning data.  So: no software prefetch; LBS_BURST k-groups of operands per burst.
+  constexpr int LBS_BURST = 2;
+  if (!(p.dbg & 2)) {
+    f32x4 a_st[LBS_BURST][3], b_st[LBS_BURST][NB];
+    constexpr int KMAIN = KGROUPS / LBS_BURST * LBS_BURST;
+    for (int g0 = 0; g0 < KMAIN; g0 += LBS_BURST) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) a_cur[c] = dp[c * 64];
+      for (int u = 0; u < LBS_BURST; ++u) {
 #pragma unroll
-  for (int q = 0; q < NB; ++q) b_cur[q] = fp[q][0];
-
-  for (int g = 0; g < KGROUPS; ++g) {
-    f32x4 a_nxt[3], b_nxt[NB];
-    const int gn = (g + 1 < KGROUPS) ? g + 1 : g;
+        for (int c = 0; c < 3; ++c) a_st[u][c] = dp[((g0 + u) * 3 + c) * 64];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) a_nxt[c] = dp[(gn * 3 + c) * 64];
+        for (int q = 0; q < NB; ++q) b_st[u][q] = fp[q][(g0 + u) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < NB; ++q) b_nxt[q] = fp[q][gn * 64];
+      for (int u = 0; u < LBS_BURST; ++u)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+          for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int q = 0; q < NB; ++q)
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[c][e], b_cur[q][e], acc[c][q], 0, 0, 0);
+            for (int q = 0; q < NB; ++q)
+              acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_st[u][c][e], b_st[u][q][e], acc[c][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) a_cur[c] = a_nxt[c];
+    for (int g = KMAIN; g < KGROUPS; ++g) {  // tail groups, one at a time
 #pragma unroll
-    for (int q = 0; q < NB; ++q) b_cur[q] = b_nxt[q];
+      for (int c = 0; c < 3; ++c) a_st[0][c] = dp[(g * 3 + c) * 64];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) b_st[0][q] = fp[q][g * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+            acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_st[0][c][e], b_st[0][q][e], acc[c][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
+  if (p.dbg & 1) {
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[c][q][r];
+    if (sum == 123.456f) p.pene[0] = 1;
+    continue;
+  }
   // ---- epilogue: each lane owns 16 vertices (rows) x NB bodies (col n of tiles bt0+q) ----------
-  // Organised in passes with many independent loads in flight (the first version walked the vertices one dependent
-  // global round trip after the other and spent more cycles here than in the 1488 MFMAs).
   float tr[NB][3];
   int body[NB];
   bool bvalid[NB];
@@ -330,73 +383,133 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
     tr[q][1] = p.xb[(size_t)bb * EGX_XB_DIM + 1];
     tr[q][2] = p.xb[(size_t)bb * EGX_XB_DIM + 2];
   }
-  // One pass per (body tile, vertex): all per-vertex metadata comes from LDS, the 12 transform rows of a vertex are
-  // fetched together, and the only dependent global access left is the SDF bracket lookup.
-  float* lds = reinterpret_cast<float*>(smem_raw) + wave * (32 * 97);
+  // Skinning walks the tile's joint list: one transform fetch per (joint, body) - prefetched one joint ahead - applied
+  // to the lane's 16 vertices with their weights from LDS (o = sum_j w_j (A_j v + t_j); rows whose weights are all zero
+  // are skipped in groups of four).  The accumulators already hold v_template + offsets (template column of the GEMM).
+  int qn = 0;  // queued undecided SDF points (wave-uniform)
+  auto sdf_flush = [&](int count) {
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < count; base += 64) {
+      const int idx = base + lane;
+      if (idx < count) {
+        const f32x4 e = s_queue[idx];
+        if (egx_sdf_neg_trilinear(p.sdf, e[0], e[1], e[2]) < 0.f) atomicAdd(p.pene + __float_as_int(e[3]), 1);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  const unsigned pick_mask = p.picked ? s_masks[0] : 0u;
+  const unsigned sdf_mask = s_masks[1];
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
     const f32x4* Aq = p.A4 + (size_t)min(bt0 + q, num_bt - 1) * NJ * 3 * 32 + n;
-    float Rw[9], Tw[3];
+    // rows are handled in adjacent pairs (r, r+1): the accumulator registers, weights and outputs of a pair are
+    // neighbours, so the nine transform FMAs and three weight FMAs map onto packed fp32 instructions
+    f32x2 o2[8][3];
+#pragma unroll
+    for (int r2 = 0; r2 < 8; ++r2) { o2[r2][0] = f32x2{0.f, 0.f}; o2[r2][1] = f32x2{0.f, 0.f}; o2[r2][2] = f32x2{0.f, 0.f}; }
+    f32x4 a0, a1, a2;
+    {
+      const int j = s_jl[0];
+      a0 = Aq[(j * 3 + 0) * 32]; a1 = Aq[(j * 3 + 1) * 32]; a2 = Aq[(j * 3 + 2) * 32];
+    }
+    for (int jj = 0; jj < JT; ++jj) {
+      const int jn = s_jl[min(jj + 1, JT - 1)];
+      const f32x4 n0 = Aq[(jn * 3 + 0) * 32], n1 = Aq[(jn * 3 + 1) * 32], n2 = Aq[(jn * 3 + 2) * 32];
+      f32x4 wq[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) wq[rg] = *reinterpret_cast<const f32x4*>(&s_W[jj * 32 + 8 * rg + 4 * half]);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 w4 = wq[rg];
+        if (__builtin_amdgcn_ballot_w64((w4[0] != 0.f) | (w4[1] != 0.f) | (w4[2] != 0.f) | (w4[3] != 0.f)) == 0) continue;
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          const int r = rg * 4 + e2 * 2;
+          const f32x2 vx = {acc[0][q][r], acc[0][q][r + 1]}, vy = {acc[1][q][r], acc[1][q][r + 1]},
+                      vz = {acc[2][q][r], acc[2][q][r + 1]};
+          const f32x2 w2 = {w4[e2 * 2], w4[e2 * 2 + 1]};
+          const f32x2 px = pk_fma(a0[0], vx, pk_fma(a0[1], vy, pk_fma(a0[2], vz, f32x2{a0[3], a0[3]})));
+          const f32x2 py = pk_fma(a1[0], vx, pk_fma(a1[1], vy, pk_fma(a1[2], vz, f32x2{a1[3], a1[3]})));
+          const f32x2 pz = pk_fma(a2[0], vx, pk_fma(a2[1], vy, pk_fma(a2[2], vz, f32x2{a2[3], a2[3]})));
+          o2[r >> 1][0] = __builtin_elementwise_fma(w2, px, o2[r >> 1][0]);
+          o2[r >> 1][1] = __builtin_elementwise_fma(w2, py, o2[r >> 1][1]);
+          o2[r >> 1][2] = __builtin_elementwise_fma(w2, pz, o2[r >> 1][2]);
+        }
+      }
+      a0 = n0; a1 = n1; a2 = n2;
+    }
+    float o[16][3];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[r][0] = o2[r >> 1][0][r & 1] + tr[q][0];
+      o[r][1] = o2[r >> 1][1][r & 1] + tr[q][1];
+      o[r][2] = o2[r >> 1][2][r & 1] + tr[q][2];
+    }
     if (DO_SDF) {
+      // Bracket table first (eight independent 8-byte loads per batch).  A vertex the brackets cannot decide needs the
+      // eight-corner interpolation; executed in place that would run for the whole wave whenever ONE lane needs it, and
+      // with 64 different bodies across the lanes that is almost every row.  Undecided points are therefore appended
+      // to a wave-private LDS queue and evaluated densely (64 queued points per pass) by sdf_flush().
       const int ag = (bvalid[q] ? body[q] : p.B - 1) / p.fpa;
+      float Rw[9], Tw[3];
 #pragma unroll
       for (int e = 0; e < 9; ++e) Rw[e] = p.R0 ? p.R0[(size_t)ag * 9 + e] : ((e % 4 == 0) ? 1.f : 0.f);
 #pragma unroll
       for (int e = 0; e < 3; ++e) Tw[e] = p.T0 ? p.T0[(size_t)ag * 3 + e] : 0.f;
+      const unsigned mine = bvalid[q] ? (sdf_mask >> (4 * half)) : 0u;  // bit (r&3)+8(r>>2) = this lane's row r
+      int cnt = 0;
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 8) {
+        float wp[8][3];
+        float2 mm[8];
+        if (qn + 512 > LBS_QCAP) { sdf_flush(qn); qn = 0; }  // room for one batch: 8 rows x 64 lanes
+#pragma unroll
+        for (int r = r0; r < r0 + 8; ++r) {
+          wp[r - r0][0] = Rw[0] * o[r][0] + Rw[1] * o[r][1] + Rw[2] * o[r][2] + Tw[0];
+          wp[r - r0][1] = Rw[3] * o[r][0] + Rw[4] * o[r][1] + Rw[5] * o[r][2] + Tw[1];
+          wp[r - r0][2] = Rw[6] * o[r][0] + Rw[7] * o[r][1] + Rw[8] * o[r][2] + Tw[2];
+          mm[r - r0] = (p.dbg & 32) ? float2{wp[r - r0][0], wp[r - r0][1]}
+                                    : egx_sdf_coarse_fetch(p.sdf, wp[r - r0][0], wp[r - r0][1], wp[r - r0][2]);
+        }
+#pragma unroll
+        for (int r = r0; r < r0 + 8; ++r) {
+          const bool on = (mine >> ((r & 3) + 8 * (r >> 2))) & 1u;
+          const bool inside = mm[r - r0].x > 0.f;
+          cnt += (on && inside) ? 1 : 0;
+          const bool und = on && !inside && !(mm[r - r0].y < 0.f) && !(p.dbg & 16);
+          const unsigned long long bm = __ballot(und);
+          if (bm != 0) {
+            const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+            if (und) s_queue[pos] = f32x4{wp[r - r0][0], wp[r - r0][1], wp[r - r0][2], __int_as_float(body[q])};
+            qn += __popcll(bm);
+          }
+        }
+      }
+      {
+        const int c2 = cnt + __shfl_xor(cnt, 32);
+        if (half == 0 && c2 != 0) atomicAdd(p.pene + body[q], c2);
+      }
+      if (WRITE_VERTS) { sdf_flush(qn); qn = 0; }  // the queue shares its LDS with the vertex transpose buffer
     }
-    int cnt = 0;
+    if (pick_mask != 0 && bvalid[q]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
-      for (int k0 = 0; k0 < p.NW; k0 += 4) {  // NW is padded to a multiple of 4 at load time (zero weights)
-        f32x4 ld[4][3];
-        float wv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {  // 12 independent 16-byte loads in flight
-          const int jn = s_widx[row][k0 + k];
-          wv[k] = s_wval[row][k0 + k];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) ld[k][c] = Aq[(jn * 3 + c) * 32];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          t0 += wv[k] * ld[k][0];
-          t1 += wv[k] * ld[k][1];
-          t2 += wv[k] * ld[k][2];
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if ((pick_mask >> row) & 1u) {
+          float* op = p.picked + ((size_t)body[q] * p.NP + s_slot[row]) * 3;
+          op[0] = o[r][0]; op[1] = o[r][1]; op[2] = o[r][2];
         }
       }
-      const float vx = acc[0][q][r] + s_vt[0][row], vy = acc[1][q][r] + s_vt[1][row], vz = acc[2][q][r] + s_vt[2][row];
-      const float ox = t0[0] * vx + t0[1] * vy + t0[2] * vz + t0[3] + tr[q][0];
-      const float oy = t1[0] * vx + t1[1] * vy + t1[2] * vz + t1[3] + tr[q][1];
-      const float oz = t2[0] * vx + t2[1] * vy + t2[2] * vz + t2[3] + tr[q][2];
-      if (DO_SDF) {
-        if ((s_flag[row] & 3) == 2) {  // valid, not a feet vertex
-          const float wx = Rw[0] * ox + Rw[1] * oy + Rw[2] * oz + Tw[0];
-          const float wy = Rw[3] * ox + Rw[4] * oy + Rw[5] * oz + Tw[1];
-          const float wz = Rw[6] * ox + Rw[7] * oy + Rw[8] * oz + Tw[2];
-          int sg = p.sdf.coarse ? egx_sdf_coarse_sign(p.sdf, wx, wy, wz) : 0;
-          if (sg == 0) sg = (egx_sdf_neg_trilinear(p.sdf, wx, wy, wz) < 0.f) ? 1 : -1;
-          cnt += (sg > 0) ? 1 : 0;
-        }
-      }
-      if (p.picked) {
-        const int slot = s_slot[row];
-        if (slot >= 0 && bvalid[q]) {
-          float* o = p.picked + ((size_t)body[q] * p.NP + slot) * 3;
-          o[0] = ox; o[1] = oy; o[2] = oz;
-        }
-      }
-      if (WRITE_VERTS) {
-        lds[n * 97 + row * 3 + 0] = ox;
-        lds[n * 97 + row * 3 + 1] = oy;
-        lds[n * 97 + row * 3 + 2] = oz;
-      }
-      asm volatile("" ::: "memory");
     }
-    if (DO_SDF) {
-      const int c2 = cnt + __shfl_xor(cnt, 32);
-      if (half == 0 && bvalid[q] && c2 != 0) atomicAdd(p.pene + body[q], c2);
+    if (WRITE_VERTS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        lds[n * 97 + row * 3 + 0] = o[r][0];
+        lds[n * 97 + row * 3 + 1] = o[r][1];
+        lds[n * 97 + row * 3 + 2] = o[r][2];
+      }
     }
     if (WRITE_VERTS) {
       // transpose through LDS: every body row is 32 vertices x 3 = 96 contiguous floats in HBM
@@ -411,6 +524,8 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused_kernel(LbsParams p) {
       }
     }
   }
+  if (DO_SDF && !WRITE_VERTS) { sdf_flush(qn); qn = 0; }
+  }  // work items
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -486,36 +601,44 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
                 const int jc = (k - 10) / 9, e9 = (k - 10) % 9;
                 const int j = jc + 1 + (jc >= 21 ? 3 : 0);        // inverse of egx_compact_joint
                 val[e] = d->posedirs_host[(size_t)((j - 1) * 9 + e9) * 3 * V + (size_t)v * 3 + c];
+              } else if (k == KACT) {
+                val[e] = d->v_template_host[(size_t)v * 3 + c];  // multiplied by the constant-1 feature
               }
             }
           dirs[(((size_t)vt * KGROUPS + g) * 3 + c) * 64 + l] = val;
         }
-  std::vector<float> vtemp((size_t)NVT * 3 * 32, 0.f);
-  for (int v = 0; v < V; ++v)
-    for (int c = 0; c < 3; ++c) vtemp[((size_t)(v / 32) * 3 + c) * 32 + (v % 32)] = d->v_template_host[(size_t)v * 3 + c];
 
-  // skinning weights -> ELL
+  // skinning weights -> per-tile joint lists: the joints any of the tile's 32 vertices is bound to, with the dense
+  // [32] weight column of each.  The epilogue walks this list once per body tile (one transform fetch per joint
+  // instead of one per vertex and weight).
   int NW = 1;
   for (int v = 0; v < V; ++v) {
     int c = 0;
     for (int j = 0; j < NJ; ++j) c += d->lbs_weights_host[(size_t)v * NJ + j] != 0.f;
     NW = std::max(NW, c);
   }
-  NW = (NW + 3) / 4 * 4;  // zero-weight padding: the skinning loop works in groups of 4
-  if (NW > LBS_NW_MAX) {
-    delete m;
-    egx_set_error("more than 16 non-zero skinning weights on one vertex are not supported");
-    return EGX_ERR_ARG;
-  }
   m->NW = NW;
-  std::vector<int> widx((size_t)VP * NW, 0);
-  std::vector<float> wval((size_t)VP * NW, 0.f);
-  for (int v = 0; v < V; ++v) {
-    int c = 0;
+  std::vector<int> tj_off(NVT + 1, 0), tj_idx;
+  std::vector<float> tj_w;
+  for (int vt = 0; vt < NVT; ++vt) {
     for (int j = 0; j < NJ; ++j) {
-      const float w = d->lbs_weights_host[(size_t)v * NJ + j];
-      if (w != 0.f) { widx[(size_t)v * NW + c] = j; wval[(size_t)v * NW + c] = w; ++c; }
+      float col[32];
+      bool any = false;
+      for (int r = 0; r < 32; ++r) {
+        const int v = vt * 32 + r;
+        col[r] = (v < V) ? d->lbs_weights_host[(size_t)v * NJ + j] : 0.f;
+        any |= col[r] != 0.f;
+      }
+      if (any) {
+        tj_idx.push_back(j);
+        tj_w.insert(tj_w.end(), col, col + 32);
+      }
     }
+    if ((int)tj_idx.size() == tj_off[vt]) {  // a tile without any weight still needs one (zero) entry
+      tj_idx.push_back(0);
+      tj_w.insert(tj_w.end(), 32, 0.f);
+    }
+    tj_off[vt + 1] = (int)tj_idx.size();
   }
 
   // picked vertices (markers, vertex joints, landmark corners)
@@ -573,8 +696,8 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
   std::memcpy(pc.hand_mean + 45, d->hand_mean_r_host, 45 * sizeof(float));
 
   int rc = EGX_OK;
-  if ((rc = upload(&m->dirs, dirs)) || (rc = upload(&m->vtemp, vtemp)) || (rc = upload(&m->widx, widx)) ||
-      (rc = upload(&m->wval, wval)) || (rc = upload(&m->pick_slot, pick_slot)) || (rc = upload(&m->vflags, vflags)) ||
+  if ((rc = upload(&m->dirs, dirs)) || (rc = upload(&m->tj_off, tj_off)) || (rc = upload(&m->tj_idx, tj_idx)) ||
+      (rc = upload(&m->tj_w, tj_w)) || (rc = upload(&m->pick_slot, pick_slot)) || (rc = upload(&m->vflags, vflags)) ||
       (rc = upload(&m->pc, pcv)) || (rc = upload(&m->marker_slot, marker_slot)) || (rc = upload(&m->extra_slot, extra_slot)) ||
       (rc = upload(&m->lmk_slot, lmk_slot)) || (rc = upload(&m->lmk_bary, lmk_bary))) {
     egx_body_model_destroy(m);
@@ -586,7 +709,7 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
 
 extern "C" void egx_body_model_destroy(egx_body_model* m) {
   if (!m) return;
-  (void)hipFree(m->dirs); (void)hipFree(m->vtemp); (void)hipFree(m->widx); (void)hipFree(m->wval);
+  (void)hipFree(m->dirs); (void)hipFree(m->tj_off); (void)hipFree(m->tj_idx); (void)hipFree(m->tj_w);
   (void)hipFree(m->pick_slot); (void)hipFree(m->vflags); (void)hipFree(m->pc); (void)hipFree(m->marker_slot);
   (void)hipFree(m->extra_slot); (void)hipFree(m->lmk_slot); (void)hipFree(m->lmk_bary);
   delete m;
@@ -622,6 +745,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   EGX_REQUIRE(m && xb && betas, "null model/xb/betas");
   EGX_REQUIRE(B > 0 && fpa > 0, "num_bodies and frames_per_agent must be positive");
   EGX_REQUIRE(!sdf || (sdf->grid && out_pene_count && sdf->d0 > 0 && sdf->d1 > 0 && sdf->d2 > 0), "sdf needs grid + out_pene_count");
+  EGX_REQUIRE(!sdf || sdf->coarse_minmax, "sdf needs its bracket table: call egx_sdf_build_coarse once per grid");
   const WsLayout wl = ws_layout(m, B);
   if (!workspace || workspace_bytes < wl.total) {
     egx_set_error("workspace too small: need " + std::to_string(wl.total) + " bytes");
@@ -638,23 +762,13 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
                      feat, A4, out_joints);
   if (out_verts || need_picks || sdf) {
     LbsParams p;
-    p.dirs = m->dirs; p.vtemp = m->vtemp; p.widx = m->widx; p.wval = m->wval; p.pick_slot = m->pick_slot;
+    p.dirs = m->dirs; p.tj_off = m->tj_off; p.tj_idx = m->tj_idx; p.tj_w = m->tj_w; p.pick_slot = m->pick_slot;
     p.vflags = m->vflags; p.feat = reinterpret_cast<const f32x4*>(feat); p.A4 = A4; p.xb = xb;
     p.B = B; p.V = m->V; p.NVT = m->NVT; p.NW = m->NW; p.NP = m->NP; p.fpa = fpa;
     p.nbg = egx_ceil_div(B, BODY_PAD);
     {
-      static int num_cu = 0;
-      static long long stagger = -1;
-      if (num_cu == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        EGX_HIP_CHECK(hipGetDevice(&dev));
-        EGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        num_cu = prop.multiProcessorCount;
-        const char* e = getenv("EGX_LBS_STAGGER_CYCLES");
-        stagger = e ? atoll(e) : 40000;  // ~ half of one tile's MFMA loop (in s_memtime / 100 MHz-or-core ticks: see DESIGN.md)
-      }
-      p.stagger_lo = num_cu; p.stagger_hi = 2 * num_cu; p.stagger_cycles = stagger;
+      const char* e = getenv("EGX_LBS_DBG");
+      p.dbg = e ? atoi(e) : 0;
     }
     p.verts = out_verts; p.picked = picked; p.R0 = R0; p.T0 = T0; p.pene = out_pene_count;
     std::memset(&p.sdf, 0, sizeof(p.sdf));
@@ -665,20 +779,47 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
       p.sdf.c0 = egx_ceil_div(sdf->d0, 4); p.sdf.c1 = egx_ceil_div(sdf->d1, 4); p.sdf.c2 = egx_ceil_div(sdf->d2, 4);
       EGX_HIP_CHECK(hipMemsetAsync(out_pene_count, 0, (size_t)B * sizeof(int32_t), stream));
     }
-    const int per = (p.nbg + 7) / 8;
-    const int grid = (p.nbg >= 8) ? 8 * per * m->NVT : p.nbg * m->NVT;
-    const size_t lds = out_verts ? 4 * 32 * 97 * sizeof(float) : 0;
+    // one persistent workgroup per CU (8 waves = 2 per SIMD); the attribute raises the dynamic-LDS cap once
+    static int num_cu = 0;
+    static long long phase_delay = 0;
+    constexpr size_t lds_meta = (size_t)8 * LBS_META_BYTES, lds_verts = (size_t)8 * (LBS_META_BYTES + LBS_VERT_BYTES),
+                     lds_sdf = (size_t)8 * (LBS_META_BYTES + LBS_QCAP * 16);
+    if (num_cu == 0) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      EGX_HIP_CHECK(hipGetDevice(&dev));
+      EGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_verts));
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<true, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_verts));
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sdf));
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<false, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_meta));
+      const char* e = getenv("EGX_LBS_PHASE_DELAY");
+      phase_delay = e ? atoll(e) : (long long)KSTEPS * 3 * 2 * 64 / 2;  // half of one wave's MFMA issue time
+      num_cu = prop.multiProcessorCount;
+    }
+    p.phase_delay = phase_delay;
+    {
+      const char* e = getenv("EGX_LBS_SET_MODE");
+      p.set_mode = e ? atoi(e) : 0;
+    }
+    const int n_items = p.nbg * m->NVT;
+    const int grid = std::max(1, std::min(num_cu, (n_items + 1) / 2));
+    const size_t lds = out_verts ? lds_verts : (sdf ? lds_sdf : lds_meta);
     hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) EGX_HIP_CHECK(hipEventRecord(ev0, stream));
     if (out_verts && sdf)
-      hipLaunchKernelGGL((egx_lbs_fused_kernel<true, true>), dim3(grid), dim3(256), lds, stream, p);
+      hipLaunchKernelGGL((egx_lbs_fused_kernel<true, true>), dim3(grid), dim3(LBS_THREADS), lds, stream, p);
     else if (out_verts)
-      hipLaunchKernelGGL((egx_lbs_fused_kernel<true, false>), dim3(grid), dim3(256), lds, stream, p);
+      hipLaunchKernelGGL((egx_lbs_fused_kernel<true, false>), dim3(grid), dim3(LBS_THREADS), lds, stream, p);
     else if (sdf)
-      hipLaunchKernelGGL((egx_lbs_fused_kernel<false, true>), dim3(grid), dim3(256), lds, stream, p);
+      hipLaunchKernelGGL((egx_lbs_fused_kernel<false, true>), dim3(grid), dim3(LBS_THREADS), lds, stream, p);
     else
-      hipLaunchKernelGGL((egx_lbs_fused_kernel<false, false>), dim3(grid), dim3(256), lds, stream, p);
+      hipLaunchKernelGGL((egx_lbs_fused_kernel<false, false>), dim3(grid), dim3(LBS_THREADS), lds, stream, p);
     if (ev1) EGX_HIP_CHECK(hipEventRecord(ev1, stream));
   }
   if (need_picks)

@@ -52,8 +52,11 @@ __device__ __forceinline__ float2 egx_sdf_coarse_fetch(const SdfDev& s, float x,
   px = fminf(fmaxf(px, 0.f), (float)(s.d0 - 1));
   py = fminf(fmaxf(py, 0.f), (float)(s.d1 - 1));
   pz = fminf(fmaxf(pz, 0.f), (float)(s.d2 - 1));
-  const int ix = (int)floorf(px) >> 2, iy = (int)floorf(py) >> 2, iz = (int)floorf(pz) >> 2;
-  return s.coarse[((size_t)ix * s.c1 + iy) * s.c2 + iz];
+  // clamped to [0, d-1]: truncation is floor; 32-bit index (the table has at most 2^31 / 8 entries) keeps the address
+  // arithmetic off the quarter-rate 64-bit VALU paths
+  const unsigned ix = (unsigned)px >> 2, iy = (unsigned)py >> 2, iz = (unsigned)pz >> 2;
+  const unsigned idx = (ix * (unsigned)s.c1 + iy) * (unsigned)s.c2 + iz;
+  return s.coarse[idx];
 }
 
 // Sign of calc_sdf at a point without touching the fine grid when the coarse {min,max} brackets decide it:

@@ -76,7 +76,7 @@ typedef struct egx_sdf_grid {
   int d0, d1, d2;
   float center[3];
   float scale;
-  const void* coarse_minmax; /* optional device table from egx_sdf_build_coarse (NULL = always sample the fine grid) */
+  const void* coarse_minmax; /* device table from egx_sdf_build_coarse: required by egx_lbs_forward, optional (NULL = fine grid only) elsewhere */
 } egx_sdf_grid;
 
 /* Acceleration table for the penetration COUNT of egx_lbs_forward: {min,max} of the fine samples each 4x4x4 block's
