@@ -134,6 +134,9 @@ SIGNATURES = {
     "egx_ppo_loss": (C.c_int, [C.c_void_p] * 9 + [C.c_float] * 6 + [C.c_int] + [C.c_void_p] * 5),
     "egx_gru_pointwise_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
+    "egx_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "egx_act_bwd_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     C.c_void_p]),
     "egx_profile_next_lbs": (C.c_int, [C.c_void_p, C.c_void_p]),
     "egx_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "egx_event_destroy": (C.c_int, [C.c_void_p]),

@@ -235,7 +235,7 @@ __device__ __forceinline__ f32x2 pk_fma(float a, f32x2 b, f32x2 c) { return __bu
 // half an MFMA phase late, so one wave of every SIMD is in its epilogue (skinning, SDF, picks: VALU + dependent loads,
 // matrix pipe untouched) while the other runs its MFMA loop.  Equal per-item work keeps the two sets in anti-phase for
 // the whole launch; nothing synchronises across waves (per-wave LDS metadata, no barriers).
-constexpr int LBS_META_BYTES = 7424;                 // s_W[55*32] f32, s_jl[56], s_slot[32], masks[4] (16-byte multiple)
+constexpr int LBS_META_BYTES = 7680;                 // s_W[55*32] f32, s_jl[56], s_slot[32], masks[4], s_cnt[64] (16-byte multiple)
 constexpr int LBS_VERT_BYTES = 32 * 97 * 4;          // per-wave transpose buffer of the vertex-writing variants
 constexpr int LBS_QCAP = 640;                        // entries of the per-wave queue of undecided SDF points (>= 512 + 64)
 constexpr int LBS_THREADS = 512;
@@ -254,8 +254,9 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
   int* s_jl = reinterpret_cast<int*>(my + NJ * 32 * 4);             // [jj]
   int* s_slot = s_jl + 56;                                          // [row]
   unsigned* s_masks = reinterpret_cast<unsigned*>(s_slot + 32);     // [0] rows with a pick slot, [1] rows in the SDF count
+  int* s_cnt = reinterpret_cast<int*>(s_masks + 4);                 // [q*32 + n] penetration count of this item's 64 bodies
   float* lds = reinterpret_cast<float*>(my + LBS_META_BYTES);
-  f32x4* s_queue = reinterpret_cast<f32x4*>(my + LBS_META_BYTES);   // undecided SDF points (x, y, z, body)
+  f32x4* s_queue = reinterpret_cast<f32x4*>(my + LBS_META_BYTES);   // undecided SDF points (voxel x, y, z, body)
   // work streams.  With >= 8 body groups every XCD (block id % 8) owns a contiguous chunk of body groups, so their packed
   // features / transforms stay in that XCD's L2 while the blend bases stream through once per XCD; the streams of an XCD
   // walk its (vertex tile, body group) list vertex-tile-major, i.e. at any time they share a dozen consecutive tiles.
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
   }
   const int n_items = p.NVT * nper;
   const int num_bt = (p.B + 31) >> 5;
+  s_cnt[lane] = 0;
   if (set == 1 && p.phase_delay > 0 && stream < n_items) {
     const long long t0 = __builtin_readcyclecounter();
     while (__builtin_readcyclecounter() - t0 < p.phase_delay) __builtin_amdgcn_s_sleep(16);
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
       const int idx = base + lane;
       if (idx < count) {
         const f32x4 e = s_queue[idx];
-        if (egx_sdf_neg_trilinear(p.sdf, e[0], e[1], e[2]) < 0.f) atomicAdd(p.pene + __float_as_int(e[3]), 1);
+        if (egx_sdf_neg_trilinear_at(p.sdf, e[0], e[1], e[2]) < 0.f) atomicAdd(&s_cnt[__float_as_int(e[3])], 1);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -466,11 +468,11 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
         if (qn + 512 > LBS_QCAP) { sdf_flush(qn); qn = 0; }  // room for one batch: 8 rows x 64 lanes
 #pragma unroll
         for (int r = r0; r < r0 + 8; ++r) {
-          wp[r - r0][0] = Rw[0] * o[r][0] + Rw[1] * o[r][1] + Rw[2] * o[r][2] + Tw[0];
-          wp[r - r0][1] = Rw[3] * o[r][0] + Rw[4] * o[r][1] + Rw[5] * o[r][2] + Tw[1];
-          wp[r - r0][2] = Rw[6] * o[r][0] + Rw[7] * o[r][1] + Rw[8] * o[r][2] + Tw[2];
-          mm[r - r0] = (p.dbg & 32) ? float2{wp[r - r0][0], wp[r - r0][1]}
-                                    : egx_sdf_coarse_fetch(p.sdf, wp[r - r0][0], wp[r - r0][1], wp[r - r0][2]);
+          const float wx = Rw[0] * o[r][0] + Rw[1] * o[r][1] + Rw[2] * o[r][2] + Tw[0];
+          const float wy = Rw[3] * o[r][0] + Rw[4] * o[r][1] + Rw[5] * o[r][2] + Tw[1];
+          const float wz = Rw[6] * o[r][0] + Rw[7] * o[r][1] + Rw[8] * o[r][2] + Tw[2];
+          egx_sdf_voxel_coords(p.sdf, wx, wy, wz, wp[r - r0][0], wp[r - r0][1], wp[r - r0][2]);  // clamped voxel coordinates
+          mm[r - r0] = (p.dbg & 32) ? float2{wx, wy} : egx_sdf_coarse_at(p.sdf, wp[r - r0][0], wp[r - r0][1], wp[r - r0][2]);
         }
 #pragma unroll
         for (int r = r0; r < r0 + 8; ++r) {
@@ -481,15 +483,12 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
           const unsigned long long bm = __ballot(und);
           if (bm != 0) {
             const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
-            if (und) s_queue[pos] = f32x4{wp[r - r0][0], wp[r - r0][1], wp[r - r0][2], __int_as_float(body[q])};
+            if (und) s_queue[pos] = f32x4{wp[r - r0][0], wp[r - r0][1], wp[r - r0][2], __int_as_float(q * 32 + n)};
             qn += __popcll(bm);
           }
         }
       }
-      {
-        const int c2 = cnt + __shfl_xor(cnt, 32);
-        if (half == 0 && c2 != 0) atomicAdd(p.pene + body[q], c2);
-      }
+      if (cnt != 0) atomicAdd(&s_cnt[q * 32 + n], cnt);
       if (WRITE_VERTS) { sdf_flush(qn); qn = 0; }  // the queue shares its LDS with the vertex transpose buffer
     }
     if (pick_mask != 0 && bvalid[q]) {
@@ -524,7 +523,15 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
       }
     }
   }
-  if (DO_SDF && !WRITE_VERTS) { sdf_flush(qn); qn = 0; }
+  if (DO_SDF) {
+    if (!WRITE_VERTS) { sdf_flush(qn); qn = 0; }
+    __builtin_amdgcn_wave_barrier();
+    const int c = s_cnt[lane];            // lane = q*32 + n: one global atomic per body and item
+    s_cnt[lane] = 0;
+    const int bd = (bt0 + (lane >> 5)) * 32 + (lane & 31);
+    if (c != 0 && bd < p.B) atomicAdd(p.pene + bd, c);
+    __builtin_amdgcn_wave_barrier();
+  }
   }  // work items
 }
 
@@ -746,6 +753,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   EGX_REQUIRE(B > 0 && fpa > 0, "num_bodies and frames_per_agent must be positive");
   EGX_REQUIRE(!sdf || (sdf->grid && out_pene_count && sdf->d0 > 0 && sdf->d1 > 0 && sdf->d2 > 0), "sdf needs grid + out_pene_count");
   EGX_REQUIRE(!sdf || sdf->coarse_minmax, "sdf needs its bracket table: call egx_sdf_build_coarse once per grid");
+  EGX_REQUIRE(!sdf || egx_sdf_dims_ok(sdf->d0, sdf->d1, sdf->d2), "sdf grid needs d2 >= 2 and fewer than 2^32 samples");
   const WsLayout wl = ws_layout(m, B);
   if (!workspace || workspace_bytes < wl.total) {
     egx_set_error("workspace too small: need " + std::to_string(wl.total) + " bytes");

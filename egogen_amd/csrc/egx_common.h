@@ -43,20 +43,74 @@ struct SdfDev {
   int c0, c1, c2;
 };
 
-__device__ __forceinline__ float2 egx_sdf_coarse_fetch(const SdfDev& s, float x, float y, float z) {
+inline bool egx_sdf_dims_ok(int d0, int d1, int d2) {
+  return d2 >= 2 && (unsigned long long)d0 * (unsigned long long)d1 * (unsigned long long)d2 < (1ull << 32);
+}
+
+// Continuous voxel coordinates of a world point, clamped to the grid (align_corners=False, padding "border").
+// explicit _rn intrinsics: immune to fma contraction, so the coordinates round exactly like the CPU path
+__device__ __forceinline__ void egx_sdf_voxel_coords(const SdfDev& s, float x, float y, float z, float& px, float& py, float& pz) {
   const float nx = __fmul_rn(__fsub_rn(x, s.cx), s.scale), ny = __fmul_rn(__fsub_rn(y, s.cy), s.scale),
               nz = __fmul_rn(__fsub_rn(z, s.cz), s.scale);
-  float px = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.f), (float)s.d0), 1.f), 0.5f);
-  float py = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.f), (float)s.d1), 1.f), 0.5f);
-  float pz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nz, 1.f), (float)s.d2), 1.f), 0.5f);
+  px = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.f), (float)s.d0), 1.f), 0.5f);
+  py = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.f), (float)s.d1), 1.f), 0.5f);
+  pz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nz, 1.f), (float)s.d2), 1.f), 0.5f);
   px = fminf(fmaxf(px, 0.f), (float)(s.d0 - 1));
   py = fminf(fmaxf(py, 0.f), (float)(s.d1 - 1));
   pz = fminf(fmaxf(pz, 0.f), (float)(s.d2 - 1));
-  // clamped to [0, d-1]: truncation is floor; 32-bit index (the table has at most 2^31 / 8 entries) keeps the address
-  // arithmetic off the quarter-rate 64-bit VALU paths
+}
+
+// {min,max} bracket of the 4^3 block that holds clamped voxel coordinates (px,py,pz) (see egx_sdf_coarse_sign)
+__device__ __forceinline__ float2 egx_sdf_coarse_at(const SdfDev& s, float px, float py, float pz) {
+  // clamped to [0, d-1]: truncation is floor; 32-bit index keeps the address arithmetic off the 64-bit VALU paths
   const unsigned ix = (unsigned)px >> 2, iy = (unsigned)py >> 2, iz = (unsigned)pz >> 2;
   const unsigned idx = (ix * (unsigned)s.c1 + iy) * (unsigned)s.c2 + iz;
   return s.coarse[idx];
+}
+
+struct __attribute__((packed, aligned(4))) EgxF2 { float x, y; };  // two z-neighbours, 4-byte aligned
+
+// -trilinear(grid) at clamped voxel coordinates: aten grid_sampler_3d corner order and rounding.  The two z-neighbours
+// of each (x,y) corner column are one 8-byte load; corners that fall off the grid have weight exactly 0 (aten drops
+// them) and a clamped index.  Requires d2 >= 2 and d0*d1*d2 < 2^32.
+__device__ __forceinline__ float egx_sdf_neg_trilinear_at(const SdfDev& s, float px, float py, float pz) {
+  const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+  const float wx1 = __fsub_rn(px, x0), wy1 = __fsub_rn(py, y0), wz1 = __fsub_rn(pz, z0);
+  const float wx0 = __fsub_rn(__fadd_rn(x0, 1.f), px), wy0 = __fsub_rn(__fadd_rn(y0, 1.f), py), wz0 = __fsub_rn(__fadd_rn(z0, 1.f), pz);
+  const unsigned ix0 = (unsigned)x0, iy0 = (unsigned)y0, iz0 = (unsigned)z0;
+  const bool x1_in = ix0 + 1 < (unsigned)s.d0, y1_in = iy0 + 1 < (unsigned)s.d1, z1_in = iz0 + 1 < (unsigned)s.d2;
+  const unsigned zb = z1_in ? iz0 : iz0 - 1;                      // pair (zb, zb+1) always inside the row
+  const unsigned i00 = (ix0 * (unsigned)s.d1 + iy0) * (unsigned)s.d2 + zb;
+  const unsigned sy = y1_in ? (unsigned)s.d2 : 0u, sx = x1_in ? (unsigned)s.d1 * (unsigned)s.d2 : 0u;
+  const EgxF2* g = reinterpret_cast<const EgxF2*>(s.grid);
+  const EgxF2 c00 = *reinterpret_cast<const EgxF2*>(s.grid + i00), c01 = *reinterpret_cast<const EgxF2*>(s.grid + (i00 + sy)),
+              c10 = *reinterpret_cast<const EgxF2*>(s.grid + (i00 + sx)), c11 = *reinterpret_cast<const EgxF2*>(s.grid + (i00 + sx + sy));
+  (void)g;
+  const float wx1e = x1_in ? wx1 : 0.f, wy1e = y1_in ? wy1 : 0.f, wz1e = z1_in ? wz1 : 0.f;
+  const float v000 = z1_in ? c00.x : c00.y, v010 = z1_in ? c01.x : c01.y, v100 = z1_in ? c10.x : c10.y, v110 = z1_in ? c11.x : c11.y;
+  const float a00 = __fmul_rn(wx0, wy0), a01 = __fmul_rn(wx0, wy1e), a10 = __fmul_rn(wx1e, wy0), a11 = __fmul_rn(wx1e, wy1e);
+  float acc;
+  acc = __fmul_rn(v000, __fmul_rn(a00, wz0));
+  acc = __fadd_rn(acc, __fmul_rn(c00.y, __fmul_rn(a00, wz1e)));
+  acc = __fadd_rn(acc, __fmul_rn(v010, __fmul_rn(a01, wz0)));
+  acc = __fadd_rn(acc, __fmul_rn(c01.y, __fmul_rn(a01, wz1e)));
+  acc = __fadd_rn(acc, __fmul_rn(v100, __fmul_rn(a10, wz0)));
+  acc = __fadd_rn(acc, __fmul_rn(c10.y, __fmul_rn(a10, wz1e)));
+  acc = __fadd_rn(acc, __fmul_rn(v110, __fmul_rn(a11, wz0)));
+  acc = __fadd_rn(acc, __fmul_rn(c11.y, __fmul_rn(a11, wz1e)));
+  return -acc;
+}
+
+__device__ __forceinline__ float egx_sdf_neg_trilinear(const SdfDev& s, float x, float y, float z) {
+  float px, py, pz;
+  egx_sdf_voxel_coords(s, x, y, z, px, py, pz);
+  return egx_sdf_neg_trilinear_at(s, px, py, pz);
+}
+
+__device__ __forceinline__ float2 egx_sdf_coarse_fetch(const SdfDev& s, float x, float y, float z) {
+  float px, py, pz;
+  egx_sdf_voxel_coords(s, x, y, z, px, py, pz);
+  return egx_sdf_coarse_at(s, px, py, pz);
 }
 
 // Sign of calc_sdf at a point without touching the fine grid when the coarse {min,max} brackets decide it:
@@ -64,52 +118,8 @@ __device__ __forceinline__ float2 egx_sdf_coarse_fetch(const SdfDev& s, float x,
 // negative (free space) the result is negative and -result > 0: not penetrating; if all are positive: penetrating.
 // Returns -1 (not penetrating), +1 (penetrating) or 0 (mixed: evaluate the fine grid).  Exact, not an approximation.
 __device__ __forceinline__ int egx_sdf_coarse_sign(const SdfDev& s, float x, float y, float z) {
-  const float nx = __fmul_rn(__fsub_rn(x, s.cx), s.scale), ny = __fmul_rn(__fsub_rn(y, s.cy), s.scale),
-              nz = __fmul_rn(__fsub_rn(z, s.cz), s.scale);
-  float px = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.f), (float)s.d0), 1.f), 0.5f);
-  float py = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.f), (float)s.d1), 1.f), 0.5f);
-  float pz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nz, 1.f), (float)s.d2), 1.f), 0.5f);
-  px = fminf(fmaxf(px, 0.f), (float)(s.d0 - 1));
-  py = fminf(fmaxf(py, 0.f), (float)(s.d1 - 1));
-  pz = fminf(fmaxf(pz, 0.f), (float)(s.d2 - 1));
-  const int ix = (int)floorf(px) >> 2, iy = (int)floorf(py) >> 2, iz = (int)floorf(pz) >> 2;
-  const float2 mm = s.coarse[((size_t)ix * s.c1 + iy) * s.c2 + iz];
+  const float2 mm = egx_sdf_coarse_fetch(s, x, y, z);
   return (mm.y < 0.f) ? -1 : ((mm.x > 0.f) ? 1 : 0);
-}
-
-__device__ __forceinline__ float egx_sdf_neg_trilinear(const SdfDev& s, float x, float y, float z) {
-  // explicit _rn intrinsics: immune to fma contraction, so the coordinates round exactly like the CPU path
-  const float nx = __fmul_rn(__fsub_rn(x, s.cx), s.scale), ny = __fmul_rn(__fsub_rn(y, s.cy), s.scale),
-              nz = __fmul_rn(__fsub_rn(z, s.cz), s.scale);
-  float px = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.f), (float)s.d0), 1.f), 0.5f);
-  float py = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.f), (float)s.d1), 1.f), 0.5f);
-  float pz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nz, 1.f), (float)s.d2), 1.f), 0.5f);
-  px = fminf(fmaxf(px, 0.f), (float)(s.d0 - 1));
-  py = fminf(fmaxf(py, 0.f), (float)(s.d1 - 1));
-  pz = fminf(fmaxf(pz, 0.f), (float)(s.d2 - 1));
-  const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
-  const float wx1 = __fsub_rn(px, x0), wy1 = __fsub_rn(py, y0), wz1 = __fsub_rn(pz, z0);
-  const float wx0 = __fsub_rn(__fadd_rn(x0, 1.f), px), wy0 = __fsub_rn(__fadd_rn(y0, 1.f), py), wz0 = __fsub_rn(__fadd_rn(z0, 1.f), pz);
-  const int ix0 = (int)x0, iy0 = (int)y0, iz0 = (int)z0;
-  const int ix1 = min(ix0 + 1, s.d0 - 1), iy1 = min(iy0 + 1, s.d1 - 1);
-  const bool z1_in = (iz0 + 1) < s.d2;
-  const float* r00 = s.grid + ((size_t)ix0 * s.d1 + iy0) * s.d2 + iz0;
-  const float* r01 = s.grid + ((size_t)ix0 * s.d1 + iy1) * s.d2 + iz0;
-  const float* r10 = s.grid + ((size_t)ix1 * s.d1 + iy0) * s.d2 + iz0;
-  const float* r11 = s.grid + ((size_t)ix1 * s.d1 + iy1) * s.d2 + iz0;
-  const int dz = z1_in ? 1 : 0;  // weight is exactly 0 when the +1 corner falls off the grid
-  // out-of-range corners contribute 0 in aten; here their weight is exactly 0 and the index is clamped
-  const float wx1e = (ix0 + 1 < s.d0) ? wx1 : 0.f, wy1e = (iy0 + 1 < s.d1) ? wy1 : 0.f, wz1e = z1_in ? wz1 : 0.f;
-  float acc;
-  acc = __fmul_rn(r00[0], __fmul_rn(__fmul_rn(wx0, wy0), wz0));
-  acc = __fadd_rn(acc, __fmul_rn(r00[dz], __fmul_rn(__fmul_rn(wx0, wy0), wz1e)));
-  acc = __fadd_rn(acc, __fmul_rn(r01[0], __fmul_rn(__fmul_rn(wx0, wy1e), wz0)));
-  acc = __fadd_rn(acc, __fmul_rn(r01[dz], __fmul_rn(__fmul_rn(wx0, wy1e), wz1e)));
-  acc = __fadd_rn(acc, __fmul_rn(r10[0], __fmul_rn(__fmul_rn(wx1e, wy0), wz0)));
-  acc = __fadd_rn(acc, __fmul_rn(r10[dz], __fmul_rn(__fmul_rn(wx1e, wy0), wz1e)));
-  acc = __fadd_rn(acc, __fmul_rn(r11[0], __fmul_rn(__fmul_rn(wx1e, wy1e), wz0)));
-  acc = __fadd_rn(acc, __fmul_rn(r11[dz], __fmul_rn(__fmul_rn(wx1e, wy1e), wz1e)));
-  return -acc;
 }
 
 // ---- rotation helpers shared with the env kernels (torchgeometry 0.1.2 semantics) ----

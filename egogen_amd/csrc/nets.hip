@@ -128,43 +128,27 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if (b0 < b1) {
-    // two K-blocks of global loads stay in flight (registers) while the current block is multiplied out of LDS
-    f32x4 gx[2][4], gw[2][4];
+  // No software prefetch: on gfx950 a wave that issues v_mfma_f32_32x32x2_f32 while its own global loads are in flight
+  // runs the matrix pipe at about half rate (scripts/ubench/mfma_loads.hip); the load latency of one wave is covered
+  // by the other waves of the SIMD (4 workgroups per CU) instead.
+  for (int b = b0; b < b1; ++b) {
+    f32x4 gx[4], gw[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int bb = min(b0 + u, b1 - 1);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        gx[u][q] = load_x4(a, min(m0 + q * 8 + lr, a.M - 1), bb * 32 + lc);
-        gw[u][q] = load_w4(a, min(n0 + q * 8 + lr, a.N - 1), bb * 32 + lc);
-      }
+    for (int q = 0; q < 4; ++q) {
+      gx[q] = load_x4(a, min(m0 + q * 8 + lr, a.M - 1), b * 32 + lc);
+      gw[q] = load_w4(a, min(n0 + q * 8 + lr, a.N - 1), b * 32 + lc);
     }
-    for (int b = b0; b < b1; b += 2) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (b + u < b1) {
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<f32x4*>(xs + (q * 8 + lr) * 36 + lc) = gx[q];
+      *reinterpret_cast<f32x4*>(ws + (q * 8 + lr) * 36 + lc) = gw[q];
+    }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<f32x4*>(xs + (q * 8 + lr) * 36 + lc) = gx[u][q];
-            *reinterpret_cast<f32x4*>(ws + (q * 8 + lr) * 36 + lc) = gw[u][q];
-          }
-          if (b + u + 2 < b1) {
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              gx[u][q] = load_x4(a, min(m0 + q * 8 + lr, a.M - 1), (b + u + 2) * 32 + lc);
-              gw[u][q] = load_w4(a, min(n0 + q * 8 + lr, a.N - 1), (b + u + 2) * 32 + lc);
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
-            const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
-          }
-        }
-      }
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
     }
   }
   // split-K reduction through the (now idle) staging strips

@@ -97,6 +97,53 @@ __global__ void egx_gru_pointwise_bwd_kernel(const float* __restrict__ gi, const
   if (dhprev) dhprev[idx] = g * z;
 }
 
+// ---- dense-layer glue of the PPO update (the GEMMs themselves are plain library calls) -----------------------
+// forward: a = act(z) in place; out = a + res when a residual is given (a is kept for the backward pass)
+__global__ void egx_act_fwd_kernel(float* __restrict__ z, const float* __restrict__ res, float* __restrict__ out, size_t n4,
+                                   int act, float slope) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<float4*>(z)[i];
+  float* e = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float x = e[k];
+    e[k] = (act == 1) ? tanhf(x) : (act == 2) ? fmaxf(x, 0.f) : (act == 3) ? (x > 0.f ? x : x * slope) : x;
+  }
+  reinterpret_cast<float4*>(z)[i] = v;
+  if (res) {
+    const float4 r = reinterpret_cast<const float4*>(res)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+  }
+}
+
+// backward: g = dy * act'(a) (derivative expressed through the saved output a) and db[n] += sum_m g[m][n].
+// Block = 64 columns x 4 row phases; blockIdx.y splits the rows, partial column sums meet in db through atomics.
+__global__ __launch_bounds__(256) void egx_act_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+                                                                 float* __restrict__ g, float* __restrict__ db, int M, int N,
+                                                                 int rows_per_block, int act, float slope) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float s = 0.f;
+  if (n < N) {
+    for (int m = m0 + ty; m < m1; m += 4) {
+      const size_t idx = (size_t)m * N + n;
+      float v = dy[idx];
+      if (act != 0) {
+        const float y = a[idx];
+        v *= (act == 1) ? (1.f - y * y) : (act == 2) ? (y > 0.f ? 1.f : 0.f) : (y > 0.f ? 1.f : slope);
+      }
+      if (g) g[idx] = v;
+      s += v;
+    }
+  }
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N && db) atomicAdd(db + n, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+}
+
 extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* value, const float* act, const float* adv,
                             const float* ret, const float* logp_old, const float* adv_stats, const float* scale,
                             float adv_eps, float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef,
@@ -118,6 +165,31 @@ extern "C" int egx_gru_pointwise_bwd(const float* gi, const float* gh, const flo
   const int n = num_rows * hidden;
   hipLaunchKernelGGL(egx_gru_pointwise_bwd_kernel, dim3(egx_ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      gi, gh, h_prev, dh, num_rows, hidden, dgi, dgh, dh_prev);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_act_fwd(float* z, const float* res, float* out, int num_rows, int width, int act, float slope, void* stream_) {
+  EGX_REQUIRE(z && num_rows > 0 && width > 0 && (!res || out), "bad arguments");
+  EGX_REQUIRE(((size_t)num_rows * width) % 4 == 0, "rows x width must be a multiple of 4");
+  EGX_REQUIRE(act >= 0 && act <= 3, "unknown activation");
+  const size_t n4 = (size_t)num_rows * width / 4;
+  hipLaunchKernelGGL(egx_act_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), z,
+                     res, out, n4, act, slope);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_act_bwd_colsum(const float* dy, const float* a, float* g, float* db_accum, int num_rows, int width, int act,
+                                  float slope, void* stream_) {
+  EGX_REQUIRE(dy && num_rows > 0 && width > 0 && (act == 0 || a) && (g || db_accum), "bad arguments");
+  EGX_REQUIRE(act >= 0 && act <= 3, "unknown activation");
+  const int strips = egx_ceil_div(width, 64);
+  int splits = std::max(1, std::min(egx_ceil_div(num_rows, 32), 512 / strips));  // enough blocks to fill the chip
+  const int rpb = egx_ceil_div(num_rows, splits);
+  splits = egx_ceil_div(num_rows, rpb);
+  hipLaunchKernelGGL(egx_act_bwd_colsum_kernel, dim3(strips, splits), dim3(256), 0, static_cast<hipStream_t>(stream_), dy, a, g,
+                     db_accum, num_rows, width, rpb, act, slope);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

@@ -43,6 +43,7 @@ extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, v
 
 extern "C" int egx_sdf_sample(const egx_sdf_grid* sdf, const float* pts, int64_t n, float* out, void* stream_) {
   EGX_REQUIRE(sdf && sdf->grid && sdf->d0 > 0 && sdf->d1 > 0 && sdf->d2 > 0, "bad sdf grid");
+  EGX_REQUIRE(egx_sdf_dims_ok(sdf->d0, sdf->d1, sdf->d2), "sdf grid needs d2 >= 2 and fewer than 2^32 samples");
   if (n == 0) return EGX_OK;  // empty input is legal
   EGX_REQUIRE(pts && out && n > 0, "null points / output");
   SdfDev s{sdf->grid, sdf->d0, sdf->d1, sdf->d2, sdf->center[0], sdf->center[1], sdf->center[2], sdf->scale, nullptr, 0, 0, 0};

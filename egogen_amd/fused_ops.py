@@ -1,5 +1,7 @@
-"""Custom autograd nodes backed by libegogen_hip.so for the PPO update: GRU gate math (forward + backward) and the
-fused clipped-PPO loss with its gradients.  Dense-layer forward/backward stay on torch (rocBLAS) this round."""
+"""Custom autograd nodes backed by libegogen_hip.so for the PPO update: GRU gate math (forward + backward), the
+fused clipped-PPO loss with its gradients, and the dense layer `LinearFn` whose matrix products are library GEMMs
+(hipBLASLt through torch.addmm / mm) while activation, residual, activation gradient, bias gradient and the
+accumulation of weight gradients into the flat gradient buffer are fused (no per-parameter AccumulateGrad kernels)."""
 from __future__ import annotations
 
 import torch
@@ -69,3 +71,57 @@ def posenc_dist_time(dist: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
     _lib.check(lib.egx_posenc(_lib.ptr(dist.contiguous()), _lib.ptr(time.contiguous()), n, _lib.ptr(out), _lib.current_stream_ptr()),
                "egx_posenc")
     return out
+
+
+ACT_CODE = {None: 0, "none": 0, "tanh": 1, "relu": 2, "lrelu": 3, "leaky_relu": 3}
+
+
+class LinearFn(torch.autograd.Function):
+    """out = act(x W^T + b) (+ res).  The gradients of W and b are ACCUMULATED into `wg` / `bg` (views of the flat
+    gradient buffer, zeroed once per minibatch by the caller) inside backward, and None is returned for them, so autograd
+    launches no per-parameter accumulation kernels.  nn.Linear + activation of models_policy_ppo.py:24-39."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, wg, bg, act, slope, res):
+        lib = _lib.load()
+        x = x.contiguous()
+        z = torch.addmm(b, x, W.t())
+        M, N = z.shape
+        out = z
+        if act != 0 or res is not None:
+            if res is not None:
+                res = res.contiguous()
+                out = torch.empty_like(z)
+            _lib.check(lib.egx_act_fwd(_lib.ptr(z), _lib.ptr(res) if res is not None else None,
+                                       _lib.ptr(out) if res is not None else None, M, N, int(act), float(slope),
+                                       _lib.current_stream_ptr()), "egx_act_fwd")
+        ctx.save_for_backward(x, W, z if act != 0 else None)
+        ctx.wg, ctx.bg, ctx.act, ctx.slope, ctx.has_res = wg, bg, int(act), float(slope), res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, W, a = ctx.saved_tensors
+        dout = dout.contiguous()
+        M, N = dout.shape
+        g = torch.empty_like(dout) if ctx.act != 0 else dout
+        _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(dout), _lib.ptr(a) if a is not None else None,
+                                          _lib.ptr(g) if ctx.act != 0 else None, _lib.ptr(ctx.bg), M, N, ctx.act, ctx.slope,
+                                          _lib.current_stream_ptr()), "egx_act_bwd_colsum")
+        ctx.wg.addmm_(g.t(), x)
+        dx = torch.mm(g, W) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, None, None, (dout if ctx.has_res else None)
+
+
+def linear_fn(x, weight, bias, act="none", slope=0.01, res=None):
+    if weight.grad is None or bias.grad is None:
+        raise _lib.EgxError("LinearFn needs pre-allocated gradient views (GAMMAPPOPolicy._ensure_flat_grads)")
+    return LinearFn.apply(x, weight, bias, weight.grad, bias.grad, ACT_CODE[act], slope, res)
+
+
+def linear_act(x, lin: torch.nn.Linear, act="none", slope=0.01, res=None):
+    """LinearFn on an nn.Linear whose .grad tensors are views of the flat gradient buffer."""
+    if lin.weight.grad is None or lin.bias.grad is None:
+        raise _lib.EgxError("linear_act needs pre-allocated gradient views (GAMMAPPOPolicy._ensure_flat_grads)")
+    return LinearFn.apply(x, lin.weight, lin.bias, lin.weight.grad, lin.bias.grad, ACT_CODE[act], slope, res)

@@ -285,6 +285,51 @@ class ActorCritic(nn.Module):
             self.shared_net = shared_net
 
 
+def _gru_last_fused(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
+    """nn.GRU over x[b,T,in] from a zero state, last hidden state.  The input products of all T steps are ONE GEMM
+    (each weight is used once per minibatch: its gradient is written by a single accumulate-GEMM), the gate math is the
+    fused HIP node, and the first step's recurrent term is the bias alone (h_0 = 0)."""
+    from .fused_ops import GRUPointwiseFn, linear_fn
+    nb, T, _ = x.shape
+    H = gru.hidden_size
+    X = x.permute(1, 0, 2).reshape(T * nb, x.shape[2])
+    gi = linear_fn(X, gru.weight_ih_l0, gru.bias_ih_l0)
+    h = x.new_zeros(nb, H)
+    for t in range(T):
+        if t == 0:
+            gh = gru.bias_hh_l0.unsqueeze(0).expand(nb, 3 * H)
+        else:
+            gh = linear_fn(h, gru.weight_hh_l0, gru.bias_hh_l0)
+        h = GRUPointwiseFn.apply(gi[t * nb:(t + 1) * nb], gh, h)
+    return h
+
+
+def _mlpblock_fused(block: MLPBlock, x: torch.Tensor) -> torch.Tensor:
+    from .fused_ops import linear_act
+    h = x
+    for mlp in block.layers:
+        t = h
+        last = len(mlp.layers) - 1
+        for i, fc in enumerate(mlp.layers):
+            t = linear_act(t, fc, mlp.act_name, res=h if (block.residual and i == last) else None)
+        h = t
+    return linear_act(h, block.out_fc, "none")
+
+
+def fused_update_forward(shared_net: "GAMMAPolicyBase", actor: "GAMMAActor", critic: "GAMMACritic", obs):
+    """Forward of (shared_net, actor, critic) for the PPO update with every dense layer a `fused_ops.LinearFn` node
+    (models_policy_ppo.py:287-350).  Returns mu[b,128], raw logvar[b,128], value[b]."""
+    from .fused_ops import posenc_dist_time
+    nb = obs["state"].shape[0]
+    hx = _gru_last_fused(shared_net.x_enc, obs["state"].float())
+    he = _gru_last_fused(shared_net.ego_enc, obs["egosensing"].float())
+    pe = posenc_dist_time(obs["dist"].reshape(nb).float(), obs["time"].reshape(nb).float())
+    h = torch.cat([hx, he, pe], dim=-1)
+    zp = _mlpblock_fused(actor.pnet, h)
+    value = _mlpblock_fused(critic.vnet, h).flatten()
+    return zp[:, :actor.z_dim], zp[:, actor.z_dim:], value
+
+
 class PolicyHipRunner:
     """Rollout-time forward of (shared_net, actor, critic) through egx_policy_forward."""
 

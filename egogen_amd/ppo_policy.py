@@ -85,6 +85,9 @@ class GAMMAPPOPolicy(nn.Module):
         self._graph_cache: dict = {}
         self.use_update_graph = bool(_ignored.get("use_update_graph", False))
         self.use_fused_loss = bool(_ignored.get("use_fused_loss", True))
+        # dense layers of the update as LinearFn nodes (library GEMMs + fused activation / bias-gradient / accumulation
+        # kernels).  Their weight gradients are ACCUMULATED into the flat buffer: callers zero it once per minibatch.
+        self.use_fused_linear = bool(_ignored.get("use_fused_linear", True))
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     # ---- rollout side (HIP) -------------------------------------------------------------------------
@@ -152,14 +155,15 @@ class GAMMAPPOPolicy(nn.Module):
 
     def _ensure_flat_grads(self):
         """One flat fp32 gradient buffer (13 168 001 floats) aliased by every .grad: a single in-place all-reduce."""
-        if self._flat_grad is not None:
-            return
         params = [p for g in self.optim.param_groups for p in g["params"]]
-        total = sum(p.numel() for p in params)
-        self._flat_grad = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        if self._flat_grad is None:
+            total = sum(p.numel() for p in params)
+            self._flat_grad = torch.zeros(total, dtype=torch.float32, device=params[0].device)
         off = 0
-        for p in params:
-            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+        base = self._flat_grad.data_ptr()
+        for p in params:  # (re-)attach: zero_grad(set_to_none=True) or a foreign backward may have replaced a view
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
 
     def minibatch_loss(self, obs, act, adv, returns, logp_old, global_stats=None):
@@ -273,9 +277,14 @@ class GAMMAPPOPolicy(nn.Module):
         """Same function as the torch expression above, with the loss and its gradients w.r.t. (mu, logvar, value)
         computed by one HIP kernel (egx_ppo_loss)."""
         from .fused_ops import PPOLossFn
-        hx = self.shared_net(obs)
-        (mu, logvar), _ = self.actor(hx)
-        value = self.critic(hx).flatten()
+        if self.use_fused_linear:
+            from .models import fused_update_forward
+            self._ensure_flat_grads()
+            mu, logvar, value = fused_update_forward(self.shared_net, self.actor, self.critic, obs)
+        else:
+            hx = self.shared_net(obs)
+            (mu, logvar), _ = self.actor(hx)
+            value = self.critic(hx).flatten()
         n_local = adv.shape[0]
         dev = adv.device
         stats = None

@@ -352,6 +352,16 @@ int egx_ppo_loss(const float* mu, const float* logvar, const float* value, const
 int egx_gru_pointwise_bwd(const float* gi, const float* gh, const float* h_prev, const float* dh, int num_rows, int hidden,
                           float* dgi, float* dgh, float* dh_prev, void* stream);
 
+/* Dense-layer glue of the PPO update (GAMMAPPOPolicy.learn, crowd_ppo/ppo_policy.py:182-265: loss.backward() through
+ * nn.Linear + activation (+ residual) of models_policy_ppo.py:24-39,233-274).  The matrix products are library GEMMs;
+ * these two kernels replace the activation / residual / activation-gradient / bias-gradient element-wise passes.
+ * activation codes as in egx_linear_desc.  egx_act_fwd: z [M,N] <- act(z) in place; out <- act(z) + res when res != NULL.
+ * egx_act_bwd_colsum: g <- dy * act'(a) (a = saved activation output; g may be NULL) and db_accum[n] += sum_m g[m][n]
+ * (db_accum may be NULL). */
+int egx_act_fwd(float* z, const float* res, float* out, int num_rows, int width, int act, float slope, void* stream);
+int egx_act_bwd_colsum(const float* dy, const float* a, float* g, float* db_accum, int num_rows, int width, int act,
+                       float slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,19 +184,29 @@ def test_fused_update_ops_match_torch_autograd():
         b.logp_old.copy_((pol.log_prob(mu, sigma, b.act.reshape(-1, 128)) + 0.2 * torch.randn(N, generator=g).cuda()).reshape(1, N))
     args = (b.obs_flat(), b.act.reshape(N, 128), b.adv.reshape(N), b.returns.reshape(N), b.logp_old.reshape(N))
 
-    def grads(fused):
+    def grads(fused, fused_linear=False):
         models.FUSED_UPDATE_OPS = fused
         pol.use_fused_loss = fused
+        pol.use_fused_linear = fused_linear
         pol.zero_grad(set_to_none=True)
+        if fused_linear:  # LinearFn accumulates into the flat gradient views
+            pol._ensure_flat_grads()
+            pol._flat_grad.zero_()
         loss, terms = pol.minibatch_loss(*args)
         loss.backward()
-        return float(loss), {k: float(v) for k, v in terms.items()}, torch.cat([p.grad.flatten() for p in pol.parameters()])
+        return float(loss), {k: float(v) for k, v in terms.items()}, torch.cat([p.grad.flatten() for p in pol.parameters()]).clone()
 
     try:
         l0, t0, g0 = grads(False)
         l1, t1, g1 = grads(True)
+        l2, t2, g2 = grads(True, fused_linear=True)
     finally:
         models.FUSED_UPDATE_OPS = True
+        pol.use_fused_linear = True
+    assert abs(l0 - l2) <= 1e-4 * max(1.0, abs(l0))
+    for k in ("loss/clip", "loss/vf", "loss/ent", "loss/kld", "approx_kl"):
+        assert abs(t0[k] - t2[k]) <= 2e-4 * max(1.0, abs(t0[k])), k
+    assert float((g0 - g2).abs().max()) <= 1e-3 * float(g0.abs().max())
     # log-probs are 128-term sums of magnitude ~1e2 feeding exp(): 1e-4 absolute on the loss is fp32 summation-order noise
     assert abs(l0 - l1) <= 1e-4 * max(1.0, abs(l0))
     for k in ("loss/clip", "loss/vf", "loss/ent", "loss/kld", "approx_kl"):
