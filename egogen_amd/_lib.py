@@ -134,6 +134,8 @@ SIGNATURES = {
     "egx_ppo_loss": (C.c_int, [C.c_void_p] * 9 + [C.c_float] * 6 + [C.c_int] + [C.c_void_p] * 5),
     "egx_gru_pointwise_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
+    "egx_lbs_set_blend_mode": (C.c_int, [C.c_int]),
+    "egx_lbs_get_blend_mode": (C.c_int, []),
     "egx_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "egx_act_bwd_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                      C.c_void_p]),

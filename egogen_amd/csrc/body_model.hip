@@ -21,6 +21,7 @@
 #include <mutex>
 #include <vector>
 
+#include <atomic>
 #include "egx_common.h"
 
 static thread_local std::string g_last_error;
@@ -62,6 +63,30 @@ constexpr int KDIM = EGX_BLEND_K;      // 472 = 469 padded to a multiple of 8
 constexpr int KSTEPS = KDIM / 2;       // 236 MFMA k-steps (32x32x2)
 constexpr int KGROUPS = KSTEPS / 4;    // 59 float4 groups
 static_assert(KGROUPS >= 2, "the operand ring preloads two k-groups");
+// 3-term bf16 split of the blend GEMM (LBS blend mode 1): every fp32 operand x = hi + mid + lo with three bf16 terms
+// (24+ significant bits, i.e. the whole fp32 mantissa); the product keeps the six partial products down to 2^-24 relative
+// (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid), accumulated in fp32 by v_mfma_f32_32x32x16_bf16 - 6 MFMAs of 32 cycles
+// per 16 k instead of 8 fp32 MFMAs of 64 cycles.  K is padded to 480 = 30 steps of 16.
+constexpr int KS3 = 30;
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__host__ __device__ inline unsigned short egx_bf16_rne(float x) {
+  union { float f; unsigned u; } c;
+  c.f = x;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((c.u >> 16) | 0x40u);
+  return (unsigned short)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ inline float egx_bf16_to_f32(unsigned short h) {
+  union { float f; unsigned u; } c;
+  c.u = (unsigned)h << 16;
+  return c.f;
+}
+__host__ __device__ inline void egx_bf16_split3(float x, unsigned short* h) {
+  h[0] = egx_bf16_rne(x);
+  const float r1 = x - egx_bf16_to_f32(h[0]);   // exact
+  h[1] = egx_bf16_rne(r1);
+  const float r2 = r1 - egx_bf16_to_f32(h[1]);  // exact
+  h[2] = egx_bf16_rne(r2);
+}
 __host__ __device__ inline int egx_compact_joint(int j) { return (j - 1) - (j > 24 ? 3 : 0); }  // j in 1..54, j != 22..24
 constexpr int NLMK = 51, NEXTRA = 21;
 constexpr int BODY_PAD = 256;          // bodies per workgroup of the fused kernel
@@ -80,7 +105,8 @@ struct PoseConsts {
 
 struct egx_body_model {
   int V = 0, NVT = 0, NW = 0, M = 0, NP = 0;
-  f32x4* dirs = nullptr;       // [NVT][62][3][64] float4
+  f32x4* dirs = nullptr;       // [NVT][59][3][64] float4 (fp32 blend)
+  bf16x8* dirs3 = nullptr;     // [NVT][30 k-steps][3 planes][3 coords][64 lanes] 8 x bf16 (bf16x3 blend)
   int* tj_off = nullptr;       // [NVT+1] offsets into the per-tile joint lists
   int* tj_idx = nullptr;       // [tj_off[NVT]] joints with a non-zero skinning weight on some vertex of the tile
   float* tj_w = nullptr;       // [tj_off[NVT]][32] dense weights of the tile's 32 vertices for that joint
@@ -99,7 +125,8 @@ struct egx_body_model {
 __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* __restrict__ pc,
                                                              const float* __restrict__ xb,
                                                              const float* __restrict__ betas, int B, int fpa,
-                                                             float* __restrict__ feat,   // packed B operand
+                                                             float* __restrict__ feat,   // packed B operand (fp32 blend) or null
+                                                             unsigned short* __restrict__ feat3,  // bf16x3 planes or null
                                                              f32x4* __restrict__ A4,     // [bt][55][3][32]
                                                              float* __restrict__ out_joints) {
   __shared__ float sR[4][NJ][9];
@@ -112,10 +139,20 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
   const float* x = xb + (size_t)bb * EGX_XB_DIM;
   const float* be = betas + (size_t)(bb / fpa) * 10;
   const int bt = bb >> 5, n = bb & 31;
-  float* featb = feat + (size_t)bt * KGROUPS * 64 * 4;  // tile base
+  float* featb = feat ? feat + (size_t)bt * KGROUPS * 64 * 4 : nullptr;  // tile base
+  unsigned short* feat3b = feat3 ? feat3 + (size_t)bt * KS3 * 3 * 64 * 8 : nullptr;
   auto feat_store = [&](int k, float v) {
-    const int s = k >> 1, kk = k & 1;
-    featb[((s >> 2) * 64 + (kk * 32 + n)) * 4 + (s & 3)] = v;
+    if (featb && k < KDIM) {
+      const int s = k >> 1, kk = k & 1;
+      featb[((s >> 2) * 64 + (kk * 32 + n)) * 4 + (s & 3)] = v;
+    }
+    if (feat3b) {  // k = 16 s + 8 half + e  ->  [s][plane][half*32 + n][e]
+      unsigned short h[3];
+      egx_bf16_split3(v, h);
+      const int s = k >> 4, hf = (k >> 3) & 1, e = k & 7;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) feat3b[(((size_t)s * 3 + pl) * 64 + hf * 32 + n) * 8 + e] = h[pl];
+    }
   };
   float R[9], Jr[3];
   if (j < NJ) {
@@ -158,6 +195,9 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       }
       // column 469 multiplies the template column of the bases (acc = v_template + offsets); 470, 471 are padding
       if (j >= 22 && j <= 24) feat_store(KACT + (j - 22), j == 22 ? 1.f : 0.f);
+      if (feat3b && j >= 22 && j <= 24) {  // bf16x3 pads K to 480: columns 472..479
+        for (int k = KDIM + (j - 22); k < KS3 * 16; k += 3) feat_store(k, 0.f);
+      }
     }
   }
   __syncthreads();
@@ -211,7 +251,9 @@ struct LbsParams {
   const float* tj_w;
   const int* pick_slot;
   const uint8_t* vflags;
-  const f32x4* feat;   // [bt][62][64] float4
+  const bf16x8* dirs3; // bf16x3 bases (blend mode 1)
+  const bf16x8* feat3; // [bt][30][3 planes][64] 8 x bf16
+  const f32x4* feat;   // [bt][59][64] float4
   const f32x4* A4;     // [bt][55][3][32] float4
   const float* xb;     // transl = xb[b*93 + 0..2]
   int B, V, NVT, NW, NP, fpa;
@@ -240,49 +282,41 @@ constexpr int LBS_VERT_BYTES = 32 * 97 * 4;          // per-wave transpose buffe
 constexpr int LBS_QCAP = 640;                        // entries of the per-wave queue of undecided SDF points (>= 512 + 64)
 constexpr int LBS_THREADS = 512;
 
+// Per-wave state of the fused kernels: lane coordinates and the wave's private LDS regions (metadata of the current
+// vertex tile, penetration counters, queue of undecided SDF points / vertex transpose buffer).
+struct LbsWave {
+  int lane, n, half;
+  float* s_W;          // [jj][row] dense skinning weights of the tile's joint list
+  int* s_jl;           // [jj] joint ids
+  int* s_slot;         // [row] pick slot or -1
+  unsigned* s_masks;   // [0] rows with a pick slot, [1] rows in the SDF count
+  int* s_cnt;          // [q*32 + n] penetration count of this item's 64 bodies
+  float* lds;          // vertex transpose buffer (vertex-writing variants)
+  f32x4* s_queue;      // undecided SDF points (voxel x, y, z, counter slot)
+  int qn;              // queued points (wave-uniform)
+};
+constexpr int LBS_NB = 2;  // 32-body MFMA column tiles per wave
+
 template <bool WRITE_VERTS, bool DO_SDF>
-__global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams p) {
-  constexpr int NB = 2;  // 32-body MFMA column tiles per wave
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // which waves share a SIMD is a property of the dispatcher; set_mode picks the pairing (see DESIGN.md section 4)
-  const int set = (p.set_mode == 0) ? (wave >> 2) : (p.set_mode == 1) ? (wave & 1) : ((wave >> 1) & 1);
-  const int w4 = (p.set_mode == 0) ? (wave & 3) : (p.set_mode == 1) ? (wave >> 1) : ((wave & 1) | ((wave >> 2) << 1));
-  const int n = lane & 31, half = lane >> 5;
-  char* my = smem_raw + wave * (LBS_META_BYTES + (WRITE_VERTS ? LBS_VERT_BYTES : (DO_SDF ? LBS_QCAP * 16 : 0)));
-  float* s_W = reinterpret_cast<float*>(my);                        // [jj][row]
-  int* s_jl = reinterpret_cast<int*>(my + NJ * 32 * 4);             // [jj]
-  int* s_slot = s_jl + 56;                                          // [row]
-  unsigned* s_masks = reinterpret_cast<unsigned*>(s_slot + 32);     // [0] rows with a pick slot, [1] rows in the SDF count
-  int* s_cnt = reinterpret_cast<int*>(s_masks + 4);                 // [q*32 + n] penetration count of this item's 64 bodies
-  float* lds = reinterpret_cast<float*>(my + LBS_META_BYTES);
-  f32x4* s_queue = reinterpret_cast<f32x4*>(my + LBS_META_BYTES);   // undecided SDF points (voxel x, y, z, body)
-  // work streams.  With >= 8 body groups every XCD (block id % 8) owns a contiguous chunk of body groups, so their packed
-  // features / transforms stay in that XCD's L2 while the blend bases stream through once per XCD; the streams of an XCD
-  // walk its (vertex tile, body group) list vertex-tile-major, i.e. at any time they share a dozen consecutive tiles.
-  int bg_lo, nper, n_streams, stream;
-  if (p.nbg >= 8 && (gridDim.x & 7) == 0) {
-    const int per = (p.nbg + 7) / 8, xcd = blockIdx.x & 7;
-    bg_lo = xcd * per;
-    nper = max(0, min(per, p.nbg - bg_lo));
-    n_streams = (gridDim.x >> 3) * 2;
-    stream = (blockIdx.x >> 3) * 2 + set;
-  } else {
-    bg_lo = 0; nper = p.nbg;
-    n_streams = gridDim.x * 2;
-    stream = blockIdx.x * 2 + set;
-  }
-  const int n_items = p.NVT * nper;
-  const int num_bt = (p.B + 31) >> 5;
-  s_cnt[lane] = 0;
-  if (set == 1 && p.phase_delay > 0 && stream < n_items) {
-    const long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < p.phase_delay) __builtin_amdgcn_s_sleep(16);
-  }
-  for (int item = stream; item < n_items; item += n_streams) {
-  const int vt = item / nper, bg = bg_lo + item % nper;
-  const int bt0 = bg * 8 + w4 * NB;  // first 32-body tile of this wave
-  // per-tile metadata, private to the wave (DS operations of one wave execute in order: no barrier)
+__device__ __forceinline__ LbsWave lbs_wave_init(char* my, int lane) {
+  LbsWave w;
+  w.lane = lane; w.n = lane & 31; w.half = lane >> 5;
+  w.s_W = reinterpret_cast<float*>(my);
+  w.s_jl = reinterpret_cast<int*>(my + NJ * 32 * 4);
+  w.s_slot = w.s_jl + 56;
+  w.s_masks = reinterpret_cast<unsigned*>(w.s_slot + 32);
+  w.s_cnt = reinterpret_cast<int*>(w.s_masks + 4);
+  w.lds = reinterpret_cast<float*>(my + LBS_META_BYTES);
+  w.s_queue = reinterpret_cast<f32x4*>(my + LBS_META_BYTES);
+  w.qn = 0;
+  w.s_cnt[lane] = 0;
+  return w;
+}
+
+// per-tile metadata, private to the wave (DS operations of one wave execute in order: no barrier)
+__device__ __forceinline__ int lbs_load_meta(const LbsParams& p, LbsWave& w, int vt) {
+  const int lane = w.lane;
+  float* s_W = w.s_W; int* s_jl = w.s_jl; int* s_slot = w.s_slot; unsigned* s_masks = w.s_masks;
   const int j_lo = p.tj_off[vt];
   const int JT = p.tj_off[vt + 1] - j_lo;
   for (int idx = lane * 4; idx < JT * 32; idx += 256)
@@ -297,82 +331,18 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
   }
   __builtin_amdgcn_wave_barrier();
 
-  f32x16 acc[3][NB];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int q = 0; q < NB; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
+  return JT;
+}
 
-  const f32x4* dp = p.dirs + (size_t)vt * KGROUPS * 3 * 64 + lane;
-  const f32x4* fp[NB];
-#pragma unroll
-  for (int q = 0; q < NB; ++q) fp[q] = p.feat + (size_t)min(bt0 + q, num_bt - 1) * KGROUPS * 64 + lane;
-
-  // Operand bursts.  Measured on gfx950 (scripts/ubench/mfma_loads.hip): a wave that issues v_mfma_f32_32x32x2_f32
-  // while its own global loads are still in flight runs the matrix pipe at about half rate (72 vs 136 TFLOP/s
-  // chip-wide for this exact loop), whereas "load a burst, s_waitcnt vmcnt(0), then only MFMAs" keeps 98 % of the
-  // load-free rate - the exposed load latency is covered by the other wave of the SIMD, whose MFMAs are not affected
-  // by this wave's returning data.  So: no software prefetch; LBS_BURST k-groups of operands per burst.
-  constexpr int LBS_BURST = 2;
-  if (!(p.dbg & 2)) {
-    f32x4 a_st[LBS_BURST][3], b_st[LBS_BURST][NB];
-    constexpr int KMAIN = KGROUPS / LBS_BURST * LBS_BURST;
-    for (int g0 = 0; g0 < KMAIN; g0 += LBS_BURST) {
-#pragma unroll
-      for (int u = 0; u < LBS_BURST; ++u) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) a_st[u][c] = dp[((g0 + u) * 3 + c) * 64];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) b_st[u][q] = fp[q][(g0 + u) * 64];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < LBS_BURST; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int q = 0; q < NB; ++q)
-              acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_st[u][c][e], b_st[u][q][e], acc[c][q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int g = KMAIN; g < KGROUPS; ++g) {  // tail groups, one at a time
-#pragma unroll
-      for (int c = 0; c < 3; ++c) a_st[0][c] = dp[(g * 3 + c) * 64];
-#pragma unroll
-      for (int q = 0; q < NB; ++q) b_st[0][q] = fp[q][g * 64];
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int q = 0; q < NB; ++q)
-            acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_st[0][c][e], b_st[0][q][e], acc[c][q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-
-  if (p.dbg & 1) {
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int q = 0; q < NB; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += acc[c][q][r];
-    if (sum == 123.456f) p.pene[0] = 1;
-    continue;
-  }
-  // ---- epilogue: each lane owns 16 vertices (rows) x NB bodies (col n of tiles bt0+q) ----------
+// Epilogue of one work item: each lane owns 16 vertices (rows) x 2 bodies (column n of tiles bt0, bt0+1).
+template <bool WRITE_VERTS, bool DO_SDF, int RB, int QCAP>
+__device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int JT) {
+  constexpr int NB = LBS_NB;
+  const int lane = w.lane, n = w.n, half = w.half;
+  float* s_W = w.s_W; int* s_jl = w.s_jl; int* s_slot = w.s_slot; unsigned* s_masks = w.s_masks; int* s_cnt = w.s_cnt;
+  float* lds = w.lds; f32x4* s_queue = w.s_queue;
+  const int num_bt = (p.B + 31) >> 5;
+  int qn = w.qn;
   float tr[NB][3];
   int body[NB];
   bool bvalid[NB];
@@ -388,7 +358,6 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
   // Skinning walks the tile's joint list: one transform fetch per (joint, body) - prefetched one joint ahead - applied
   // to the lane's 16 vertices with their weights from LDS (o = sum_j w_j (A_j v + t_j); rows whose weights are all zero
   // are skipped in groups of four).  The accumulators already hold v_template + offsets (template column of the GEMM).
-  int qn = 0;  // queued undecided SDF points (wave-uniform)
   auto sdf_flush = [&](int count) {
     __builtin_amdgcn_wave_barrier();
     for (int base = 0; base < count; base += 64) {
@@ -462,12 +431,12 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
       const unsigned mine = bvalid[q] ? (sdf_mask >> (4 * half)) : 0u;  // bit (r&3)+8(r>>2) = this lane's row r
       int cnt = 0;
 #pragma unroll
-      for (int r0 = 0; r0 < 16; r0 += 8) {
-        float wp[8][3];
-        float2 mm[8];
-        if (qn + 512 > LBS_QCAP) { sdf_flush(qn); qn = 0; }  // room for one batch: 8 rows x 64 lanes
+      for (int r0 = 0; r0 < 16; r0 += RB) {
+        float wp[RB][3];
+        float2 mm[RB];
+        if (qn + RB * 64 > QCAP) { sdf_flush(qn); qn = 0; }  // room for one batch: RB rows x 64 lanes
 #pragma unroll
-        for (int r = r0; r < r0 + 8; ++r) {
+        for (int r = r0; r < r0 + RB; ++r) {
           const float wx = Rw[0] * o[r][0] + Rw[1] * o[r][1] + Rw[2] * o[r][2] + Tw[0];
           const float wy = Rw[3] * o[r][0] + Rw[4] * o[r][1] + Rw[5] * o[r][2] + Tw[1];
           const float wz = Rw[6] * o[r][0] + Rw[7] * o[r][1] + Rw[8] * o[r][2] + Tw[2];
@@ -475,7 +444,7 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
           mm[r - r0] = (p.dbg & 32) ? float2{wx, wy} : egx_sdf_coarse_at(p.sdf, wp[r - r0][0], wp[r - r0][1], wp[r - r0][2]);
         }
 #pragma unroll
-        for (int r = r0; r < r0 + 8; ++r) {
+        for (int r = r0; r < r0 + RB; ++r) {
           const bool on = (mine >> ((r & 3) + 8 * (r >> 2))) & 1u;
           const bool inside = mm[r - r0].x > 0.f;
           cnt += (on && inside) ? 1 : 0;
@@ -532,7 +501,267 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
     if (c != 0 && bd < p.B) atomicAdd(p.pene + bd, c);
     __builtin_amdgcn_wave_barrier();
   }
-  }  // work items
+  w.qn = qn;
+}
+
+// fp32 blend GEMM of one work item on v_mfma_f32_32x32x2_f32: acc = [v_template | bases] x [1 | features]
+__device__ __forceinline__ void lbs_blend_f32(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane) {
+  constexpr int NB = LBS_NB;
+  const int num_bt = (p.B + 31) >> 5;
+  const f32x4* dp = p.dirs + (size_t)vt * KGROUPS * 3 * 64 + lane;
+  const f32x4* fp[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) fp[q] = p.feat + (size_t)min(bt0 + q, num_bt - 1) * KGROUPS * 64 + lane;
+
+  // Operand bursts.  Measured on gfx950 (scripts/ubench/mfma_loads.hip): a wave that issues v_mfma_f32_32x32x2_f32
+  // while its own global loads are still in flight runs the matrix pipe at about half rate (72 vs 136 TFLOP/s
+  // chip-wide for this exact loop), whereas "load a burst, s_waitcnt vmcnt(0), then only MFMAs" keeps 98 % of the
+  // load-free rate - the exposed load latency is covered by the other wave of the SIMD, whose MFMAs are not affected
+  // by this wave's returning data.  So: no software prefetch; LBS_BURST k-groups of operands per burst.
+  constexpr int LBS_BURST = 2;
+  if (!(p.dbg & 2)) {
+    f32x4 a_st[LBS_BURST][3], b_st[LBS_BURST][NB];
+    constexpr int KMAIN = KGROUPS / LBS_BURST * LBS_BURST;
+    for (int g0 = 0; g0 < KMAIN; g0 += LBS_BURST) {
+#pragma unroll
+      for (int u = 0; u < LBS_BURST; ++u) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a_st[u][c] = dp[((g0 + u) * 3 + c) * 64];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) b_st[u][q] = fp[q][(g0 + u) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < LBS_BURST; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+              acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_st[u][c][e], b_st[u][q][e], acc[c][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = KMAIN; g < KGROUPS; ++g) {  // tail groups, one at a time
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a_st[0][c] = dp[(g * 3 + c) * 64];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) b_st[0][q] = fp[q][g * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+            acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_st[0][c][e], b_st[0][q][e], acc[c][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+}
+
+template <bool WRITE_VERTS, bool DO_SDF>
+__global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams p) {
+  constexpr int NB = LBS_NB;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // which waves share a SIMD is a property of the dispatcher; set_mode picks the pairing (see DESIGN.md section 4)
+  const int set = (p.set_mode == 0) ? (wave >> 2) : (p.set_mode == 1) ? (wave & 1) : ((wave >> 1) & 1);
+  const int w4 = (p.set_mode == 0) ? (wave & 3) : (p.set_mode == 1) ? (wave >> 1) : ((wave & 1) | ((wave >> 2) << 1));
+  char* my = smem_raw + wave * (LBS_META_BYTES + (WRITE_VERTS ? LBS_VERT_BYTES : (DO_SDF ? LBS_QCAP * 16 : 0)));
+  LbsWave w = lbs_wave_init<WRITE_VERTS, DO_SDF>(my, lane);
+  // work streams.  With >= 8 body groups every XCD (block id % 8) owns a contiguous chunk of body groups, so their packed
+  // features / transforms stay in that XCD's L2 while the blend bases stream through once per XCD; the streams of an XCD
+  // walk its (vertex tile, body group) list vertex-tile-major, i.e. at any time they share a dozen consecutive tiles.
+  int bg_lo, nper, n_streams, stream;
+  if (p.nbg >= 8 && (gridDim.x & 7) == 0) {
+    const int per = (p.nbg + 7) / 8, xcd = blockIdx.x & 7;
+    bg_lo = xcd * per;
+    nper = max(0, min(per, p.nbg - bg_lo));
+    n_streams = (gridDim.x >> 3) * 2;
+    stream = (blockIdx.x >> 3) * 2 + set;
+  } else {
+    bg_lo = 0; nper = p.nbg;
+    n_streams = gridDim.x * 2;
+    stream = blockIdx.x * 2 + set;
+  }
+  const int n_items = p.NVT * nper;
+  if (set == 1 && p.phase_delay > 0 && stream < n_items) {
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < p.phase_delay) __builtin_amdgcn_s_sleep(16);
+  }
+  for (int item = stream; item < n_items; item += n_streams) {
+    const int vt = item / nper, bg = bg_lo + item % nper;
+    const int bt0 = bg * 8 + w4 * NB;  // first 32-body tile of this wave
+    const int JT = lbs_load_meta(p, w, vt);
+    f32x16 acc[3][NB];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
+    if (!(p.dbg & 2)) lbs_blend_f32(p, acc, vt, bt0, lane);
+    if (p.dbg & 1) {
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sum += acc[c][q][r];
+      if (sum == 123.456f) p.pene[0] = 1;
+      continue;
+    }
+    lbs_epilogue<WRITE_VERTS, DO_SDF, 8, LBS_QCAP>(p, w, acc, vt, bt0, JT);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel 2b: the same work item with the blend GEMM as a 3-term bf16 split (see KS3 above).
+// Workgroup = 4 waves = one vertex tile x 256 bodies; the bases of a stage (2 k-steps x 3 planes x 3 coordinates = 18
+// pieces of 1 KiB) are fetched once per workgroup, parked in LDS (double buffered, one barrier per stage) and read back
+// by all four waves; each wave fetches its own feature pieces (12 KiB per stage) into registers.  Loads are issued as a
+// burst and waited for before the stage's 72 MFMAs (no VMEM in flight under MFMA, scripts/ubench/mfma_bf16.hip); the
+// second workgroup of the CU covers the gap, and - unlike the fp32 MFMA, which shares the fp32 VALU lanes - the bf16
+// matrix pipe runs concurrently with the other workgroup's VALU epilogue.
+// ------------------------------------------------------------------------------------------------
+constexpr int LBS3_STAGE_KS = 2;
+constexpr int LBS3_STAGE_PIECES = LBS3_STAGE_KS * 9;
+constexpr int LBS3_STAGES = KS3 / LBS3_STAGE_KS;
+constexpr int LBS3_SHARED_BYTES = 2 * LBS3_STAGE_PIECES * 1024 + 7424;  // stage ring + tile metadata
+constexpr int LBS3_RB = 4;                                             // SDF rows per bracket batch
+constexpr int LBS3_QCAP = LBS3_RB * 64 + 64;
+constexpr int LBS3_WAVE_BYTES = 256 + LBS3_QCAP * 16;                  // s_cnt + queue
+static_assert(KS3 % LBS3_STAGE_KS == 0, "stages cover K exactly");
+
+__device__ __forceinline__ void lbs_blend_bf16x3(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave,
+                                                 bf16x8* sA) {
+  constexpr int NB = LBS_NB;
+  const int num_bt = (p.B + 31) >> 5;
+  const bf16x8* dpv = p.dirs3 + (size_t)vt * KS3 * 9 * 64 + lane;  // piece (s, plane, coord) at ((s*3 + plane)*3 + coord)*64
+  const bf16x8* fq[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) fq[q] = p.feat3 + (size_t)min(bt0 + q, num_bt - 1) * KS3 * 3 * 64 + lane;
+  for (int st = 0; st < LBS3_STAGES; ++st) {
+    // burst: this wave's share of the stage's base pieces + its own feature pieces
+    bf16x8 ga[5], b[LBS3_STAGE_KS][3][NB];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int piece = wave + 4 * i;
+      if (piece < LBS3_STAGE_PIECES) ga[i] = dpv[(size_t)(st * LBS3_STAGE_PIECES + piece) * 64];
+    }
+#pragma unroll
+    for (int ks = 0; ks < LBS3_STAGE_KS; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int q = 0; q < NB; ++q) b[ks][pl][q] = fq[q][((st * LBS3_STAGE_KS + ks) * 3 + pl) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8* buf = sA + (st & 1) * LBS3_STAGE_PIECES * 64;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int piece = wave + 4 * i;
+      if (piece < LBS3_STAGE_PIECES) buf[piece * 64 + lane] = ga[i];
+    }
+    __syncthreads();  // stage visible; also: everyone is done reading the other buffer's previous contents
+#pragma unroll
+    for (int ks = 0; ks < LBS3_STAGE_KS; ++ks)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const bf16x8 a0 = buf[(ks * 9 + 0 * 3 + c) * 64 + lane], a1 = buf[(ks * 9 + 1 * 3 + c) * 64 + lane],
+                     a2 = buf[(ks * 9 + 2 * 3 + c) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {  // small partial products first
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[ks][1][q], acc[c][q], 0, 0, 0);
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][2][q], acc[c][q], 0, 0, 0);
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[ks][0][q], acc[c][q], 0, 0, 0);
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][1][q], acc[c][q], 0, 0, 0);
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[ks][0][q], acc[c][q], 0, 0, 0);
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][0][q], acc[c][q], 0, 0, 0);
+        }
+      }
+  }
+}
+
+template <bool DO_SDF>
+__global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
+  constexpr int NB = LBS_NB;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bf16x8* sA = reinterpret_cast<bf16x8*>(smem_raw);
+  char* meta = smem_raw + 2 * LBS3_STAGE_PIECES * 1024;
+  char* my = smem_raw + LBS3_SHARED_BYTES + wave * LBS3_WAVE_BYTES;
+  LbsWave w;
+  w.lane = lane; w.n = lane & 31; w.half = lane >> 5;
+  w.s_W = reinterpret_cast<float*>(meta);                    // tile metadata is shared by the four waves here
+  w.s_jl = reinterpret_cast<int*>(meta + NJ * 32 * 4);
+  w.s_slot = w.s_jl + 56;
+  w.s_masks = reinterpret_cast<unsigned*>(w.s_slot + 32);
+  w.s_cnt = reinterpret_cast<int*>(my);
+  w.s_queue = reinterpret_cast<f32x4*>(my + 256);
+  w.lds = nullptr;
+  w.qn = 0;
+  w.s_cnt[lane] = 0;
+  int bg_lo, nper, n_streams, stream;
+  if (p.nbg >= 8 && (gridDim.x & 7) == 0) {
+    const int per = (p.nbg + 7) / 8, xcd = blockIdx.x & 7;
+    bg_lo = xcd * per;
+    nper = max(0, min(per, p.nbg - bg_lo));
+    n_streams = gridDim.x >> 3;
+    stream = blockIdx.x >> 3;
+  } else {
+    bg_lo = 0; nper = p.nbg;
+    n_streams = gridDim.x;
+    stream = blockIdx.x;
+  }
+  const int n_items = p.NVT * nper;
+  for (int item = stream; item < n_items; item += n_streams) {
+    const int vt = item / nper, bg = bg_lo + item % nper;
+    const int bt0 = bg * 8 + wave * NB;
+    __syncthreads();  // previous item: every wave is done with the metadata and with the stage ring
+    const int j_lo = p.tj_off[vt];
+    const int JT = p.tj_off[vt + 1] - j_lo;
+    for (int idx = threadIdx.x * 4; idx < JT * 32; idx += 1024)
+      *reinterpret_cast<f32x4*>(&w.s_W[idx]) = *reinterpret_cast<const f32x4*>(&p.tj_w[(size_t)j_lo * 32 + idx]);
+    if (wave == 0) {
+      if (lane < JT) w.s_jl[lane] = p.tj_idx[j_lo + lane];
+      const int sl = (lane < 32) ? p.pick_slot[vt * 32 + lane] : -1;
+      const int fl = (lane < 32) ? p.vflags[vt * 32 + lane] : 0;
+      if (lane < 32) w.s_slot[lane] = sl;
+      const unsigned long long mp = __ballot(sl >= 0), ms = __ballot((fl & 3) == 2);
+      if (lane == 0) { w.s_masks[0] = (unsigned)mp; w.s_masks[1] = (unsigned)ms; }
+    }
+    f32x16 acc[3][NB];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
+    if (!(p.dbg & 2)) lbs_blend_bf16x3(p, acc, vt, bt0, lane, wave, sA);
+    else __syncthreads();  // the blend's barriers also publish the metadata
+    if (p.dbg & 1) {
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sum += acc[c][q][r];
+      if (sum == 123.456f) p.pene[0] = 1;
+      continue;
+    }
+    lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP>(p, w, acc, vt, bt0, JT);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -613,6 +842,34 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
               }
             }
           dirs[(((size_t)vt * KGROUPS + g) * 3 + c) * 64 + l] = val;
+        }
+
+  // the same bases as three bf16 planes in the A-operand order of v_mfma_f32_32x32x16_bf16:
+  // [vt][s][plane][c][lane] 8 x bf16, element e <-> k = 16 s + 8 (lane>>5) + e, row = lane & 31
+  std::vector<unsigned short> dirs3((size_t)NVT * KS3 * 9 * 64 * 8, 0);
+  for (int vt = 0; vt < NVT; ++vt)
+    for (int sidx = 0; sidx < KS3; ++sidx)
+      for (int c = 0; c < 3; ++c)
+        for (int l = 0; l < 64; ++l) {
+          const int v = vt * 32 + (l & 31);
+          if (v >= V) continue;
+          for (int e = 0; e < 8; ++e) {
+            const int k = 16 * sidx + 8 * (l >> 5) + e;
+            float val = 0.f;
+            if (k < 10) {
+              val = d->shapedirs_host[((size_t)v * 3 + c) * 10 + k];
+            } else if (k < KACT) {
+              const int jc = (k - 10) / 9, e9 = (k - 10) % 9;
+              const int j = jc + 1 + (jc >= 21 ? 3 : 0);
+              val = d->posedirs_host[(size_t)((j - 1) * 9 + e9) * 3 * V + (size_t)v * 3 + c];
+            } else if (k == KACT) {
+              val = d->v_template_host[(size_t)v * 3 + c];
+            }
+            unsigned short h[3];
+            egx_bf16_split3(val, h);
+            for (int pl = 0; pl < 3; ++pl)
+              dirs3[(((((size_t)vt * KS3 + sidx) * 3 + pl) * 3 + c) * 64 + l) * 8 + e] = h[pl];
+          }
         }
 
   // skinning weights -> per-tile joint lists: the joints any of the tile's 32 vertices is bound to, with the dense
@@ -703,6 +960,11 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
   std::memcpy(pc.hand_mean + 45, d->hand_mean_r_host, 45 * sizeof(float));
 
   int rc = EGX_OK;
+  {
+    unsigned short* d3 = nullptr;
+    if ((rc = upload(&d3, dirs3))) { egx_body_model_destroy(m); return rc; }
+    m->dirs3 = reinterpret_cast<bf16x8*>(d3);
+  }
   if ((rc = upload(&m->dirs, dirs)) || (rc = upload(&m->tj_off, tj_off)) || (rc = upload(&m->tj_idx, tj_idx)) ||
       (rc = upload(&m->tj_w, tj_w)) || (rc = upload(&m->pick_slot, pick_slot)) || (rc = upload(&m->vflags, vflags)) ||
       (rc = upload(&m->pc, pcv)) || (rc = upload(&m->marker_slot, marker_slot)) || (rc = upload(&m->extra_slot, extra_slot)) ||
@@ -716,7 +978,7 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
 
 extern "C" void egx_body_model_destroy(egx_body_model* m) {
   if (!m) return;
-  (void)hipFree(m->dirs); (void)hipFree(m->tj_off); (void)hipFree(m->tj_idx); (void)hipFree(m->tj_w);
+  (void)hipFree(m->dirs); (void)hipFree(m->dirs3); (void)hipFree(m->tj_off); (void)hipFree(m->tj_idx); (void)hipFree(m->tj_w);
   (void)hipFree(m->pick_slot); (void)hipFree(m->vflags); (void)hipFree(m->pc); (void)hipFree(m->marker_slot);
   (void)hipFree(m->extra_slot); (void)hipFree(m->lmk_slot); (void)hipFree(m->lmk_bary);
   delete m;
@@ -726,6 +988,17 @@ extern "C" int egx_body_model_num_verts(const egx_body_model* m) { return m ? m-
 extern "C" int egx_body_model_nnz(const egx_body_model* m) { return m ? m->NW : 0; }
 
 namespace {
+// blend mode of the fused kernel: 0 = fp32 MFMA, 1 = 3-term bf16 split (default); vertex-writing calls always use 0
+std::atomic<int> g_blend_mode{-1};
+int blend_mode() {
+  int m = g_blend_mode.load();
+  if (m < 0) {
+    const char* e = getenv("EGX_LBS_BLEND");
+    m = (e && (std::string(e) == "f32" || std::string(e) == "0")) ? 0 : 1;
+    g_blend_mode.store(m);
+  }
+  return m;
+}
 struct WsLayout {
   size_t feat, A4, picked, total;
 };
@@ -733,12 +1006,19 @@ WsLayout ws_layout(const egx_body_model* m, int B) {
   const size_t Bp = egx_align_up((size_t)B, BODY_PAD);
   WsLayout w;
   w.feat = 0;
-  w.A4 = egx_align_up(w.feat + Bp * KDIM * sizeof(float), 256);
+  w.A4 = egx_align_up(w.feat + Bp * std::max<size_t>(KDIM * sizeof(float), (size_t)KS3 * 16 * 3 * 2), 256);
   w.picked = egx_align_up(w.A4 + Bp * NJ * 12 * sizeof(float), 256);
   w.total = egx_align_up(w.picked + (size_t)B * m->NP * 3 * sizeof(float), 256);
   return w;
 }
 }  // namespace
+
+extern "C" int egx_lbs_set_blend_mode(int mode) {
+  EGX_REQUIRE(mode == 0 || mode == 1, "blend mode must be 0 (fp32 MFMA) or 1 (bf16x3 split)");
+  g_blend_mode.store(mode);
+  return EGX_OK;
+}
+extern "C" int egx_lbs_get_blend_mode(void) { return blend_mode(); }
 
 extern "C" size_t egx_lbs_workspace_bytes(const egx_body_model* m, int num_bodies) {
   if (!m || num_bodies <= 0) return 0;
@@ -766,11 +1046,13 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   const bool need_picks = out_joints || out_markers;
   float* picked = need_picks ? reinterpret_cast<float*>(ws + wl.picked) : nullptr;
 
+  const bool split3 = blend_mode() == 1 && !out_verts;
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, stream, m->pc, xb, betas, B, fpa,
-                     feat, A4, out_joints);
+                     split3 ? nullptr : feat, split3 ? reinterpret_cast<unsigned short*>(feat) : nullptr, A4, out_joints);
   if (out_verts || need_picks || sdf) {
     LbsParams p;
     p.dirs = m->dirs; p.tj_off = m->tj_off; p.tj_idx = m->tj_idx; p.tj_w = m->tj_w; p.pick_slot = m->pick_slot;
+    p.dirs3 = m->dirs3; p.feat3 = reinterpret_cast<const bf16x8*>(feat);
     p.vflags = m->vflags; p.feat = reinterpret_cast<const f32x4*>(feat); p.A4 = A4; p.xb = xb;
     p.B = B; p.V = m->V; p.NVT = m->NVT; p.NW = m->NW; p.NP = m->NP; p.fpa = fpa;
     p.nbg = egx_ceil_div(B, BODY_PAD);
@@ -820,7 +1102,22 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) EGX_HIP_CHECK(hipEventRecord(ev0, stream));
-    if (out_verts && sdf)
+    if (split3) {
+      static bool attr3 = false;
+      constexpr size_t lds3 = (size_t)LBS3_SHARED_BYTES + 4 * LBS3_WAVE_BYTES;
+      if (!attr3) {
+        EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        attr3 = true;
+      }
+      const int grid3 = std::max(1, std::min(((p.dbg & 64) ? 1 : 2) * num_cu, n_items));  // two persistent 4-wave workgroups per CU
+      if (sdf)
+        hipLaunchKernelGGL((egx_lbs_fused3_kernel<true>), dim3(grid3), dim3(256), lds3, stream, p);
+      else
+        hipLaunchKernelGGL((egx_lbs_fused3_kernel<false>), dim3(grid3), dim3(256), lds3, stream, p);
+    } else if (out_verts && sdf)
       hipLaunchKernelGGL((egx_lbs_fused_kernel<true, true>), dim3(grid), dim3(LBS_THREADS), lds, stream, p);
     else if (out_verts)
       hipLaunchKernelGGL((egx_lbs_fused_kernel<true, false>), dim3(grid), dim3(LBS_THREADS), lds, stream, p);

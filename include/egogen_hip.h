@@ -86,6 +86,16 @@ size_t egx_sdf_coarse_bytes(int d0, int d1, int d2);
 int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream);
 
 /* Bytes of scratch egx_lbs_forward needs for `num_bodies` bodies. */
+/* Blend-GEMM arithmetic of egx_lbs_forward calls that do not write full vertices (process-wide switch; the environment
+ * variable EGX_LBS_BLEND=f32 selects mode 0 at first use):
+ *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   1  3-term bf16 split of both operands, six partial products per fp32 product on v_mfma_f32_32x32x16_bf16 with fp32
+ *      accumulation: same 2^-24-level accuracy as mode 0 (tests/test_lbs_gpu.py holds both to the same tolerances) at a
+ *      third of the matrix-pipe time.  Default.
+ * (No reference counterpart: smplx evaluates the blend shapes as fp32 einsum/matmul, lbs.py [upstream smplx 0.1.28].) */
+int egx_lbs_set_blend_mode(int mode);
+int egx_lbs_get_blend_mode(void);
+
 size_t egx_lbs_workspace_bytes(const egx_body_model* m, int num_bodies);
 
 /*
