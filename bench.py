@@ -38,7 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_BODY = 2.0 * 469 * 31425          # blend GEMM only: K = 10 betas + 9 x 51 movable joints (jaw/eye columns are exactly 0)
-PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F32_MFMA_TFLOPS = 157.3               # dense fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 MFMA peak (same guide); the bf16x3 blend issues 6 bf16 products per fp32 product
 
 
 def get_args():
@@ -260,7 +261,8 @@ def main():
     # it applies only to the configuration that pass was taken on
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lbs_pmc.json")))
+        blend = int(lib.egx_lbs_get_blend_mode())
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lbs_pmc_bf16x3.json" if blend == 1 else "r01_lbs_pmc.json")))
         c = pmc["config"]
         if c["agents"] == A and c["num_verts"] == args.num_verts and args.scene == "single_box" and args.sdf_res == 256:
             traffic = pmc["derived"]["hbm_side_bytes_per_launch"]
@@ -268,6 +270,15 @@ def main():
         pass
     bodies = A * 20
     achieved = FLOP_PER_BODY * bodies / (lbs_ms * 1e-3) / 1e12
+    blend = int(lib.egx_lbs_get_blend_mode())
+    if blend == 1:
+        # 3-term bf16 split: six bf16 MFMA products per fp32 product -> the matrix-pipe ceiling of the ALGORITHMIC fp32
+        # flops is the dense bf16 peak / 6
+        kernel_name, peak = "egx_lbs_fused3_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0
+        peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product (bf16x3 split, fp32 accumulate)"
+        executed = 6 * 2.0 * 480 * (328 * 32 * 3) * bodies / (lbs_ms * 1e-3) / 1e12 if args.num_verts == 10475 else None
+    else:
+        kernel_name, peak, peak_note, executed = "egx_lbs_fused_kernel", PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA peak", None
 
     transitions = args.steps * n_vec * A * world
     result = {
@@ -281,7 +292,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if blend == 0 else "f32 (blend GEMM operands as 3-term bf16 splits, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"crowd_ppo PPO loop: {A} agents/GPU, scene={args.scene}"
                                f"{'' if args.scene == 'box' else f' SDF {args.sdf_res}^3'}, synthetic SMPL-X body V={args.num_verts}, "
@@ -289,10 +300,11 @@ def main():
                    "agents_per_gpu": A, "scene": args.scene, "vec_steps_per_collect": n_vec, "minibatch_per_gpu": args.batch_size,
                    "parallelism": f"dp{world}" if world > 1 else "single", "hip_graph_env": bool(args.graph),
                    "hip_graph_update": bool(args.update_graph) and not any(v.get("failed") for v in policy._graph_cache.values())},
-        "roofline": {"bound": "mfma", "kernel": "egx_lbs_fused_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+        "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
-                     "flop_per_body": FLOP_PER_BODY},
+                     "flop_per_body": FLOP_PER_BODY, "peak_note": peak_note, "executed_bf16_tflops": executed,
+                     "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _log("cpu baseline ...")
