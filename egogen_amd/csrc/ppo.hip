@@ -1,5 +1,6 @@
 // Fused forward+gradient kernels for the PPO update (crowd_ppo/ppo_policy.py:189-241) and the GRU gate math of the
 // policy's two encoders, so that the autograd graph of one minibatch is ~40 kernels instead of ~300 tiny elementwise ones.
+#include <cstring>
 #include "egx_common.h"
 
 namespace {
@@ -144,6 +145,49 @@ __global__ __launch_bounds__(256) void egx_act_bwd_colsum_kernel(const float* __
   if (ty == 0 && n < N && db) atomicAdd(db + n, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
 }
 
+// ---- minibatch assembly: one launch gathers the rows idx[0..n) of up to 8 row-major fp32 tensors --------------
+struct GatherArgs {  // scalar fields only (a runtime-indexed array inside kernel arguments is copied to scratch)
+  const float *s0, *s1, *s2, *s3, *s4, *s5, *s6, *s7;
+  float *d0, *d1, *d2, *d3, *d4, *d5, *d6, *d7;
+  int w0, w1, w2, w3, w4, w5, w6, w7;
+  const long long* idx;
+  int n;
+};
+__device__ __forceinline__ void gather_seg(const float* __restrict__ s, float* __restrict__ d, int w, long long src_row, int dst_row) {
+  if (!s || w <= 0) return;
+  const float* sr = s + (size_t)src_row * w;
+  float* dr = d + (size_t)dst_row * w;
+  for (int c = threadIdx.x; c < w; c += blockDim.x) dr[c] = sr[c];
+}
+__global__ __launch_bounds__(256) void egx_gather_rows_kernel(GatherArgs a) {
+  const int r = blockIdx.x;
+  const long long src = a.idx[r];
+  gather_seg(a.s0, a.d0, a.w0, src, r); gather_seg(a.s1, a.d1, a.w1, src, r);
+  gather_seg(a.s2, a.d2, a.w2, src, r); gather_seg(a.s3, a.d3, a.w3, src, r);
+  gather_seg(a.s4, a.d4, a.w4, src, r); gather_seg(a.s5, a.d5, a.w5, src, r);
+  gather_seg(a.s6, a.d6, a.w6, src, r); gather_seg(a.s7, a.d7, a.w7, src, r);
+}
+
+// mean and UNBIASED standard deviation of the minibatch advantages (ppo_policy.py:195-197: adv.mean(), adv.std())
+__global__ __launch_bounds__(256) void egx_adv_stats_kernel(const float* __restrict__ adv, int n, float* __restrict__ out) {
+  __shared__ double s1[256], s2[256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { const double v = adv[i]; a += v; b += v * v; }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) { s1[threadIdx.x] += s1[threadIdx.x + st]; s2[threadIdx.x] += s2[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mean = s1[0] / n;
+    double var = 0.0;
+    for (int i = 0; i < n; ++i) { const double dlt = adv[i] - mean; var += dlt * dlt; }  // two-pass: n is a minibatch (<= a few k)
+    out[0] = (float)mean;
+    out[1] = (n > 1) ? (float)sqrt(var / (n - 1)) : nanf("");
+  }
+}
+
 extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* value, const float* act, const float* adv,
                             const float* ret, const float* logp_old, const float* adv_stats, const float* scale,
                             float adv_eps, float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef,
@@ -190,6 +234,32 @@ extern "C" int egx_act_bwd_colsum(const float* dy, const float* a, float* g, flo
   splits = egx_ceil_div(num_rows, rpb);
   hipLaunchKernelGGL(egx_act_bwd_colsum_kernel, dim3(strips, splits), dim3(256), 0, static_cast<hipStream_t>(stream_), dy, a, g,
                      db_accum, num_rows, width, rpb, act, slope);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_gather_rows(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
+                               float* const* dst, void* stream_) {
+  EGX_REQUIRE(idx && src && width && dst && num_rows > 0 && num_tensors > 0 && num_tensors <= 8, "bad arguments");
+  GatherArgs a;
+  std::memset(&a, 0, sizeof(a));
+  const float** sp[8] = {&a.s0, &a.s1, &a.s2, &a.s3, &a.s4, &a.s5, &a.s6, &a.s7};
+  float** dp[8] = {&a.d0, &a.d1, &a.d2, &a.d3, &a.d4, &a.d5, &a.d6, &a.d7};
+  int* wp[8] = {&a.w0, &a.w1, &a.w2, &a.w3, &a.w4, &a.w5, &a.w6, &a.w7};
+  for (int t = 0; t < num_tensors; ++t) {
+    EGX_REQUIRE(src[t] && dst[t] && width[t] > 0, "null tensor or non-positive width");
+    *sp[t] = src[t]; *dp[t] = dst[t]; *wp[t] = width[t];
+  }
+  a.idx = reinterpret_cast<const long long*>(idx);
+  a.n = num_rows;
+  hipLaunchKernelGGL(egx_gather_rows_kernel, dim3(num_rows), dim3(256), 0, static_cast<hipStream_t>(stream_), a);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_adv_stats(const float* adv, int n, float* out_mean_std, void* stream_) {
+  EGX_REQUIRE(adv && out_mean_std && n > 0, "bad arguments");
+  hipLaunchKernelGGL(egx_adv_stats_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), adv, n, out_mean_std);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

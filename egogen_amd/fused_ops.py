@@ -125,3 +125,29 @@ def linear_act(x, lin: torch.nn.Linear, act="none", slope=0.01, res=None):
     if lin.weight.grad is None or lin.bias.grad is None:
         raise _lib.EgxError("linear_act needs pre-allocated gradient views (GAMMAPPOPolicy._ensure_flat_grads)")
     return LinearFn.apply(x, lin.weight, lin.bias, lin.weight.grad, lin.bias.grad, ACT_CODE[act], slope, res)
+
+
+def gather_rows(idx: torch.Tensor, srcs, out=None):
+    """dst[t][r] = src[t][idx[r]] for up to 8 dense fp32 tensors (leading dimension = rows) in ONE launch."""
+    import ctypes as C
+    lib = _lib.load()
+    n = int(idx.shape[0])
+    k = len(srcs)
+    srcs = [s if s.is_contiguous() else s.contiguous() for s in srcs]
+    if out is None:
+        out = [torch.empty((n,) + tuple(s.shape[1:]), dtype=torch.float32, device=s.device) for s in srcs]
+    widths = [int(s[0].numel()) for s in srcs]
+    sp = (C.c_void_p * k)(*[s.data_ptr() for s in srcs])
+    dp = (C.c_void_p * k)(*[o.data_ptr() for o in out])
+    wp = (C.c_int * k)(*widths)
+    _lib.check(lib.egx_gather_rows(_lib.ptr(idx), n, k, sp, wp, dp, _lib.current_stream_ptr()), "egx_gather_rows")
+    return out
+
+
+def adv_stats(adv: torch.Tensor) -> torch.Tensor:
+    """[mean, unbiased std] of a minibatch of advantages, one launch."""
+    lib = _lib.load()
+    out = torch.empty(2, dtype=torch.float32, device=adv.device)
+    _lib.check(lib.egx_adv_stats(_lib.ptr(adv.contiguous()), int(adv.numel()), _lib.ptr(out), _lib.current_stream_ptr()),
+               "egx_adv_stats")
+    return out

@@ -85,6 +85,7 @@ class GAMMAPPOPolicy(nn.Module):
         self._graph_cache: dict = {}
         self.use_update_graph = bool(_ignored.get("use_update_graph", False))
         self.use_fused_loss = bool(_ignored.get("use_fused_loss", True))
+        self._scale_cache = {}
         # dense layers of the update as LinearFn nodes (library GEMMs + fused activation / bias-gradient / accumulation
         # kernels).  Their weight gradients are ACCUMULATED into the flat buffer: callers zero it once per minibatch.
         self.use_fused_linear = bool(_ignored.get("use_fused_linear", True))
@@ -197,6 +198,15 @@ class GAMMAPPOPolicy(nn.Module):
     def _gather(self, batch: RolloutBatch, idx: torch.Tensor):
         N = batch.n * batch.A
         obs_all = batch.obs_flat()
+        if idx.is_cuda and self.use_fused_loss and all(v.dtype == torch.float32 for v in obs_all.values()):
+            from .fused_ops import gather_rows  # eight row gathers in one launch
+            st, ego, di, ti, act, adv, ret, lpo = gather_rows(idx, [
+                obs_all["state"].reshape(N, 804), obs_all["egosensing"].reshape(N, 64), obs_all["dist"].reshape(N, 1),
+                obs_all["time"].reshape(N, 1), batch.act.reshape(N, 128), batch.adv.reshape(N, 1), batch.returns.reshape(N, 1),
+                batch.logp_old.reshape(N, 1)])
+            n = idx.shape[0]
+            obs = {"state": st.reshape(n, 2, 402), "egosensing": ego.reshape(n, 2, 32), "dist": di.reshape(n), "time": ti.reshape(n)}
+            return obs, act, adv.reshape(n), ret.reshape(n), lpo.reshape(n)
         obs = {k: v.index_select(0, idx) for k, v in obs_all.items()}
         return (obs, batch.act.reshape(N, 128).index_select(0, idx), batch.adv.reshape(N).index_select(0, idx),
                 batch.returns.reshape(N).index_select(0, idx), batch.logp_old.reshape(N).index_select(0, idx))
@@ -206,7 +216,11 @@ class GAMMAPPOPolicy(nn.Module):
         loss, terms = self.minibatch_loss(obs, act, adv, ret, lpo, gstats)
         self._flat_grad.zero_()
         loss.backward()
-        log_out.copy_(torch.stack([terms[k].detach() for k in ("loss", "loss/clip", "loss/vf", "loss/ent", "loss/kld", "approx_kl")]))
+        packed = terms.get("_packed")
+        if packed is not None:  # the fused loss already holds the six terms in one tensor
+            log_out.copy_(packed)
+        else:
+            log_out.copy_(torch.stack([terms[k].detach() for k in ("loss", "loss/clip", "loss/vf", "loss/ent", "loss/kld", "approx_kl")]))
 
     def _clip_and_step(self):
         if self._grad_norm:
@@ -290,17 +304,21 @@ class GAMMAPPOPolicy(nn.Module):
         stats = None
         if self._norm_adv:
             if global_stats is None:
-                stats = torch.stack([adv.mean(), adv.std()])
+                from .fused_ops import adv_stats
+                stats = adv_stats(adv)
             else:
                 stats = torch.stack([global_stats[0], global_stats[1]]).float()
         if global_stats is None:
-            scale = torch.full((1,), 1.0 / n_local, dtype=torch.float32, device=dev)
+            scale = self._scale_cache.get((n_local, dev))
+            if scale is None:  # constant: built once, outside any graph capture
+                scale = torch.full((1,), 1.0 / n_local, dtype=torch.float32, device=dev)
+                self._scale_cache[(n_local, dev)] = scale
         else:
             scale = (1.0 / global_stats[2]).reshape(1).float()
         loss, terms = PPOLossFn.apply(mu, logvar, value, act, adv, returns, logp_old, stats, scale, _EPS, self.actor.min_logvar,
                                       self.actor.max_logvar, self._eps_clip, self._weight_vf, self._weight_ent)
         return loss, {"loss": terms[0], "loss/clip": terms[1], "loss/vf": terms[2], "loss/ent": terms[3], "loss/kld": terms[4],
-                      "approx_kl": terms[5]}
+                      "approx_kl": terms[5], "_packed": terms}
 
     def learn(self, batch: RolloutBatch, batch_size: int, repeat: int) -> Dict[str, List[float]]:
         """ppo_policy.py:182-265.  `batch_size` is the GLOBAL minibatch size; each rank contributes batch_size/world."""

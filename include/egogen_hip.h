@@ -372,6 +372,15 @@ int egx_act_fwd(float* z, const float* res, float* out, int num_rows, int width,
 int egx_act_bwd_colsum(const float* dy, const float* a, float* g, float* db_accum, int num_rows, int width, int act,
                        float slope, void* stream);
 
+/* Minibatch assembly of GAMMAPPOPolicy.learn (ppo_policy.py:189-193: `for minibatch in batch.split(...)`, tianshou
+ * Batch indexing [upstream]): dst[t][r, :] = src[t][idx[r], :] for up to 8 dense row-major fp32 tensors in one launch.
+ * src / width / dst are HOST arrays of device pointers / row widths. */
+int egx_gather_rows(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
+                    float* const* dst, void* stream);
+
+/* Advantage normalisation statistics of one minibatch (ppo_policy.py:195-197): out = {mean, unbiased std}. */
+int egx_adv_stats(const float* adv, int n, float* out_mean_std, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
