@@ -138,6 +138,7 @@ SIGNATURES = {
     "egx_lbs_get_blend_mode": (C.c_int, []),
     "egx_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egx_adv_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "egx_track_episode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egx_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "egx_act_bwd_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                      C.c_void_p]),

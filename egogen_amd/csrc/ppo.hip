@@ -188,6 +188,30 @@ __global__ __launch_bounds__(256) void egx_adv_stats_kernel(const float* __restr
   }
 }
 
+// episode bookkeeping of the collector (tianshou Collector.collect [upstream]: running return / length per env, sums over
+// the episodes that finished in this step); single workgroup, A is a few hundred
+__global__ __launch_bounds__(256) void egx_track_episode_kernel(const float* __restrict__ rew, const int* __restrict__ term, int A,
+                                                                float* __restrict__ ep_ret, float* __restrict__ ep_len,
+                                                                float* __restrict__ done_sums /* ret, len, count */) {
+  __shared__ float s[3][256];
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < A; i += 256) {
+    const float r = ep_ret[i] + rew[i], l = ep_len[i] + 1.f;
+    const bool d = term[i] != 0;
+    if (d) { a += r; b += l; c += 1.f; }
+    ep_ret[i] = d ? 0.f : r;
+    ep_len[i] = d ? 0.f : l;
+  }
+  s[0][threadIdx.x] = a; s[1][threadIdx.x] = b; s[2][threadIdx.x] = c;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int k = 0; k < 3; ++k) s[k][threadIdx.x] += s[k][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) done_sums[threadIdx.x] += s[threadIdx.x][0];
+}
+
 extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* value, const float* act, const float* adv,
                             const float* ret, const float* logp_old, const float* adv_stats, const float* scale,
                             float adv_eps, float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef,
@@ -260,6 +284,15 @@ extern "C" int egx_gather_rows(const int64_t* idx, int num_rows, int num_tensors
 extern "C" int egx_adv_stats(const float* adv, int n, float* out_mean_std, void* stream_) {
   EGX_REQUIRE(adv && out_mean_std && n > 0, "bad arguments");
   hipLaunchKernelGGL(egx_adv_stats_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), adv, n, out_mean_std);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_track_episode(const float* rew, const int32_t* term, int num_agents, float* ep_ret, float* ep_len,
+                                 float* done_sums, void* stream_) {
+  EGX_REQUIRE(rew && term && ep_ret && ep_len && done_sums && num_agents > 0, "bad arguments");
+  hipLaunchKernelGGL(egx_track_episode_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), rew, term, num_agents,
+                     ep_ret, ep_len, done_sums);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

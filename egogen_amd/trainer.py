@@ -35,9 +35,8 @@ class Collector:
         dev = env.dev
         self.ep_ret = torch.zeros(self.A, device=dev)
         self.ep_len = torch.zeros(self.A, device=dev)
-        self.done_ret = torch.zeros((), device=dev)
-        self.done_len = torch.zeros((), device=dev)
-        self.done_cnt = torch.zeros((), device=dev)
+        self._done = torch.zeros(3, device=dev)  # sum of returns, sum of lengths, count of the finished episodes
+        self.done_ret, self.done_len, self.done_cnt = self._done[0], self._done[1], self._done[2]
         self._pol_out: dict = {}
         self._batches: Dict[int, RolloutBatch] = {}
         self.obs = None
@@ -51,11 +50,15 @@ class Collector:
         self.reset_stat()
 
     def reset_stat(self):
-        self.done_ret.zero_()
-        self.done_len.zero_()
-        self.done_cnt.zero_()
+        self._done.zero_()
 
     def _track(self, rew, term):
+        if rew.is_cuda and rew.dtype == torch.float32 and term.dtype == torch.int32:
+            from . import _lib
+            lib = _lib.load()
+            _lib.check(lib.egx_track_episode(_lib.ptr(rew), _lib.ptr(term), self.A, _lib.ptr(self.ep_ret), _lib.ptr(self.ep_len),
+                                             _lib.ptr(self._done), _lib.current_stream_ptr()), "egx_track_episode")
+            return
         self.ep_ret += rew
         self.ep_len += 1
         d = term.to(self.ep_ret.dtype)
@@ -91,12 +94,9 @@ class Collector:
             self._batches[n_vec_steps] = b
         for t in range(n_vec_steps):
             b.store_obs(t, self.obs)
-            out = self.policy(self.obs, out=self._pol_out)
-            b.act[t].copy_(out["act"])
-            b.mu[t].copy_(out["mu"])
-            b.logvar[t].copy_(out["logvar"])
-            b.logp_old[t].copy_(out["logp"])
-            b.values[t].copy_(out["value"])
+            # the policy writes straight into the rollout slot of this step
+            out = self.policy(self.obs, out={"act": b.act[t], "mu": b.mu[t], "logvar": b.logvar[t], "logp": b.logp_old[t],
+                                             "value": b.values[t]})
             if self._episodes is not None:
                 self._wpath_before = self.env.wpath.cpu()
             if self._episodes is not None:

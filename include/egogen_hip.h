@@ -381,6 +381,12 @@ int egx_gather_rows(const int64_t* idx, int num_rows, int num_tensors, const flo
 /* Advantage normalisation statistics of one minibatch (ppo_policy.py:195-197): out = {mean, unbiased std}. */
 int egx_adv_stats(const float* adv, int n, float* out_mean_std, void* stream);
 
+/* Episode statistics of the training collector (tianshou Collector.collect [upstream], crowd_ppo/main_ppo.py:177-183):
+ * ep_ret += rew, ep_len += 1; for finished agents the totals are added to done_sums = {sum of returns, sum of lengths,
+ * episode count} and the running values reset. */
+int egx_track_episode(const float* rew, const int32_t* term, int num_agents, float* ep_ret, float* ep_len, float* done_sums,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif
