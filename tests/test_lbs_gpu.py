@@ -63,6 +63,32 @@ def test_lbs_matches_oracle(V, A, T, blend_mode):
         assert max_abs(out2["markers"].cpu(), out["markers"].cpu()) < 3e-6
 
 
+@pytest.mark.parametrize("A,T", [(1, 1), (257, 1), (105, 20)])
+def test_lbs_ragged_batches(A, T, blend_mode):
+    """Single body, one body past a 256-body group, and 2100 bodies (>= 8 body groups: the XCD-partitioned item list with
+    a ragged last group) - picks and fused SDF counts against the oracle in both blend modes."""
+    from egogen_amd.body_model import SdfScene
+    from oracle.sdf import calc_sdf
+    from oracle.smplx_lbs import smplx_forward
+    V = 1000
+    bm, mk, feet, h, ob = _setup(V)
+    xb, betas = _poses(A, T, seed=A)
+    xb[:, 2] = 0.05
+    scene = synth.make_sdf_scene(32)
+    out = h.forward(xb.cuda(), betas.cuda(), T, sdf=SdfScene(scene))
+    torch.cuda.synchronize()
+    v, j = smplx_forward(ob, xb, betas.repeat_interleave(T, 0))
+    assert max_abs(out["joints"].cpu(), j) < 2e-5
+    assert max_abs(out["markers"].cpu(), v[:, torch.as_tensor(mk).long()]) < 2e-5
+    sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
+    s = calc_sdf(v, sd)
+    s[:, torch.as_tensor(feet).long()] = 0.0
+    ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
+    got = out["pene_count"].cpu().long()
+    assert ref.max() > 10
+    assert ((got - ref).abs() <= near).all(), (got - ref).abs().max()
+
+
 def test_lbs_fp64_oracle_agrees():
     """fp64 restatement vs the fp32 HIP path (SURVEY 8(c) invariant)."""
     from oracle.smplx_lbs import BodyModel, smplx_forward

@@ -231,3 +231,47 @@ def test_main_crowd_eval_entry_point(tmp_path):
     assert pk
     d = pickle.load(open(pk[0], "rb"))
     assert d["motion"][0]["blended_marker"].shape == (20, 67, 3) and d["wpath"].shape == (2, 3)
+
+
+def test_update_glue_kernels():
+    """egx_gather_rows / egx_adv_stats / egx_track_episode / egx_act_fwd / egx_act_bwd_colsum against torch."""
+    from egogen_amd import _lib
+    from egogen_amd.fused_ops import adv_stats, gather_rows
+    import ctypes as C
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    N, n = 300, 77
+    srcs = [torch.randn(N, w, generator=g).cuda() for w in (804, 64, 1, 1, 128, 1, 1, 1)]
+    idx = torch.randperm(N, generator=g)[:n].cuda()
+    out = gather_rows(idx, srcs)
+    for s_, o in zip(srcs, out):
+        assert torch.equal(o, s_.index_select(0, idx))
+    adv = (torch.randn(256, generator=g) * 3 + 0.7).cuda()
+    st = adv_stats(adv)
+    assert abs(float(st[0]) - float(adv.mean())) < 1e-6 and abs(float(st[1]) - float(adv.std())) < 1e-5
+    # episode bookkeeping
+    A = 37
+    rew = torch.randn(A, generator=g).cuda(); term = (torch.rand(A, generator=g) < 0.3).int().cuda()
+    ep_ret = torch.randn(A, generator=g).cuda(); ep_len = torch.randint(0, 9, (A,), generator=g).float().cuda()
+    done = torch.tensor([1.0, 2.0, 3.0]).cuda()
+    r0, l0 = ep_ret.clone(), ep_len.clone()
+    _lib.check(lib.egx_track_episode(_lib.ptr(rew), _lib.ptr(term), A, _lib.ptr(ep_ret), _lib.ptr(ep_len), _lib.ptr(done),
+                                     _lib.current_stream_ptr()), "egx_track_episode")
+    d = term.bool()
+    assert torch.allclose(done, torch.tensor([1.0, 2.0, 3.0]).cuda() + torch.stack([((r0 + rew) * d).sum(), ((l0 + 1) * d).sum(), d.sum().float()]), atol=1e-5)
+    assert torch.allclose(ep_ret, torch.where(d, torch.zeros_like(r0), r0 + rew)) and torch.allclose(ep_len, torch.where(d, torch.zeros_like(l0), l0 + 1))
+    # activation forward / backward + bias gradient, all four activation codes, with and without residual
+    M, W = 50, 72
+    for act, fn in ((0, lambda z: z), (1, torch.tanh), (2, torch.relu), (3, lambda z: torch.nn.functional.leaky_relu(z, 0.01))):
+        z = torch.randn(M, W, generator=g).cuda(); res = torch.randn(M, W, generator=g).cuda(); dy = torch.randn(M, W, generator=g).cuda()
+        zz = z.clone().requires_grad_(True)
+        ref = fn(zz) + res
+        ref.backward(dy)
+        a = z.clone(); outt = torch.empty_like(z)
+        _lib.check(lib.egx_act_fwd(_lib.ptr(a), _lib.ptr(res), _lib.ptr(outt), M, W, act, 0.01, _lib.current_stream_ptr()), "egx_act_fwd")
+        assert torch.allclose(outt, ref.detach(), atol=1e-6) and torch.allclose(a, fn(z), atol=1e-6)
+        gbuf = torch.empty_like(z); db = torch.full((W,), 0.5).cuda()
+        _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(dy), _lib.ptr(a), _lib.ptr(gbuf), _lib.ptr(db), M, W, act, 0.01,
+                                          _lib.current_stream_ptr()), "egx_act_bwd_colsum")
+        assert torch.allclose(gbuf, zz.grad, atol=1e-5)
+        assert torch.allclose(db, 0.5 + zz.grad.sum(0), atol=1e-4)
