@@ -139,6 +139,9 @@ SIGNATURES = {
     "egx_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egx_adv_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "egx_track_episode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egx_adamw_workspace_floats": (C.c_size_t, []),
+    "egx_adamw_clip_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float] + [C.c_double] * 5 +
+                            [C.c_void_p, C.c_void_p, C.c_void_p]),
     "egx_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "egx_act_bwd_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                      C.c_void_p]),

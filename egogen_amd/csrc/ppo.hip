@@ -212,6 +212,97 @@ __global__ __launch_bounds__(256) void egx_track_episode_kernel(const float* __r
   if (threadIdx.x < 3) done_sums[threadIdx.x] += s[threadIdx.x][0];
 }
 
+// ---- optimiser step over flat buffers: gradient-norm clip of a prefix + AdamW (torch.optim.AdamW semantics) ----------
+// pass 1: per-block partial sums of squares of g[0..n_clip) (double accumulation, fixed order -> deterministic); block 0
+// also advances the step counter, so that pass 2 (a later kernel on the same stream) reads the new value everywhere.
+__global__ __launch_bounds__(256) void egx_sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partials,
+                                                                float* __restrict__ step) {
+  __shared__ double red[256];
+  double a = 0.0;
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += stride) {
+    const float4 v = *reinterpret_cast<const float4*>(g + i);
+    a += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (size_t i = n & ~(size_t)3; i < n; ++i) a += (double)g[i] * g[i];
+    *step += 1.f;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = (float)red[0];
+}
+
+// pass 1b (one workgroup): total norm -> clip coefficient; bias corrections of the new step count
+__global__ __launch_bounds__(256) void egx_adamw_consts_kernel(const float* __restrict__ partials, int n_partials, int do_clip,
+                                                               float max_norm, double lr, double b1, double b2,
+                                                               const float* __restrict__ step, float* __restrict__ consts) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += 256) a += partials[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double t = (double)*step;
+    const float bc1 = (float)(1.0 - pow(b1, t)), bc2 = (float)(1.0 - pow(b2, t));
+    float coef = 1.f;
+    if (do_clip) coef = fminf(max_norm / ((float)sqrt(red[0]) + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
+    consts[0] = coef;
+    consts[1] = (float)(lr / bc1);
+    consts[2] = sqrtf(bc2);
+  }
+}
+
+// pass 2: AdamW on 4 elements per thread: decoupled weight decay, exp_avg lerp, exp_avg_sq, bias corrections - the arithmetic of torch's fused
+// multi-tensor AdamW functor (aten/src/ATen/native/cuda/fused_adam_utils.cuh [upstream torch]).
+__global__ __launch_bounds__(256) void egx_adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                             float* __restrict__ v, size_t n, size_t n_clip,
+                                                             const float* __restrict__ consts /* clip coef, step size, sqrt(bc2) */,
+                                                             double lr, double b1, double b2, double eps, double wd) {
+  const float coef = consts[0], step_size = consts[1], bc2s = consts[2];
+  const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  const int cnt = (int)((n - i0 < 4) ? (n - i0) : 4);
+  float gr[4], pv[4], mv[4], vv[4];
+  if (cnt == 4) {
+    *reinterpret_cast<float4*>(gr) = *reinterpret_cast<const float4*>(g + i0);
+    *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i0);
+    *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i0);
+    *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i0);
+  } else {
+    for (int e = 0; e < cnt; ++e) { gr[e] = g[i0 + e]; pv[e] = p[i0 + e]; mv[e] = m[i0 + e]; vv[e] = v[i0 + e]; }
+  }
+  const double omb1 = 1.0 - b1, omb2 = 1.0 - b2, lrwd = lr * wd;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < cnt) {
+      // operand types as in torch's functor: fp32 state, double hyper-parameters (the mixed expressions run in double)
+      float gg = gr[e];
+      if (i0 + e < n_clip) gg *= coef;
+      pv[e] = (float)((double)pv[e] - lrwd * (double)pv[e]);
+      mv[e] = (float)((double)mv[e] + omb1 * ((double)gg - (double)mv[e]));
+      vv[e] = (float)(b2 * (double)vv[e] + omb2 * (double)gg * (double)gg);
+      const float denom = (float)((double)(sqrtf(vv[e]) / bc2s) + eps);
+      pv[e] -= step_size * mv[e] / denom;
+    }
+  }
+  if (cnt == 4) {
+    *reinterpret_cast<float4*>(p + i0) = *reinterpret_cast<const float4*>(pv);
+    *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<const float4*>(mv);
+    *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<const float4*>(vv);
+  } else {
+    for (int e = 0; e < cnt; ++e) { p[i0 + e] = pv[e]; m[i0 + e] = mv[e]; v[i0 + e] = vv[e]; }
+  }
+}
+
 extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* value, const float* act, const float* adv,
                             const float* ret, const float* logp_old, const float* adv_stats, const float* scale,
                             float adv_eps, float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef,
@@ -293,6 +384,25 @@ extern "C" int egx_track_episode(const float* rew, const int32_t* term, int num_
   EGX_REQUIRE(rew && term && ep_ret && ep_len && done_sums && num_agents > 0, "bad arguments");
   hipLaunchKernelGGL(egx_track_episode_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), rew, term, num_agents,
                      ep_ret, ep_len, done_sums);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" size_t egx_adamw_workspace_floats(void) { return 1024 + 8; }
+
+extern "C" int egx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_clip,
+                                   float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                   float* step, float* workspace, void* stream_) {
+  EGX_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && workspace && n > 0 && n_clip <= n, "bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int nb = 1024;
+  const bool do_clip = max_norm > 0.f && n_clip > 0;
+  hipLaunchKernelGGL(egx_sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, grad, do_clip ? n_clip : (size_t)0, workspace, step);
+  hipLaunchKernelGGL(egx_adamw_consts_kernel, dim3(1), dim3(256), 0, st, workspace, nb, do_clip ? 1 : 0, max_norm, lr, beta1, beta2,
+                     step, workspace + nb);
+  const size_t blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(egx_adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, n_clip,
+                     workspace + nb, lr, beta1, beta2, eps, weight_decay);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

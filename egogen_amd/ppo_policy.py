@@ -9,6 +9,7 @@ of one flat gradient buffer for data parallelism (one process per GPU).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -82,6 +83,7 @@ class GAMMAPPOPolicy(nn.Module):
         self._seed = seed
         self._perm_gen = torch.Generator().manual_seed(seed)
         self._flat_grad: Optional[torch.Tensor] = None
+        self._layout = None
         self._graph_cache: dict = {}
         self.use_update_graph = bool(_ignored.get("use_update_graph", False))
         self.use_fused_loss = bool(_ignored.get("use_fused_loss", True))
@@ -89,6 +91,9 @@ class GAMMAPPOPolicy(nn.Module):
         # dense layers of the update as LinearFn nodes (library GEMMs + fused activation / bias-gradient / accumulation
         # kernels).  Their weight gradients are ACCUMULATED into the flat buffer: callers zero it once per minibatch.
         self.use_fused_linear = bool(_ignored.get("use_fused_linear", True))
+        # clip + AdamW as two kernels over flat buffers (CUDA, single-group AdamW); see _flat_optimizer_ready
+        self.use_flat_optimizer = bool(_ignored.get("use_flat_optimizer", os.environ.get("EGX_FLAT_OPTIMIZER", "1") != "0"))
+        self._flat_opt_state = None
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     # ---- rollout side (HIP) -------------------------------------------------------------------------
@@ -154,18 +159,28 @@ class GAMMAPPOPolicy(nn.Module):
     def entropy(sigma):
         return (0.5 + _LOG_SQRT_2PI + torch.log(sigma)).sum(-1)
 
+    def _flat_layout(self):
+        """(parameter, offset, numel) in optimiser order, every tensor starting on a 256-byte boundary (library GEMMs pick
+        slower kernels for operands that are only 4-byte aligned); the padding elements stay zero in every flat buffer."""
+        if self._layout is None:
+            params = [p for g in self.optim.param_groups for p in g["params"]]
+            off, lay = 0, []
+            for p in params:
+                lay.append((p, off, p.numel()))
+                off += (p.numel() + 63) // 64 * 64
+            self._layout, self._layout_total = lay, off
+        return self._layout
+
     def _ensure_flat_grads(self):
-        """One flat fp32 gradient buffer (13 168 001 floats) aliased by every .grad: a single in-place all-reduce."""
-        params = [p for g in self.optim.param_groups for p in g["params"]]
+        """One flat fp32 gradient buffer (13 168 001 floats + alignment padding) aliased by every .grad: a single
+        in-place all-reduce."""
+        lay = self._flat_layout()
         if self._flat_grad is None:
-            total = sum(p.numel() for p in params)
-            self._flat_grad = torch.zeros(total, dtype=torch.float32, device=params[0].device)
-        off = 0
+            self._flat_grad = torch.zeros(self._layout_total, dtype=torch.float32, device=lay[0][0].device)
         base = self._flat_grad.data_ptr()
-        for p in params:  # (re-)attach: zero_grad(set_to_none=True) or a foreign backward may have replaced a view
+        for p, off, n in lay:  # (re-)attach: zero_grad(set_to_none=True) or a foreign backward may have replaced a view
             if p.grad is None or p.grad.data_ptr() != base + 4 * off:
-                p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
+                p.grad = self._flat_grad[off:off + n].view_as(p)
 
     def minibatch_loss(self, obs, act, adv, returns, logp_old, global_stats=None):
         """ppo_policy.py:189-241 for one minibatch.  With data parallelism `global_stats` = (mean, std, n_global):
@@ -223,9 +238,69 @@ class GAMMAPPOPolicy(nn.Module):
             log_out.copy_(torch.stack([terms[k].detach() for k in ("loss", "loss/clip", "loss/vf", "loss/ent", "loss/kld", "approx_kl")]))
 
     def _clip_and_step(self):
+        if self.use_flat_optimizer and self._flat_opt_state == "ready":
+            g = self.optim.param_groups[0]
+            lib = _lib.load()
+            b1, b2 = g["betas"]
+            rc = lib.egx_adamw_clip_step(_lib.ptr(self._flat_p), _lib.ptr(self._flat_grad), _lib.ptr(self._flat_m), _lib.ptr(self._flat_v),
+                                         self._flat_p.numel(), self._n_clip, float(self._grad_norm or 0.0), float(g["lr"]), float(b1),
+                                         float(b2), float(g["eps"]), float(g["weight_decay"]), _lib.ptr(self._step_t),
+                                         _lib.ptr(self._adamw_ws), _lib.current_stream_ptr())
+            _lib.check(rc, "egx_adamw_clip_step")
+            return
         if self._grad_norm:
             nn.utils.clip_grad_norm_(self._actor_critic.parameters(), max_norm=self._grad_norm)
         self.optim.step()
+
+    def _flat_optimizer_ready(self) -> bool:
+        """Flat-buffer AdamW (egx_adamw_clip_step): parameters, exp_avg and exp_avg_sq of the single AdamW group are
+        re-pointed to views of three flat buffers (values preserved), `optim.state` keeps its torch layout, so
+        optim.state_dict() / load_state_dict() and the checkpoint format are unchanged.  Falls back to torch when the
+        optimiser is not a plain single-group AdamW or the clipped parameters are not a prefix of its parameter list."""
+        if self._flat_opt_state == "unsupported":
+            return False
+        opt = self.optim
+        params = [p for g in opt.param_groups for p in g["params"]]
+        if self._flat_opt_state is None:
+            ok = (isinstance(opt, torch.optim.AdamW) and len(opt.param_groups) == 1 and not opt.param_groups[0].get("amsgrad", False)
+                  and not opt.param_groups[0].get("maximize", False) and all(p.is_cuda and p.dtype == torch.float32 for p in params))
+            clip = list(self._actor_critic.parameters())
+            ok = ok and len(clip) <= len(params) and all(a is b for a, b in zip(clip, params))
+            if not ok:
+                self._flat_opt_state = "unsupported"
+                return False
+            dev = params[0].device
+            lay = self._flat_layout()
+            total = self._layout_total
+            self._flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._step_t = torch.zeros((), dtype=torch.float32, device=dev)
+            self._adamw_ws = torch.zeros(int(_lib.load().egx_adamw_workspace_floats()), dtype=torch.float32, device=dev)
+            # the clipped parameters are a prefix of the layout: clip length = start of the first unclipped tensor
+            self._n_clip = lay[len(clip)][1] if len(clip) < len(lay) else total
+            with torch.no_grad():
+                for p, off, n in lay:
+                    self._flat_p[off:off + n].copy_(p.detach().reshape(-1))
+                    p.data = self._flat_p[off:off + n].view_as(p)
+            self._flat_opt_state = "ready"
+            self._graph_cache.clear()  # parameter storage moved
+        # (re-)adopt the optimiser state: first use, or optim.load_state_dict() replaced the tensors
+        st0 = opt.state.get(params[0], {})
+        if st0.get("exp_avg") is None or st0["exp_avg"].data_ptr() != self._flat_m.data_ptr():
+            with torch.no_grad():
+                for p, off, n in self._flat_layout():
+                    st = opt.state[p]
+                    mv, vv = self._flat_m[off:off + n].view_as(p), self._flat_v[off:off + n].view_as(p)
+                    if torch.is_tensor(st.get("exp_avg")):
+                        mv.copy_(st["exp_avg"]); vv.copy_(st["exp_avg_sq"])
+                    else:
+                        mv.zero_(); vv.zero_()
+                    if "step" in st and p is params[0]:
+                        self._step_t.fill_(float(st["step"]))
+                    st["exp_avg"], st["exp_avg_sq"], st["step"] = mv, vv, self._step_t
+            self._graph_cache.clear()
+        return True
 
     def _adv_moments(self, batch, idx, out):
         adv = batch.adv.reshape(-1).index_select(0, idx).double()
@@ -324,6 +399,8 @@ class GAMMAPPOPolicy(nn.Module):
         """ppo_policy.py:182-265.  `batch_size` is the GLOBAL minibatch size; each rank contributes batch_size/world."""
         self.train()
         self._ensure_flat_grads()
+        if self.use_flat_optimizer and batch.act.is_cuda:
+            self._flat_optimizer_ready()  # (re-)points parameters / optimiser state BEFORE anything is captured
         ws = self.world_size
         N = batch.n * batch.A
         dev = batch.act.device

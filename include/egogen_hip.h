@@ -387,6 +387,17 @@ int egx_adv_stats(const float* adv, int n, float* out_mean_std, void* stream);
 int egx_track_episode(const float* rew, const int32_t* term, int num_agents, float* ep_ret, float* ep_len, float* done_sums,
                       void* stream);
 
+/* One optimiser step of GAMMAPPOPolicy.learn (ppo_policy.py:243-247: clip_grad_norm_ over the actor+critic parameters,
+ * optim.step() with the AdamW of main_ppo.py:134) over FLAT fp32 buffers of n elements: the gradient norm of the first
+ * n_clip elements is clipped to max_norm (skipped when max_norm <= 0), then AdamW with decoupled weight decay and bias
+ * correction (torch.optim.AdamW arithmetic [upstream torch]) updates param / exp_avg / exp_avg_sq in place.  `step` is a
+ * device scalar holding the number of steps taken so far; it is incremented by the call.  workspace: device floats,
+ * egx_adamw_workspace_floats() of them.  grad is left unscaled.  Hyper-parameters are doubles, as torch passes them. */
+size_t egx_adamw_workspace_floats(void);
+int egx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_clip,
+                        float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay, float* step,
+                        float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

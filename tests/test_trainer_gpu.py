@@ -275,3 +275,39 @@ def test_update_glue_kernels():
                                           _lib.current_stream_ptr()), "egx_act_bwd_colsum")
         assert torch.allclose(gbuf, zz.grad, atol=1e-5)
         assert torch.allclose(db, 0.5 + zz.grad.sum(0), atol=1e-4)
+
+
+def test_flat_adamw_clip_matches_torch():
+    """egx_adamw_clip_step (flat buffers, clip of the actor+critic prefix) against clip_grad_norm_ + torch.optim.AdamW
+    over three steps, and the optimiser state_dict keeps torch's layout."""
+    import copy
+    from egogen_amd import setup_world as sw
+
+    class _A(_Args):
+        update_graph = False
+    pol = sw.build_policy(_A())
+    ref = sw.build_policy(_A())   # same seed -> identical initial parameters
+    ref.use_flat_optimizer = False
+    pol.use_flat_optimizer = True
+    pol._ensure_flat_grads(); ref._ensure_flat_grads()
+    assert pol._flat_optimizer_ready()
+    g = torch.Generator().manual_seed(1)
+    for step in range(3):
+        for (pp, off, n), (rp, roff, _) in zip(pol._flat_layout(), ref._flat_layout()):  # padding stays zero
+            gi = (torch.randn(n, generator=g) * (10.0 if step == 1 else 0.001)).cuda()  # clipped and unclipped steps
+            pol._flat_grad[off:off + n].copy_(gi); ref._flat_grad[roff:roff + n].copy_(gi)
+        pol._clip_and_step(); ref._clip_and_step()
+        for (k, a), (_, b) in zip(pol.named_parameters(), ref.named_parameters()):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-8), (step, k, float((a - b).abs().max()))
+    sd = pol.optim.state_dict()
+    sr = ref.optim.state_dict()
+    assert sd["state"].keys() == sr["state"].keys()
+    for i in sd["state"]:
+        assert set(sd["state"][i].keys()) == set(sr["state"][i].keys())
+        assert float(sd["state"][i]["step"]) == float(sr["state"][i]["step"]) == 3.0
+        a, b = sd["state"][i]["exp_avg_sq"], sr["state"][i]["exp_avg_sq"]
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-12), (i, float(((a - b).abs() / (b.abs() + 1e-12)).max()), float(b.abs().max()))
+    # loading a torch-layout state back re-adopts it into the flat buffers
+    pol.optim.load_state_dict(copy.deepcopy(sr))
+    assert pol._flat_optimizer_ready()
+    assert float(pol._step_t) == 3.0 and pol.optim.state[next(iter(pol.optim.param_groups[0]["params"]))]["exp_avg"].data_ptr() == pol._flat_m.data_ptr()
