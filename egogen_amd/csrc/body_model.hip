@@ -260,9 +260,7 @@ struct LbsParams {
   const float* xb;     // transl = xb[b*93 + 0..2]
   int B, V, NVT, NW, NP, fpa;
   int nbg;             // body groups (256 bodies each)
-  int set_mode;
   int bg_block;        // body groups per L2 block of the item order (bf16x3 kernel)
-  long long phase_delay;  // shader cycles the second wave set waits before its first item (half an MFMA phase)
   int dbg;             // development ablations (EGX_LBS_DBG): 1 = skip the epilogue, 2 = skip the MFMA loop
   float* verts;        // [B][V][3] or null
   float* picked;       // [B][NP][3] or null
@@ -275,11 +273,12 @@ struct LbsParams {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(float a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(f32x2{a, a}, b, c); }
 
-// Persistent workgroups, one per CU, eight waves = two wave SETS that share the four SIMDs (wave w and w+4 sit on the
-// same SIMD).  Each set walks its own stream of work items (vertex tile x 256 bodies: 4 waves x 64 bodies); set 1 starts
-// half an MFMA phase late, so one wave of every SIMD is in its epilogue (skinning, SDF, picks: VALU + dependent loads,
-// matrix pipe untouched) while the other runs its MFMA loop.  Equal per-item work keeps the two sets in anti-phase for
-// the whole launch; nothing synchronises across waves (per-wave LDS metadata, no barriers).
+// fp32-MFMA variant (blend mode 0 and every vertex-writing call): persistent workgroups, one per CU, eight waves = two
+// SETS of four waves; each set walks its own stream of work items (vertex tile x 256 bodies: 4 waves x 64 bodies), so
+// one wave of a SIMD can wait for its operand burst while the other issues MFMAs.  Nothing synchronises across waves
+// (per-wave LDS metadata, no barriers).  The fp32 MFMA shares the fp32 VALU lanes (scripts/ubench/mfma_valu.hip), so here
+// the epilogue's VALU work adds to the MFMA time whatever the relative phase of the two sets (a phase offset between
+// them was tried and changes nothing).
 constexpr int LBS_META_BYTES = 7680;                 // s_W[55*32] f32, s_jl[56], s_slot[32], masks[4], s_cnt[64] (16-byte multiple)
 constexpr int LBS_VERT_BYTES = 32 * 97 * 4;          // per-wave transpose buffer of the vertex-writing variants
 constexpr int LBS_QCAP = 640;                        // entries of the per-wave queue of undecided SDF points (>= 512 + 64)
@@ -582,9 +581,7 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
   constexpr int NB = LBS_NB;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // which waves share a SIMD is a property of the dispatcher; set_mode picks the pairing
-  const int set = (p.set_mode == 0) ? (wave >> 2) : (p.set_mode == 1) ? (wave & 1) : ((wave >> 1) & 1);
-  const int w4 = (p.set_mode == 0) ? (wave & 3) : (p.set_mode == 1) ? (wave >> 1) : ((wave & 1) | ((wave >> 2) << 1));
+  const int set = wave >> 2, w4 = wave & 3;  // two independent sets of four waves, each walking its own item stream
   char* my = smem_raw + wave * (LBS_META_BYTES + (WRITE_VERTS ? LBS_VERT_BYTES : (DO_SDF ? LBS_QCAP * 16 : 0)));
   LbsWave w = lbs_wave_init<WRITE_VERTS, DO_SDF>(my, lane);
   // work streams.  With >= 8 body groups every XCD (block id % 8) owns a contiguous chunk of body groups, so their packed
@@ -603,10 +600,6 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
     stream = blockIdx.x * 2 + set;
   }
   const int n_items = p.NVT * nper;
-  if (set == 1 && p.phase_delay > 0 && stream < n_items) {
-    const long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < p.phase_delay) __builtin_amdgcn_s_sleep(16);
-  }
   for (int item = stream; item < n_items; item += n_streams) {
     const int vt = item / nper, bg = bg_lo + item % nper;
     const int bt0 = bg * 8 + w4 * NB;  // first 32-body tile of this wave
@@ -1110,7 +1103,6 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     }
     // one persistent workgroup per CU (8 waves = 2 per SIMD); the attribute raises the dynamic-LDS cap once
     static int num_cu = 0;
-    static long long phase_delay = 0;
     constexpr size_t lds_meta = (size_t)8 * LBS_META_BYTES, lds_verts = (size_t)8 * (LBS_META_BYTES + LBS_VERT_BYTES),
                      lds_sdf = (size_t)8 * (LBS_META_BYTES + LBS_QCAP * 16);
     if (num_cu == 0) {
@@ -1126,18 +1118,11 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sdf));
       EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<false, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_meta));
-      const char* e = getenv("EGX_LBS_PHASE_DELAY");
-      phase_delay = e ? atoll(e) : (long long)KSTEPS * 3 * 2 * 64 / 2;  // half of one wave's MFMA issue time
       num_cu = prop.multiProcessorCount;
     }
-    p.phase_delay = phase_delay;
     {
       const char* e = getenv("EGX_LBS_BG_BLOCK");
       p.bg_block = e ? atoi(e) : 2;
-    }
-    {
-      const char* e = getenv("EGX_LBS_SET_MODE");
-      p.set_mode = e ? atoi(e) : 0;
     }
     const int n_items = p.nbg * m->NVT;
     const int grid = std::max(1, std::min(num_cu, (n_items + 1) / 2));
