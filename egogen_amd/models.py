@@ -16,6 +16,7 @@ every rollout-time forward goes through libegogen_hip.so and raises if tensors a
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -285,6 +286,18 @@ class ActorCritic(nn.Module):
             self.shared_net = shared_net
 
 
+_TWO_STREAM_UPDATE = os.environ.get("EGX_TWO_STREAM_UPDATE", "1") == "1"
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[device] = s
+    return s
+
+
 def _gru_last_fused(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
     """nn.GRU over x[b,T,in] from a zero state, last hidden state.  The input products of all T steps are ONE GEMM
     (each weight is used once per minibatch: its gradient is written by a single accumulate-GEMM), the gate math is the
@@ -321,12 +334,33 @@ def fused_update_forward(shared_net: "GAMMAPolicyBase", actor: "GAMMAActor", cri
     (models_policy_ppo.py:287-350).  Returns mu[b,128], raw logvar[b,128], value[b]."""
     from .fused_ops import posenc_dist_time
     nb = obs["state"].shape[0]
-    hx = _gru_last_fused(shared_net.x_enc, obs["state"].float())
-    he = _gru_last_fused(shared_net.ego_enc, obs["egosensing"].float())
+    if _TWO_STREAM_UPDATE:  # the two encoders are independent as well
+        cur = torch.cuda.current_stream()
+        side = _side_stream(obs["state"].device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            he = _gru_last_fused(shared_net.ego_enc, obs["egosensing"].float())
+        hx = _gru_last_fused(shared_net.x_enc, obs["state"].float())
+        cur.wait_stream(side)
+    else:
+        hx = _gru_last_fused(shared_net.x_enc, obs["state"].float())
+        he = _gru_last_fused(shared_net.ego_enc, obs["egosensing"].float())
     pe = posenc_dist_time(obs["dist"].reshape(nb).float(), obs["time"].reshape(nb).float())
     h = torch.cat([hx, he, pe], dim=-1)
-    zp = _mlpblock_fused(actor.pnet, h)
-    value = _mlpblock_fused(critic.vnet, h).flatten()
+    if _TWO_STREAM_UPDATE:
+        # actor and critic heads are independent given h: run the critic on a side stream (forked / joined around it;
+        # inside a graph capture this becomes a parallel branch, and autograd replays each backward node on the stream of
+        # its forward) - two half-filling GEMM streams share the chip instead of running back to back
+        cur = torch.cuda.current_stream()
+        side = _side_stream(h.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            value = _mlpblock_fused(critic.vnet, h).flatten()
+        zp = _mlpblock_fused(actor.pnet, h)
+        cur.wait_stream(side)
+    else:
+        zp = _mlpblock_fused(actor.pnet, h)
+        value = _mlpblock_fused(critic.vnet, h).flatten()
     return zp[:, :actor.z_dim], zp[:, actor.z_dim:], value
 
 
