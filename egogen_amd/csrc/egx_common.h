@@ -60,11 +60,21 @@ __device__ __forceinline__ void egx_sdf_voxel_coords(const SdfDev& s, float x, f
   pz = fminf(fmaxf(pz, 0.f), (float)(s.d2 - 1));
 }
 
-// {min,max} bracket of the 4^3 block that holds clamped voxel coordinates (px,py,pz) (see egx_sdf_coarse_sign)
+// {min,max} bracket of the samples the interpolation at clamped voxel coordinates (px,py,pz) can touch: the 4^3 block's
+// footprint, or - for a point clamped onto the first / last sample plane of an axis (outside the cube or exactly on that
+// plane: the neighbouring layer has weight exactly 0 or is dropped) - the footprint inside that single layer (face tables
+// behind the block table, sdf.hip).  See egx_sdf_coarse_sign.
 __device__ __forceinline__ float2 egx_sdf_coarse_at(const SdfDev& s, float px, float py, float pz) {
   // clamped to [0, d-1]: truncation is floor; 32-bit index keeps the address arithmetic off the 64-bit VALU paths
   const unsigned ix = (unsigned)px >> 2, iy = (unsigned)py >> 2, iz = (unsigned)pz >> 2;
-  const unsigned idx = (ix * (unsigned)s.c1 + iy) * (unsigned)s.c2 + iz;
+  const unsigned c0 = (unsigned)s.c0, c1 = (unsigned)s.c1, c2 = (unsigned)s.c2;
+  const unsigned n_blk = c0 * c1 * c2, n_x = c1 * c2, n_y = c0 * c2, n_z = c0 * c1;
+  const bool xl = px == 0.f, xh = px == (float)(s.d0 - 1), yl = py == 0.f, yh = py == (float)(s.d1 - 1),
+             zl = pz == 0.f, zh = pz == (float)(s.d2 - 1);
+  unsigned idx = (ix * c1 + iy) * c2 + iz;
+  if (xl | xh) idx = n_blk + (xh ? n_x : 0u) + iy * c2 + iz;
+  if (yl | yh) idx = n_blk + 2u * n_x + (yh ? n_y : 0u) + ix * c2 + iz;
+  if (zl | zh) idx = n_blk + 2u * n_x + 2u * n_y + (zh ? n_z : 0u) + ix * c1 + iy;
   return s.coarse[idx];
 }
 

@@ -81,7 +81,10 @@ typedef struct egx_sdf_grid {
 
 /* Acceleration table for the penetration COUNT of egx_lbs_forward: {min,max} of the fine samples each 4x4x4 block's
  * interpolation footprint can touch.  Trilinear interpolation is a convex combination, so a block whose bracket does not
- * contain 0 decides `calc_sdf < 0` exactly without gathering from the 64 MiB grid. */
+ * contain 0 decides `calc_sdf < 0` exactly without gathering from the 64 MiB grid.  Six face tables follow the block table:
+ * a point that border clamping (grid_sample padding_mode="border", utils.py:75-81) puts onto the first / last sample plane
+ * of an axis only touches samples of that plane, so it is bracketed over the plane alone - bodies outside the cube are
+ * decided without gathers as well. */
 size_t egx_sdf_coarse_bytes(int d0, int d1, int d2);
 int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream);
 

@@ -82,7 +82,7 @@ def test_lbs_ragged_batches(A, T, blend_mode):
     assert max_abs(out["markers"].cpu(), v[:, torch.as_tensor(mk).long()]) < 2e-5
     sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
     s = calc_sdf(v, sd)
-    s[:, torch.as_tensor(feet).long()] = 0.0
+    s[:, torch.as_tensor(feet).long()] = 1.0  # feet are excluded: neither counted nor "near zero"
     ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
     got = out["pene_count"].cpu().long()
     assert ref.max() > 10
@@ -120,7 +120,7 @@ def test_lbs_sdf_fused_counts(blend_mode):
     vw = torch.einsum("bij,btpj->btpi", R0, v.reshape(A, T, V, 3)) + T0[:, None, None, :]
     sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
     s = calc_sdf(vw.reshape(A * T, V, 3), sd)
-    s[:, torch.as_tensor(feet).long()] = 0.0
+    s[:, torch.as_tensor(feet).long()] = 1.0  # feet are excluded: neither counted nor "near zero"
     ref = s.lt(0).sum(-1)
     got = out["pene_count"].cpu().long()
     assert ref.max() > 50, "test should exercise penetration"
@@ -133,6 +133,34 @@ def test_lbs_sdf_fused_counts(blend_mode):
     assert ((got2 - ref).abs() <= near).all(), (got2 - ref).abs().max()
     if blend_mode == "f32":
         assert torch.equal(out2["pene_count"], out["pene_count"])
+
+
+def test_lbs_sdf_counts_outside_grid(blend_mode):
+    """Bodies partly or completely outside the SDF cube (border clamping; face brackets of the coarse table): counts
+    still equal the oracle's calc_sdf on the clamped coordinates."""
+    from egogen_amd.body_model import SdfScene
+    from oracle.sdf import calc_sdf
+    from oracle.smplx_lbs import smplx_forward
+    V, A, T = 1000, 12, 4
+    bm, mk, feet, h, ob = _setup(V)
+    xb, betas = _poses(A, T, seed=21)
+    scene = synth.make_sdf_scene(48)  # border samples 1.7 cm beyond the walls: clamped points are strictly "inside"
+    R0 = torch.eye(3).repeat(A, 1, 1)
+    # agents 0-3 straddle a wall / the ceiling / the grid border, the others are far outside in every direction
+    T0 = torch.tensor([[3.6, 0, 0], [0, -3.8, 0.2], [0, 0, 3.9], [3.95, 3.95, 0.0], [9, 0, 0], [-9, 1, 1], [0, 12, 0], [1, -15, 2],
+                       [0, 0, 18.0], [0.5, 0.5, -6.0], [7, 7, 7], [-8, -8, -5]], dtype=torch.float32)
+    out = h.forward(xb.cuda(), betas.cuda(), T, sdf=SdfScene(scene), R0=R0.cuda(), T0=T0.cuda())
+    torch.cuda.synchronize()
+    v, _ = smplx_forward(ob, xb, betas.repeat_interleave(T, 0))
+    vw = v.reshape(A, T, V, 3) + T0[:, None, None, :]
+    sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
+    s = calc_sdf(vw.reshape(A * T, V, 3), sd)
+    s[:, torch.as_tensor(feet).long()] = 1.0  # feet are excluded: neither counted nor "near zero"
+    ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
+    got = out["pene_count"].cpu().long()
+    assert ref.reshape(A, T)[4:].min() == V - len(feet), "bodies outside the room count as penetrating everywhere"
+    assert near.reshape(A, T)[4:].max() == 0
+    assert ((got - ref).abs() <= near).all(), (got - ref).abs().max()
 
 
 def test_calc_sdf_kernel_matches_reference_golden():
