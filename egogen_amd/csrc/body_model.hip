@@ -655,9 +655,10 @@ __device__ __forceinline__ void lbs_blend_bf16x3(const LbsParams& p, f32x16 (&ac
   for (int q = 0; q < NB; ++q) fq[q] = p.feat3 + (size_t)min(bt0 + q, num_bt - 1) * KS3 * 3 * 64 + lane;
   for (int st = 0; st < LBS3_STAGES; ++st) {
     // burst: this wave's share of the stage's base pieces + its own feature pieces
-    bf16x8 ga[5], b[LBS3_STAGE_KS][3][NB];
+    constexpr int NGA = (LBS3_STAGE_PIECES + 3) / 4;
+    bf16x8 ga[NGA], b[LBS3_STAGE_KS][3][NB];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NGA; ++i) {
       const int piece = wave + 4 * i;
       if (piece < LBS3_STAGE_PIECES) ga[i] = dpv[(size_t)(st * LBS3_STAGE_PIECES + piece) * 64];
     }
@@ -672,7 +673,7 @@ __device__ __forceinline__ void lbs_blend_bf16x3(const LbsParams& p, f32x16 (&ac
     __builtin_amdgcn_sched_barrier(0);
     bf16x8* buf = sA + (st & 1) * LBS3_STAGE_PIECES * 64;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NGA; ++i) {
       const int piece = wave + 4 * i;
       if (piece < LBS3_STAGE_PIECES) buf[piece * 64 + lane] = ga[i];
     }
