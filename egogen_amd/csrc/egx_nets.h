@@ -39,3 +39,5 @@ struct RegWeights {
 };
 int egx_launch_regressor_fused(hipStream_t st, const RegWeights& w, const float* Y, const float* betas, int A, int M,
                                float* out_Yb);
+// y[t][a][c] += y[t-1][a][c] for t = 0..T-1 with y[-1] = x_last[a][c] (row stride x_ld): residual chain of the decoder
+void egx_launch_frame_scan(hipStream_t st, float* y, const float* x_last, int x_ld, int A, int width, int T);

@@ -556,3 +556,19 @@ extern "C" int egx_gae(const float* values, const float* rew, const int32_t* ter
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
+
+__global__ void egx_frame_scan_kernel(float* __restrict__ y, const float* __restrict__ x_last, int x_ld, int A, int width, int T) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= A * width) return;
+  const int a = idx / width, c = idx % width;
+  float run = x_last[(size_t)a * x_ld + c];
+  for (int t = 0; t < T; ++t) {
+    float* p = y + ((size_t)t * A + a) * width + c;
+    run = *p + run;  // d_t + y_(t-1), the order of `d_out(hfc) + y_p`
+    *p = run;
+  }
+}
+
+void egx_launch_frame_scan(hipStream_t st, float* y, const float* x_last, int x_ld, int A, int width, int T) {
+  hipLaunchKernelGGL(egx_frame_scan_kernel, dim3(egx_ceil_div(A * width, 256)), dim3(256), 0, st, y, x_last, x_ld, A, width, T);
+}

@@ -26,7 +26,7 @@ extern "C" size_t egx_sample_prior_workspace_bytes(int A) {
   if (A <= 0) return 0;
   const size_t a = A, m = (size_t)A * T_PRED;
   (void)m;
-  return carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 3 * H, a * 512, a * H});
+  return carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 3 * H, a * 512, a * H, m * H});
 }
 
 extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, const float* x1, int x_ld,
@@ -49,6 +49,7 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
   float* gconst = cv.take((size_t)A * 3 * H);
   float* t512 = cv.take((size_t)A * 512);
   float* t256 = cv.take((size_t)A * H);
+  float* hfc_all = cv.take((size_t)M * H);  // d_mlp outputs of all 18 steps (folded-output path)
 
   auto lin = [](int M, int N, std::initializer_list<EgxSeg> segs, const float* W, int ldw, const float* b, int act,
                 const float* res, int ldr, float* out, int ldo) {
@@ -81,20 +82,37 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
     egx_launch_linear(st, A, H, &s3, 1, w->drnn_w[2], w->drnn_b[2], 1, 0.f, nullptr, 0, hcur, H);
   }
   // ---- 18 decode steps: one paired launch for the two GRU products, gate math, two MLP layers, output + residual
+  const bool fold = w->d_comb_w && w->d_comb_b;
   for (int i = 0; i < T_PRED; ++i) {
     const float* yp = (i == 0) ? x1 : out_Y + (size_t)(i - 1) * A * MK;
     const int yp_ld = (i == 0) ? x_ld : MK;
-    egx_launch_linear_pair(st, lin(A, 3 * H, {{yp, MK, yp_ld}}, w->d_rnn_w_ih + (H + ZD), KIN, nullptr, 0, gconst, 3 * H, gi, 3 * H),
-                           lin(A, 3 * H, {{hcur, H, H}}, w->d_rnn_w_hh, 0, w->d_rnn_b_hh, 0, nullptr, 0, gh, 3 * H));
+    float* hfc = fold ? hfc_all + (size_t)i * A * H : t256;
+    if (!fold || i == 0) {
+      egx_launch_linear_pair(st, lin(A, 3 * H, {{yp, MK, yp_ld}}, w->d_rnn_w_ih + (H + ZD), KIN, nullptr, 0, gconst, 3 * H, gi, 3 * H),
+                             lin(A, 3 * H, {{hcur, H, H}}, w->d_rnn_w_hh, 0, w->d_rnn_b_hh, 0, nullptr, 0, gh, 3 * H));
+    } else {
+      // y_(i-1) = d_out(hfc_(i-1)) + y_(i-2)  =>  gi_i = gi_(i-1) + hfc_(i-1) d_comb_w^T + d_comb_b (in place: every
+      // element of gi is read once, as the residual, by the thread that then writes it)
+      egx_launch_linear_pair(st, lin(A, 3 * H, {{hfc_all + (size_t)(i - 1) * A * H, H, H}}, w->d_comb_w, 0, w->d_comb_b, 0, gi, 3 * H, gi, 3 * H),
+                             lin(A, 3 * H, {{hcur, H, H}}, w->d_rnn_w_hh, 0, w->d_rnn_b_hh, 0, nullptr, 0, gh, 3 * H));
+    }
     egx_launch_gru_pointwise(st, gi, gh, hcur, H, hnext, H, A, H);
     EgxSeg s1{hnext, H, H};
     egx_launch_linear(st, A, 512, &s1, 1, w->d_mlp_w[0], w->d_mlp_b[0], 1, 0.f, nullptr, 0, t512, 512);
     EgxSeg s2{t512, 512, 512};
-    egx_launch_linear(st, A, H, &s2, 1, w->d_mlp_w[1], w->d_mlp_b[1], 1, 0.f, nullptr, 0, t256, H);
-    EgxSeg s3{t256, H, H};
-    // y_i = d_out(hfc) + y_p   (residual)
-    egx_launch_linear(st, A, MK, &s3, 1, w->d_out_w, w->d_out_b, 0, 0.f, yp, yp_ld, out_Y + (size_t)i * A * MK, MK);
+    egx_launch_linear(st, A, H, &s2, 1, w->d_mlp_w[1], w->d_mlp_b[1], 1, 0.f, nullptr, 0, hfc, H);
+    if (!fold) {
+      EgxSeg s3{hfc, H, H};
+      // y_i = d_out(hfc) + y_p   (residual)
+      egx_launch_linear(st, A, MK, &s3, 1, w->d_out_w, w->d_out_b, 0, 0.f, yp, yp_ld, out_Y + (size_t)i * A * MK, MK);
+    }
     float* tmp = hcur; hcur = hnext; hnext = tmp;
+  }
+  if (fold) {
+    // all 18 output layers as one product over M = 18 A rows, then the residual chain y_i = d_i + y_(i-1) as a scan
+    EgxSeg sa{hfc_all, H, H};
+    egx_launch_linear(st, M, MK, &sa, 1, w->d_out_w, w->d_out_b, 0, 0.f, nullptr, 0, out_Y, MK);
+    egx_launch_frame_scan(st, out_Y, x1, x_ld, A, MK, T_PRED);
   }
   // ---- regressor on all 18*A frames (rows ordered [t][a] like Y_gen.view(nt*nb,-1); betas row = a):
   // one fused launch, 66 dense layers + the 6D -> axis-angle tail

@@ -105,6 +105,9 @@ class MoshRegressor(nn.Module):
         self.pnet = ResNetBlock(self.in_dim + self.body_dim + 10, 128, self.body_dim, 10, "relu")
 
 
+FOLD_DECODER_OUTPUT = os.environ.get("EGX_FOLD_DECODER_OUTPUT", "1") == "1"
+
+
 class GAMMAPrimitiveCombo(nn.Module):
     def __init__(self, markercfg, bparamscfg):
         super().__init__()
@@ -116,7 +119,9 @@ class GAMMAPrimitiveCombo(nn.Module):
 
     def _weights(self) -> _lib.PriorWeights:
         p, r = self.predictor, self.regressor.pnet
-        key = (p.x_enc.weight_ih_l0.data_ptr(), r.out_fc.weight.data_ptr())
+        # pointer + in-place version of the tensors the folded decoder weights depend on
+        key = (p.x_enc.weight_ih_l0.data_ptr(), r.out_fc.weight.data_ptr(), p.d_rnn.weight_ih._version, p.d_out.weight._version,
+               p.d_out.bias._version)
         if self._wstruct is not None and self._wkey == key:
             return self._wstruct
         w = _lib.PriorWeights()
@@ -134,6 +139,12 @@ class GAMMAPrimitiveCombo(nn.Module):
             for k in range(2):
                 w.reg_blk_w[2 * b + k], w.reg_blk_b[2 * b + k] = _p(r.layers[b].layers[k].weight), _p(r.layers[b].layers[k].bias)
         w.reg_out_w, w.reg_out_b = _p(r.out_fc.weight), _p(r.out_fc.bias)
+        # output layer folded into the GRU cell's input product (egx_prior_weights.d_comb_*), in float64
+        with torch.no_grad():
+            wy = p.d_rnn.weight_ih[:, p.d_rnn.weight_ih.shape[1] - p.d_out.weight.shape[0]:].double()
+            self._comb_w = (wy @ p.d_out.weight.double()).float().contiguous()
+            self._comb_b = (wy @ p.d_out.bias.double()).float().contiguous()
+        w.d_comb_w, w.d_comb_b = (_p(self._comb_w), _p(self._comb_b)) if FOLD_DECODER_OUTPUT else (None, None)
         self._wstruct, self._wkey = w, key
         return w
 

@@ -188,6 +188,12 @@ typedef struct egx_prior_weights {
   const float *reg_in_w, *reg_in_b;                               /* regressor.pnet.in_fc 370-128        */
   const float *reg_blk_w[20], *reg_blk_b[20];                     /* regressor.pnet.layers.{0..9}.layers.{0,1} */
   const float *reg_out_w, *reg_out_b;                             /* regressor.pnet.out_fc 128-159       */
+  /* Optional (NULL = evaluate as written in the reference): d_comb_w [768,256] = d_rnn_w_ih[:, 384:585] . d_out_w and
+   * d_comb_b [768] = d_rnn_w_ih[:, 384:585] . d_out_b.  The residual decoder feeds y_i = d_out(h_i) + y_(i-1) back into the
+   * GRU cell (models_GAMMA_primitive.py:95-103), so the cell's input product obeys
+   * gi_(i+1) = gi_i + h_i . d_comb_w^T + d_comb_b: with the two folded tensors the output layer leaves the 18-step
+   * critical path and is evaluated for all steps at once afterwards. */
+  const float *d_comb_w, *d_comb_b;
 } egx_prior_weights;
 
 size_t egx_sample_prior_workspace_bytes(int num_agents);
