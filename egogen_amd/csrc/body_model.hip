@@ -645,8 +645,18 @@ constexpr int LBS3_QCAP = LBS3_RB * 64 + 64;
 constexpr int LBS3_WAVE_BYTES = 256 + LBS3_QCAP * 16;                  // s_cnt + queue
 static_assert(KS3 % LBS3_STAGE_KS == 0, "stages cover K exactly");
 
+#ifdef EGX_LBS_TIMING
+// development build only (make CXXFLAGS+=-DEGX_LBS_TIMING): cycle totals of the phases of the bf16x3 stage loop
+__device__ unsigned long long g_lbs_t[8];
+#define LBS_T(i, v) do { tacc[i] += (unsigned long long)(v); } while (0)
+#define LBS_NOW() __builtin_readcyclecounter()
+#else
+#define LBS_T(i, v) do { } while (0)
+#define LBS_NOW() 0ull
+#endif
+
 __device__ __forceinline__ void lbs_blend_bf16x3(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave,
-                                                 bf16x8* sA) {
+                                                 bf16x8* sA, unsigned long long* tacc) {
   constexpr int NB = LBS_NB;
   const int num_bt = (p.B + 31) >> 5;
   const bf16x8* dpv = p.dirs3 + (size_t)vt * KS3 * 9 * 64 + lane;  // piece (s, plane, coord) at ((s*3 + plane)*3 + coord)*64
@@ -657,6 +667,7 @@ __device__ __forceinline__ void lbs_blend_bf16x3(const LbsParams& p, f32x16 (&ac
     // burst: this wave's share of the stage's base pieces + its own feature pieces
     constexpr int NGA = (LBS3_STAGE_PIECES + 3) / 4;
     bf16x8 ga[NGA], b[LBS3_STAGE_KS][3][NB];
+    const unsigned long long t0 = LBS_NOW();
 #pragma unroll
     for (int i = 0; i < NGA; ++i) {
       const int piece = wave + 4 * i;
@@ -671,6 +682,7 @@ __device__ __forceinline__ void lbs_blend_bf16x3(const LbsParams& p, f32x16 (&ac
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = LBS_NOW();
     bf16x8* buf = sA + (st & 1) * LBS3_STAGE_PIECES * 64;
 #pragma unroll
     for (int i = 0; i < NGA; ++i) {
@@ -678,22 +690,34 @@ __device__ __forceinline__ void lbs_blend_bf16x3(const LbsParams& p, f32x16 (&ac
       if (piece < LBS3_STAGE_PIECES) buf[piece * 64 + lane] = ga[i];
     }
     __syncthreads();  // stage visible; also: everyone is done reading the other buffer's previous contents
+    const unsigned long long t2 = LBS_NOW();
 #pragma unroll
-    for (int ks = 0; ks < LBS3_STAGE_KS; ++ks)
+    for (int ks = 0; ks < LBS3_STAGE_KS; ++ks) {
+      bf16x8 a[3][3];  // [plane][coord]
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const bf16x8 a0 = buf[(ks * 9 + 0 * 3 + c) * 64 + lane], a1 = buf[(ks * 9 + 1 * 3 + c) * 64 + lane],
-                     a2 = buf[(ks * 9 + 2 * 3 + c) * 64 + lane];
+      for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {  // small partial products first
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[ks][1][q], acc[c][q], 0, 0, 0);
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][2][q], acc[c][q], 0, 0, 0);
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[ks][0][q], acc[c][q], 0, 0, 0);
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][1][q], acc[c][q], 0, 0, 0);
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[ks][0][q], acc[c][q], 0, 0, 0);
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][0][q], acc[c][q], 0, 0, 0);
-        }
+        for (int c = 0; c < 3; ++c) a[pl][c] = buf[(ks * 9 + pl * 3 + c) * 64 + lane];
+      // product-major order: consecutive MFMAs go to the six different accumulator tuples, so no MFMA waits for the
+      // previous one's result (small partial products first)
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr) {
+        const int pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
+        const int pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+            acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][c], b[ks][pb][q], acc[c][q], 0, 0, 0);
       }
+    }
+#ifdef EGX_LBS_TIMING
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t3 = LBS_NOW();
+      LBS_T(0, t1 - t0); LBS_T(1, t2 - t1); LBS_T(2, t3 - t2); LBS_T(3, 1);
+    }
+#endif
   }
 }
 
@@ -732,6 +756,8 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
   // item order: blocks of bg_block body groups, vertex-tile-major inside a block - the features / joint transforms of
   // a block (1.4 MB per group) stay in the XCD's 4 MiB L2 while the bases stream through once per block
   const int PB = max(1, min(p.bg_block, max(nper, 1)));
+  unsigned long long tacc[4] = {0, 0, 0, 0};
+  (void)tacc;
   for (int item = stream; item < n_items; item += n_streams) {
     const int blk = item / (p.NVT * PB);
     const int pb = min(PB, nper - blk * PB);
@@ -758,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
       for (int q = 0; q < NB; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
-    if (!(p.dbg & 2)) lbs_blend_bf16x3(p, acc, vt, bt0, lane, wave, sA);
+    if (!(p.dbg & 2)) lbs_blend_bf16x3(p, acc, vt, bt0, lane, wave, sA, tacc);
     else __syncthreads();  // the blend's barriers also publish the metadata
     if (p.dbg & 1) {
       float sum = 0.f;
@@ -773,6 +799,10 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
     }
     lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP>(p, w, acc, vt, bt0, JT);
   }
+#ifdef EGX_LBS_TIMING
+  if (lane == 0)
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_lbs_t[i], tacc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1044,6 +1074,17 @@ WsLayout ws_layout(const egx_body_model* m, int B) {
   return w;
 }
 }  // namespace
+
+#ifdef EGX_LBS_TIMING
+extern "C" int egx_lbs_timing_read(unsigned long long* out8, int reset) {
+  EGX_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lbs_t), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    EGX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lbs_t), z, sizeof(z)));
+  }
+  return EGX_OK;
+}
+#endif
 
 extern "C" int egx_lbs_set_blend_mode(int mode) {
   EGX_REQUIRE(mode == 0 || mode == 1, "blend mode must be 0 (fp32 MFMA) or 1 (bf16x3 split)");
