@@ -151,3 +151,58 @@ def adv_stats(adv: torch.Tensor) -> torch.Tensor:
     _lib.check(lib.egx_adv_stats(_lib.ptr(adv.contiguous()), int(adv.numel()), _lib.ptr(out), _lib.current_stream_ptr()),
                "egx_adv_stats")
     return out
+
+
+class GRUSeqFn(torch.autograd.Function):
+    """Last hidden state of a one-layer nn.GRU over x[T*nb, in] (time-major, zero initial state) as ONE autograd node:
+    the input products of all steps are one GEMM, each step is a recurrent GEMM + the fused gate kernel, and backward
+    writes the gate gradients of every step straight into one [T*nb, 3H] buffer (no slicing / expand / accumulate nodes).
+    Parameter gradients are accumulated into the flat-buffer views like LinearFn; x gets no gradient (observations)."""
+
+    @staticmethod
+    def forward(ctx, x2, w_ih, b_ih, w_hh, b_hh, g_w_ih, g_b_ih, g_w_hh, g_b_hh, T):
+        lib = _lib.load()
+        x2 = x2.contiguous()
+        nb = x2.shape[0] // T
+        H = w_hh.shape[1]
+        st = _lib.current_stream_ptr()
+        gi = torch.addmm(b_ih, x2, w_ih.t())
+        gh = torch.empty(T, nb, 3 * H, dtype=torch.float32, device=x2.device)
+        hs = torch.zeros(T + 1, nb, H, dtype=torch.float32, device=x2.device)  # hs[0] = initial state
+        gh[0].copy_(b_hh.unsqueeze(0).expand(nb, 3 * H))
+        for t in range(T):
+            if t > 0:
+                torch.addmm(b_hh, hs[t], w_hh.t(), out=gh[t])
+            _lib.check(lib.egx_gru_pointwise(_lib.ptr(gi[t * nb:(t + 1) * nb]), _lib.ptr(gh[t]), _lib.ptr(hs[t]), H, _lib.ptr(hs[t + 1]), H,
+                                             nb, H, st), "egx_gru_pointwise")
+        ctx.save_for_backward(x2, w_hh, gi, gh, hs)
+        ctx.views = (g_w_ih, g_b_ih, g_w_hh, g_b_hh)
+        ctx.T = T
+        return hs[T]
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        x2, w_hh, gi, gh, hs = ctx.saved_tensors
+        g_w_ih, g_b_ih, g_w_hh, g_b_hh = ctx.views
+        T = ctx.T
+        nb, H = hs.shape[1], hs.shape[2]
+        st = _lib.current_stream_ptr()
+        dgi = torch.empty_like(gi)
+        dgh = torch.empty_like(gh)
+        dhp = torch.empty(nb, H, dtype=torch.float32, device=dh.device)
+        dh = dh.contiguous()
+        for t in range(T - 1, -1, -1):
+            _lib.check(lib.egx_gru_pointwise_bwd(_lib.ptr(gi[t * nb:(t + 1) * nb]), _lib.ptr(gh[t]), _lib.ptr(hs[t]), _lib.ptr(dh), nb, H,
+                                                 _lib.ptr(dgi[t * nb:(t + 1) * nb]), _lib.ptr(dgh[t]), _lib.ptr(dhp), st),
+                       "egx_gru_pointwise_bwd")
+            if t > 0:  # through gh_t = h_t W_hh^T + b_hh
+                dh = torch.addmm(dhp, dgh[t], w_hh)
+                dhp = torch.empty_like(dhp)
+        dgh2 = dgh.reshape(T * nb, 3 * H)
+        _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(dgh2), None, None, _lib.ptr(g_b_hh), T * nb, 3 * H, 0, 0.0, st), "egx_act_bwd_colsum")
+        _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(dgi), None, None, _lib.ptr(g_b_ih), T * nb, 3 * H, 0, 0.0, st), "egx_act_bwd_colsum")
+        if T > 1:
+            g_w_hh.addmm_(dgh2[nb:].t(), hs[1:T].reshape((T - 1) * nb, H))
+        g_w_ih.addmm_(dgi.t(), x2)
+        return (None,) * 10

@@ -313,19 +313,13 @@ def _gru_last_fused(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
     """nn.GRU over x[b,T,in] from a zero state, last hidden state.  The input products of all T steps are ONE GEMM
     (each weight is used once per minibatch: its gradient is written by a single accumulate-GEMM), the gate math is the
     fused HIP node, and the first step's recurrent term is the bias alone (h_0 = 0)."""
-    from .fused_ops import GRUPointwiseFn, linear_fn
+    from .fused_ops import GRUSeqFn
     nb, T, _ = x.shape
-    H = gru.hidden_size
     X = x.permute(1, 0, 2).reshape(T * nb, x.shape[2])
-    gi = linear_fn(X, gru.weight_ih_l0, gru.bias_ih_l0)
-    h = x.new_zeros(nb, H)
-    for t in range(T):
-        if t == 0:
-            gh = gru.bias_hh_l0.unsqueeze(0).expand(nb, 3 * H)
-        else:
-            gh = linear_fn(h, gru.weight_hh_l0, gru.bias_hh_l0)
-        h = GRUPointwiseFn.apply(gi[t * nb:(t + 1) * nb], gh, h)
-    return h
+    w_ih, b_ih, w_hh, b_hh = gru.weight_ih_l0, gru.bias_ih_l0, gru.weight_hh_l0, gru.bias_hh_l0
+    if any(t.grad is None for t in (w_ih, b_ih, w_hh, b_hh)):
+        raise _lib.EgxError("GRUSeqFn needs pre-allocated gradient views (GAMMAPPOPolicy._ensure_flat_grads)")
+    return GRUSeqFn.apply(X, w_ih, b_ih, w_hh, b_hh, w_ih.grad, b_ih.grad, w_hh.grad, b_hh.grad, T)
 
 
 def _mlpblock_fused(block: MLPBlock, x: torch.Tensor) -> torch.Tensor:
