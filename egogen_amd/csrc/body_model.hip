@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
   __shared__ float sR[4][NJ][9];
   __shared__ float sJ[4][NJ][3];
   __shared__ float sG[4][NJ][12];
+  __shared__ __attribute__((aligned(16))) unsigned short sF3[4][3][KS3 * 16];  // bf16x3 planes of the 4 bodies of the block
   const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + w;
   const bool live = b < B;
@@ -147,12 +148,11 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       const int s = k >> 1, kk = k & 1;
       featb[((s >> 2) * 64 + (kk * 32 + n)) * 4 + (s & 3)] = v;
     }
-    if (feat3b) {  // k = 16 s + 8 half + e  ->  [s][plane][half*32 + n][e]
+    if (feat3b) {  // staged in LDS; written out below as whole 16-byte operand fragments
       unsigned short h[3];
       egx_bf16_split3(v, h);
-      const int s = k >> 4, hf = (k >> 3) & 1, e = k & 7;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) feat3b[(((size_t)s * 3 + pl) * 64 + hf * 32 + n) * 8 + e] = h[pl];
+      for (int pl = 0; pl < 3; ++pl) sF3[w][pl][k] = h[pl];
     }
   };
   float R[9], Jr[3];
@@ -202,6 +202,20 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
     }
   }
   __syncthreads();
+  if (feat3) {
+    // k = 16 s + 8 half + e  ->  [bt][s][plane][half*32 + n][e]: one 16-byte fragment per (s, plane, half, body); the four
+    // bodies of the block are neighbours in n, so a quarter-wave writes 64 contiguous bytes
+    for (int c = threadIdx.x; c < KS3 * 3 * 2 * 4; c += 256) {
+      const int wb = c & 3, hf = (c >> 2) & 1, pl = (c >> 3) % 3, sidx = c / 24;
+      const int body = blockIdx.x * 4 + wb;
+      if (body < B) {
+        const int4 frag = *reinterpret_cast<const int4*>(&sF3[wb][pl][sidx * 16 + hf * 8]);
+        unsigned short* dst = feat3 + ((((size_t)(body >> 5) * KS3 + sidx) * 3 + pl) * 64 + hf * 32 + (body & 31)) * 8;
+        *reinterpret_cast<int4*>(dst) = frag;
+      }
+    }
+  }
+
   const int par = (j < NJ) ? pc->parents[j] : -1;
   const int dep = (j < NJ) ? pc->depth[j] : -1;
   float rel[3] = {0.f, 0.f, 0.f};
