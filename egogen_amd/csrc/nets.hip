@@ -316,10 +316,15 @@ __global__ __launch_bounds__(256, 2) void egx_regressor_fused_kernel(RegWeights 
     // ---- 10 residual blocks
     for (int l = 0; l < 20; ++l) {
       // next layer's weights (or out_fc tile `wave`) while this layer computes
+      // The next layer's weights are requested AFTER this layer's MFMAs: a wave that issues MFMAs with its own loads in
+      // flight runs the matrix pipe at half rate on gfx950 (scripts/ubench/mfma_loads.hip), which cost more than the
+      // latency the prefetch hid.  The loads now fly during the LDS epilogue and the barrier.
       const float* Wn = (l + 1 < 20) ? w.blk_w[l + 1] : w.out_w;
-      rg_load_w128(Wn, n0 + i, h, wnext);
       const float* src = (l & 1) ? tb : hb;
+      __builtin_amdgcn_sched_barrier(0);
       f32x16 acc = rg_mma128(src, i, h, wcur);
+      __builtin_amdgcn_sched_barrier(0);
+      rg_load_w128(Wn, n0 + i, h, wnext);
       const float b = w.blk_b[l][n0 + i];
       if ((l & 1) == 0) {
 #pragma unroll
