@@ -207,6 +207,28 @@ def test_lbs_invariants_full_size():
     assert (dist1 - dist4).abs().max() < 2e-5
 
 
+def test_lbs_batch_independence_full_size(blend_mode):
+    """BASELINE scale (512 agents x 20 frames, V = 10475): a body's picks and penetration count do not depend on what else
+    is in the launch - the first 37 agents evaluated alone are bit-identical to their rows of the 10240-body launch."""
+    from egogen_amd.body_model import SdfScene
+    bm, mk, feet, h, _ = _setup(10475)
+    A, T, As = 512, 20, 37
+    xb, betas = _poses(A, T, seed=3)
+    xb[:, 2] = 0.3
+    xb, betas = xb.cuda(), betas.cuda()
+    scene = SdfScene(synth.make_sdf_scene(64))
+    g = torch.Generator().manual_seed(9)
+    R0 = torch.eye(3).repeat(A, 1, 1).cuda()
+    T0 = torch.cat([torch.rand(A, 2, generator=g) * 6 - 3, torch.zeros(A, 1)], -1).cuda()
+    full = {k: v.clone() for k, v in h.forward(xb, betas, T, sdf=scene, R0=R0, T0=T0).items()}
+    sub = h.forward(xb[:As * T].contiguous(), betas[:As].contiguous(), T, sdf=scene, R0=R0[:As].contiguous(), T0=T0[:As].contiguous())
+    torch.cuda.synchronize()
+    assert full["pene_count"].max() > 0
+    for k in ("joints", "markers", "pene_count"):
+        assert torch.equal(full[k][:As * T], sub[k]), k
+    assert torch.isfinite(full["joints"]).all() and torch.isfinite(full["markers"]).all()
+
+
 def test_bad_arguments_raise():
     from egogen_amd import _lib
     bm, mk, feet, h, _ = _setup(1000)
