@@ -87,7 +87,7 @@ class EnvState(C.Structure):
 class EnvStepIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("Y_gen", "pred_params", "joints", "markers_proj", "pene_count", "vp_emb",
                                           "feet_marker_idx", "reward", "terminated", "reward_terms", "obs_ego", "obs_dist",
-                                          "obs_time", "out_marker_b", "out_prev_frame")]
+                                          "obs_time", "out_marker_b", "out_prev_frame", "nonfinite_count")]
 
 
 class EnvResetIO(C.Structure):

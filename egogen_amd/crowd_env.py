@@ -184,6 +184,8 @@ class VecCrowdEnv:
         io.pene_count = self.pene_count.data_ptr() if scene_kind == "sdf" else None
         io.vp_emb, io.feet_marker_idx = self.vp_emb.data_ptr(), self.feet_marker_idx.data_ptr()
         io.reward, io.terminated, io.reward_terms = self.reward.data_ptr(), self.terminated.data_ptr(), self.rterms.data_ptr()
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        io.nonfinite_count = self.nonfinite.data_ptr()
         io.obs_ego, io.obs_dist, io.obs_time = self.obs_ego.data_ptr(), self.obs_dist.data_ptr(), self.obs_time.data_ptr()
         io.out_marker_b = self.marker_b.data_ptr() if keep_rollout else None
         io.out_prev_frame = self.prev_frame.data_ptr() if keep_rollout else None
@@ -348,6 +350,14 @@ class VecCrowdEnv:
         self.vposer.encode_mean_into(self.pred_params.reshape(A * 20, 93)[:, 6:], 93, A * 20, self.vp_emb)
         _lib.check(lib.egx_env_step_post(C.byref(self._ec), C.byref(self._sc), C.byref(self._st), C.byref(self._io), A, st),
                    "egx_env_step_post")
+
+    def check_finite(self):
+        """Raise if any step since the last call produced a non-finite reward / target distance (one host sync; the
+        reference stops in pdb at the NaN/Inf checks of crowd_env_2f.py:287-297)."""
+        n = int(self.nonfinite.item())
+        if n:
+            self.nonfinite.zero_()
+            raise FloatingPointError(f"{n} agent-steps produced non-finite rewards since the last check")
 
     def step(self, actions: torch.Tensor, auto_reset: bool = True):
         """actions[A,128] -> (obs, reward[A], terminated[A] int32).  Returned tensors are views of internal

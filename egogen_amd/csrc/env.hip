@@ -229,6 +229,7 @@ struct StepArgs {
   float* reward;       // [A]
   int* terminated;     // [A]
   float* rterms;       // [A,8] or null: skate, floor, face, look, goal, target_dist, pene, vp
+  int* nonfinite;      // device counter or null
   float* obs_ego;      // [A,2,32]
   float* obs_dist;     // [A]
   float* obs_time;     // [A]
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(BLK) void egx_env_step_post_kernel(StepArgs p) {
     bool term = (r_goal > 0.f) || (steps == c.max_depth);
     if (c.terminate_on_pene) term = term || penetration;
     p.reward[a] = reward;
+    if (p.nonfinite && !(isfinite(reward) && isfinite(d2t))) atomicAdd(p.nonfinite, 1);
     p.terminated[a] = term ? 1 : 0;
     p.dist[a] = d2t;
     p.obs_dist[a] = 1.f / (d2t + 1.f);
@@ -783,7 +785,7 @@ extern "C" int egx_env_step_post(const egx_env_config* cfg, const egx_env_scenes
   p.wpath = st->wpath; p.scene_idx = st->scene_idx;
   p.Y_gen = io->Y_gen; p.pred_params = io->pred_params; p.joints = io->joints; p.markers_proj = io->markers_proj;
   p.pene_count = io->pene_count; p.vp_emb = io->vp_emb; p.feet_marker_idx = io->feet_marker_idx;
-  p.reward = io->reward; p.terminated = io->terminated; p.rterms = io->reward_terms; p.obs_ego = io->obs_ego;
+  p.reward = io->reward; p.terminated = io->terminated; p.rterms = io->reward_terms; p.nonfinite = io->nonfinite_count; p.obs_ego = io->obs_ego;
   p.obs_dist = io->obs_dist; p.obs_time = io->obs_time; p.out_marker_b = io->out_marker_b; p.out_prev_frame = io->out_prev_frame;
   hipLaunchKernelGGL(egx_env_step_post_kernel, dim3(A), dim3(BLK), 0, static_cast<hipStream_t>(stream_), p);
   EGX_HIP_CHECK(hipGetLastError());

@@ -188,6 +188,7 @@ def onpolicy_trainer(policy: GAMMAPPOPolicy, train_collector: Collector, test_co
         steps_in_epoch = 0
         while steps_in_epoch < step_per_epoch:
             batch = train_collector.collect(n_vec)
+            train_collector.env.check_finite()  # device-side NaN/Inf counter, polled once per collect
             n_new = n_vec * A_global
             env_step += n_new
             steps_in_epoch += n_new

@@ -302,6 +302,9 @@ typedef struct egx_env_step_io {
   float* obs_time;           /* [A]      */
   float* out_marker_b;       /* [A,20,67,3] blended markers (save_rollout) or NULL      */
   float* out_prev_frame;     /* [A,12] R0|T0 before the update (save_rollout) or NULL   */
+  int32_t* nonfinite_count;  /* device counter or NULL: +1 per agent whose reward / target distance is not finite
+                              * (the reference drops into pdb on NaN/Inf, crowd_env_2f.py:287-297; here the host polls
+                              * the counter once per collect and raises) */
 } egx_env_step_io;
 
 typedef struct egx_env_reset_io {

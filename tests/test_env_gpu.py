@@ -295,3 +295,19 @@ def test_env_full_size_determinism_and_ranges():
         assert (o0["dist"] > 0).all() and (o0["dist"] <= 1.0).all()          # 1 / (dist + 1)
         assert set(t0.unique().tolist()) <= {0, 1}
         assert (o0["time"] >= 0).all() and (o0["time"] <= 1.0).all()
+
+
+def test_nonfinite_counter_raises():
+    """A NaN that reaches the reward is counted on the device and reported by check_finite() (once, then cleared)."""
+    A = 4
+    w = build_world(A=A, scene_kind="sdf")
+    env = w["env"]
+    env.reset()
+    z = torch.zeros(A, 128, device="cuda")
+    env.step(z, auto_reset=False)
+    env.check_finite()  # clean so far
+    z[1, 3] = float("nan")
+    env.step(z, auto_reset=False)
+    with pytest.raises(FloatingPointError):
+        env.check_finite()
+    env.check_finite()  # the counter was cleared
