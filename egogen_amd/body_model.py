@@ -91,7 +91,7 @@ class BodyModelHandle:
         self.M = d.num_markers
         self.marker_vids = [int(v) for v in k["marker"]]
         self.nnz = lib.egx_body_model_nnz(h)
-        self._ws: Dict[int, torch.Tensor] = {}
+        self._ws: Dict[tuple, torch.Tensor] = {}
         del self._keep  # device copies are owned by the handle now
 
     def __del__(self):
@@ -104,11 +104,13 @@ class BodyModelHandle:
             self.handle = None
 
     def workspace(self, B: int) -> torch.Tensor:
-        ws = self._ws.get(B)
+        """Scratch of one forward, cached per (batch size, stream): forwards on distinct streams never share it."""
+        key = (B, torch.cuda.current_stream().cuda_stream)
+        ws = self._ws.get(key)
         if ws is None:
             nbytes = _lib.load().egx_lbs_workspace_bytes(self.handle, B)
             ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-            self._ws[B] = ws
+            self._ws[key] = ws
         return ws
 
     def forward(self, xb: torch.Tensor, betas: torch.Tensor, frames_per_agent: int, want_verts=False,

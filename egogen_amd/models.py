@@ -36,13 +36,18 @@ def _p(t: torch.Tensor) -> int:
 
 
 class _Workspace:
+    """Scratch of the network entry points, one buffer per stream (calls on distinct streams never share scratch)."""
+
     def __init__(self):
-        self.buf: Optional[torch.Tensor] = None
+        self.bufs: Dict[int, torch.Tensor] = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-        return self.buf
+        key = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes or buf.device != torch.device(device):
+            buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
 
 
 class MLP(nn.Module):
