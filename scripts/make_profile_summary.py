@@ -25,7 +25,18 @@ L = ["# Round 1 final profile (1x MI355X)", "",
      "| share | ms / cycle | launches / cycle | avg us | kernel |", "|---|---|---|---|---|"]
 for k, v in cat.most_common(24):
     L.append(f"| {v/tot*100:.2f} % | {v/ncyc/1e6:.3f} | {calls[k]/ncyc:.1f} | {v/calls[k]/1e3:.1f} | `{k}` |")
+# derived rates of kernels whose algorithmic work per launch is fixed by the benchmark configuration
+def avg_us(sub):
+    r = [x for x in rows if sub in x["Name"]]
+    return sum(float(x["TotalDurationNs"]) for x in r) / max(1, sum(int(x["Calls"]) for x in r)) / 1e3
+n_flat = 13_168_001 + 28 * 32          # parameters + alignment padding of the flat buffers (upper bound of the padding)
+adam_bytes = 7 * 4 * n_flat            # read p, g, m, v; write p, m, v
+reg_flop = 2.0 * 9216 * 3 * (370 * 128 + 20 * 128 * 128 + 128 * 159)
+extra = ["", "| kernel | work per launch | avg us | rate | bound |", "|---|---|---|---|---|",
+         f"| `egx_adamw_flat_kernel` | {adam_bytes/1e6:.0f} MB (p, g, m, v in; p, m, v out) | {avg_us('egx_adamw_flat'):.1f} | {adam_bytes/avg_us('egx_adamw_flat')/1e6:.2f} TB/s | HBM (8 TB/s peak, ~6.3 achievable) |",
+         f"| `egx_regressor_fused_kernel` | {reg_flop/1e9:.1f} GFLOP (9216 rows x 66 layers) | {avg_us('egx_regressor_fused'):.1f} | {reg_flop/avg_us('egx_regressor_fused')/1e6:.1f} TFLOP/s | fp32 MFMA 157.3 / L2 weight stream (64 KB per layer and workgroup) |"]
 egx = sum(v for k, v in cat.items() if "egx_" in k)
+L += extra
 L += ["", f"hand-written kernels (`egx_*`): {egx/tot*100:.1f} % of GPU time; summed kernel time {tot/ncyc/1e6:.2f} ms per cycle (the update's actor / critic and encoder branches run concurrently, so the sum exceeds the wall time).",
       "PMC passes of the LBS kernel: `r01_lbs_pmc_bf16x3.json` (default blend mode), `r01_lbs_pmc.json` (fp32-MFMA kernel of the first half of the round); micro-benchmarks: `r01_ubench.md`."]
 open(os.path.join(R, "r01_final_summary.md"), "w").write("\n".join(L) + "\n")
