@@ -175,6 +175,63 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
   }
 }
 
+// Large-M variant (vposer encoder over 20 A rows, batched decoder output over 18 A rows): 64x64 output tile per workgroup,
+// each wave one 32x32 quadrant over the FULL K.  A 32-wide k-block of X (64 rows) and of W (64 rows) is fetched once per
+// workgroup (two 16-byte loads per thread and operand, waited for before anything else - no loads in flight under the
+// MFMAs), parked in a double-buffered LDS tile (36-float pitch) and read by the two waves that share it: half the L2
+// traffic per MFMA of the 32x32 split-K kernel, whose extra parallelism these shapes do not need.
+__global__ __launch_bounds__(256) void egx_linear64_kernel(LinArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[2][2][64 * 36];  // [buffer][X | W][row * 36 + k]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  int mt, nt;
+  {
+    const int MT = (a.M + 63) >> 6, NT = (a.N + 63) >> 6;
+    const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int per = (MT + 7) >> 3;          // M is the long axis here: every XCD owns a contiguous chunk of row tiles
+    mt = xcd * per + local / NT;
+    nt = local % NT;
+    if (local >= per * NT || mt >= MT) return;
+  }
+  const int m0 = mt * 64, n0 = nt * 64;
+  const int lrow = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 8;  // loader role: row 0..63, k offset 0, 8, 16, 24
+  const int xrow = min(m0 + lrow, a.M - 1), wrow = min(n0 + lrow, a.N - 1);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nblk = (a.K + 31) >> 5;
+  for (int b = 0; b < nblk; ++b) {
+    const f32x4 x0 = load_x4(a, xrow, b * 32 + lk), x1 = load_x4(a, xrow, b * 32 + lk + 4);
+    const f32x4 w0 = load_w4(a, wrow, b * 32 + lk), w1 = load_w4(a, wrow, b * 32 + lk + 4);
+    float* xs = tile[b & 1][0];
+    float* ws = tile[b & 1][1];
+    *reinterpret_cast<f32x4*>(xs + lrow * 36 + lk) = x0;
+    *reinterpret_cast<f32x4*>(xs + lrow * 36 + lk + 4) = x1;
+    *reinterpret_cast<f32x4*>(ws + lrow * 36 + lk) = w0;
+    *reinterpret_cast<f32x4*>(ws + lrow * 36 + lk + 4) = w1;
+    __syncthreads();  // tile b visible; the other buffer (tile b-1) is free again once everyone has passed this point
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + (wr * 32 + i) * 36 + c * 8 + 4 * h);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + (wc * 32 + i) * 36 + c * 8 + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
+    }
+  }
+  const int n = n0 + wc * 32 + i;
+  const float bsv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    float v = apply_act(acc[r] + bsv, a.act, a.slope);
+    if (m < a.M && n < a.N) {
+      if (a.res) v += a.res[(size_t)m * a.ldr + n];
+      a.y[(size_t)m * a.ldy + n] = v;
+    }
+  }
+}
+
 // GRU gate math (torch.nn.GRU / GRUCell, gate order r,z,n): gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh
 __global__ void egx_gru_pointwise_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
                                          const float* __restrict__ gh_bias, const float* __restrict__ hprev, int ldh,
@@ -460,6 +517,12 @@ int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg
                       int act, float slope, const float* res, int ldr, float* out, int ldo) {
   LinArgs2 two;
   two.p0 = make_lin_args(M, N, segs, nseg, W, 0, b, act, slope, res, ldr, out, ldo);
+  if (M >= 2048 && N >= 64) {  // enough row tiles to fill the chip without split-K: the 64x64 kernel
+    const int MT = (M + 63) >> 6, NT = (N + 63) >> 6;
+    const int blocks = 8 * ((MT + 7) >> 3) * NT;
+    hipLaunchKernelGGL(egx_linear64_kernel, dim3(blocks), dim3(256), 0, st, two.p0);
+    return EGX_OK;
+  }
   two.p1 = two.p0;
   two.blocks0 = lin_blocks(two.p0);
   hipLaunchKernelGGL(egx_linear_kernel, dim3(two.blocks0), dim3(256), 0, st, two);
