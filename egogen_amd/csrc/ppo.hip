@@ -170,21 +170,30 @@ __global__ __launch_bounds__(256) void egx_gather_rows_kernel(GatherArgs a) {
 
 // mean and UNBIASED standard deviation of the minibatch advantages (ppo_policy.py:195-197: adv.mean(), adv.std())
 __global__ __launch_bounds__(256) void egx_adv_stats_kernel(const float* __restrict__ adv, int n, float* __restrict__ out) {
-  __shared__ double s1[256], s2[256];
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) { const double v = adv[i]; a += v; b += v * v; }
-  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __shared__ double red[256];
+  __shared__ double s_mean;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += adv[i];
+  red[threadIdx.x] = a;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) { s1[threadIdx.x] += s1[threadIdx.x + st]; s2[threadIdx.x] += s2[threadIdx.x + st]; }
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_mean = red[0] / n;
+  __syncthreads();
+  const double mean = s_mean;
+  double b = 0.0;  // second pass around the mean (two-pass variance)
+  for (int i = threadIdx.x; i < n; i += 256) { const double d = adv[i] - mean; b += d * d; }
+  red[threadIdx.x] = b;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double mean = s1[0] / n;
-    double var = 0.0;
-    for (int i = 0; i < n; ++i) { const double dlt = adv[i] - mean; var += dlt * dlt; }  // two-pass: n is a minibatch (<= a few k)
     out[0] = (float)mean;
-    out[1] = (n > 1) ? (float)sqrt(var / (n - 1)) : nanf("");
+    out[1] = (n > 1) ? (float)sqrt(red[0] / (n - 1)) : nanf("");
   }
 }
 
