@@ -27,7 +27,10 @@ def _linear(segs, W, b, act=0, slope=0.0, res=None):
 
 
 @pytest.mark.parametrize("M,widths,N,act", [(5, [201], 768, 0), (64, [256, 128, 201], 768, 1), (333, [201, 159, 10], 128, 2),
-                                            (512, [512, 512, 64, 64], 1152, 3), (1, [7], 3, 0), (40, [1152], 1, 0)])
+                                            (512, [512, 512, 64, 64], 1152, 3), (1, [7], 3, 0), (40, [1152], 1, 0),
+                                            # M >= 2048 and N >= 64: the 64x64-tile kernel (ragged M, N, K; segments)
+                                            (2048, [63], 512, 3), (2093, [256], 201, 0), (2560, [201, 159, 10], 128, 2),
+                                            (4000, [70, 33], 65, 1)])
 def test_linear_kernel(M, widths, N, act):
     g = torch.Generator().manual_seed(M + N)
     big = [torch.randn(M, w + 5, generator=g).cuda() for w in widths]   # padded rows: exercise ld != width
