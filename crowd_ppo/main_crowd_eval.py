@@ -33,6 +33,12 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
     body = BodyModelHandle(bm, synth.marker_ids(args.num_verts), synth.feet_vids(args.num_verts))
     prior, vposer = sw.build_motion_prior(seed=args.seed), sw.build_vposer(seed=args.seed)
     policy = sw.build_policy(args)
+    # BASELINE config 5: the policy's dense layers on the bf16 MFMA (operands rounded to bf16, fp32 accumulate) unless
+    # --policy-dtype fp32; everything else (motion prior, SMPL-X, collision) stays fp32
+    from egogen_amd import _lib
+    bf16 = (getattr(args, "policy_dtype", None) or "bf16") == "bf16"
+    _lib.check(_lib.load().egx_policy_set_precision(1 if bf16 else 0), "egx_policy_set_precision")
+    print("policy dense layers:", "bf16 operands / fp32 accumulate" if bf16 else "fp32")
     if args.resume_path:
         policy.load_state_dict(torch.load(args.resume_path, map_location="cuda")["model"])
         print("Loaded agent from: ", args.resume_path)
@@ -88,4 +94,4 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
 
 if __name__ == "__main__":
     a = get_args()
-    main(a, num_scenes=int(os.environ.get("EGX_CROWD_SCENES", "1")))
+    main(a, num_scenes=a.num_scenes or int(os.environ.get("EGX_CROWD_SCENES", "1")))

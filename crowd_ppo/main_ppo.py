@@ -72,7 +72,16 @@ def get_args(argv=None):
     p.add_argument("--sdf-res", type=int, default=256)
     p.add_argument("--save-rollout", type=int, default=None, help="write log/eval_results/motion_*.pkl (default: only with --watch)")
     p.add_argument("--num-verts", type=int, default=synth.NUM_VERTS, help="reduced synthetic body (tests)")
+    p.add_argument("--policy-dtype", type=str, default=None, choices=["fp32", "bf16"],
+                   help="arithmetic of the rollout policy's dense layers (default: fp32; main_crowd_eval.py: bf16, BASELINE config 5)")
+    p.add_argument("--num-scenes", type=int, default=None, help="main_crowd_eval.py: independent 4-human scenes per GPU")
     return p.parse_args(argv)
+
+
+def _apply_policy_dtype(args):
+    if getattr(args, "policy_dtype", None):
+        from egogen_amd import _lib
+        _lib.check(_lib.load().egx_policy_set_precision(1 if args.policy_dtype == "bf16" else 0), "egx_policy_set_precision")
 
 
 def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True):
@@ -82,6 +91,7 @@ def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True
     if not torch.cuda.is_available():
         raise SystemExit("crowd_ppo needs a HIP device: the MI355X path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    _apply_policy_dtype(args)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dirs = sw.create_dirs(cfg_name)

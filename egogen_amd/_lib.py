@@ -142,6 +142,8 @@ SIGNATURES = {
     "egx_adamw_workspace_floats": (C.c_size_t, []),
     "egx_adamw_clip_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float] + [C.c_double] * 5 +
                             [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egx_policy_set_precision": (C.c_int, [C.c_int]),
+    "egx_policy_get_precision": (C.c_int, []),
     "egx_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "egx_act_bwd_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                      C.c_void_p]),

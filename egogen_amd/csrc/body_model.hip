@@ -68,18 +68,6 @@ static_assert(KGROUPS >= 2, "the operand ring preloads two k-groups");
 // (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid), accumulated in fp32 by v_mfma_f32_32x32x16_bf16 - 6 MFMAs of 32 cycles
 // per 16 k instead of 8 fp32 MFMAs of 64 cycles.  K is padded to 480 = 30 steps of 16.
 constexpr int KS3 = 30;
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-__host__ __device__ inline unsigned short egx_bf16_rne(float x) {
-  union { float f; unsigned u; } c;
-  c.f = x;
-  if ((c.u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((c.u >> 16) | 0x40u);
-  return (unsigned short)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
-}
-__host__ __device__ inline float egx_bf16_to_f32(unsigned short h) {
-  union { float f; unsigned u; } c;
-  c.u = (unsigned)h << 16;
-  return c.f;
-}
 __host__ __device__ inline void egx_bf16_split3(float x, unsigned short* h) {
   h[0] = egx_bf16_rne(x);
   const float r1 = x - egx_bf16_to_f32(h[0]);   // exact

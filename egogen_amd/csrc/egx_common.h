@@ -9,6 +9,19 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__host__ __device__ inline unsigned short egx_bf16_rne(float x) {
+  union { float f; unsigned u; } c;
+  c.f = x;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((c.u >> 16) | 0x40u);
+  return (unsigned short)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ inline float egx_bf16_to_f32(unsigned short h) {
+  union { float f; unsigned u; } c;
+  c.u = (unsigned)h << 16;
+  return c.f;
+}
+
 
 void egx_set_error(const std::string& msg);
 

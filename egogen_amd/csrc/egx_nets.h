@@ -24,6 +24,7 @@ struct EgxLin {
   int ldr;
   float* out;
   int ldo;
+  int bf16 = 0;  // 1: operands rounded to bf16, products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (config-5 policy inference)
 };
 int egx_launch_linear_pair(hipStream_t st, const EgxLin& A, const EgxLin& B);
 int egx_launch_gru_pointwise(hipStream_t st, const float* gi, const float* gh, const float* hprev, int ldh, float* hout,
@@ -39,5 +40,6 @@ struct RegWeights {
 };
 int egx_launch_regressor_fused(hipStream_t st, const RegWeights& w, const float* Y, const float* betas, int A, int M,
                                float* out_Yb);
+int egx_launch_linear_one(hipStream_t st, const EgxLin& A);  // honours EgxLin::bf16 (always the 32x32 split-K kernel)
 // y[t][a][c] += y[t-1][a][c] for t = 0..T-1 with y[-1] = x_last[a][c] (row stride x_ld): residual chain of the decoder
 void egx_launch_frame_scan(hipStream_t st, float* y, const float* x_last, int x_ld, int A, int width, int T);

@@ -26,6 +26,7 @@ struct LinArgs {
   int M, N, K;
   int act;      // 0 none, 1 tanh, 2 relu, 3 leaky relu
   float slope;
+  int bf16;     // operands rounded to bf16 (RNE), fp32 accumulate
 };
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -143,12 +144,28 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
       *reinterpret_cast<f32x4*>(xs + (q * 8 + lr) * 36 + lc) = gx[q];
       *reinterpret_cast<f32x4*>(ws + (q * 8 + lr) * 36 + lc) = gw[q];
     }
+    if (a.bf16) {
+      // two 16-wide k sub-blocks: lane (i, h) holds k = 16 s + 8 h + 0..7 of row i as 8 bf16 (A and B alike)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
+      for (int sb = 0; sb < 2; ++sb) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h), x1 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h + 4);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h), w1 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h + 4);
+        bf16x8 xa, wb;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          xa[e] = (short)egx_bf16_rne(x0[e]); xa[4 + e] = (short)egx_bf16_rne(x1[e]);
+          wb[e] = (short)egx_bf16_rne(w0[e]); wb[4 + e] = (short)egx_bf16_rne(w1[e]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wb, acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
+      }
     }
   }
   // split-K reduction through the (now idle) staging strips
@@ -492,8 +509,9 @@ __global__ void egx_gae_kernel(const float* __restrict__ v, const float* __restr
 
 // ---- internal launchers ---------------------------------------------------------------------------
 static LinArgs make_lin_args(int M, int N, const EgxSeg* segs, int nseg, const float* W, int ldw, const float* b, int act,
-                             float slope, const float* res, int ldr, float* out, int ldo) {
+                             float slope, const float* res, int ldr, float* out, int ldo, int bf16 = 0) {
   LinArgs a;
+  a.bf16 = bf16;
   const float* ps[4] = {nullptr, nullptr, nullptr, nullptr};
   int ws[4] = {0, 0, 0, 0}, ls[4] = {0, 0, 0, 0};
   int K = 0;
@@ -529,11 +547,20 @@ int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg
   return EGX_OK;
 }
 
+int egx_launch_linear_one(hipStream_t st, const EgxLin& A) {
+  LinArgs2 two;
+  two.p0 = make_lin_args(A.M, A.N, A.segs, A.nseg, A.W, A.ldw, A.b, A.act, A.slope, A.res, A.ldr, A.out, A.ldo, A.bf16);
+  two.p1 = two.p0;
+  two.blocks0 = lin_blocks(two.p0);
+  hipLaunchKernelGGL(egx_linear_kernel, dim3(two.blocks0), dim3(256), 0, st, two);
+  return EGX_OK;
+}
+
 // two independent GEMMs in one launch (e.g. the x-side and h-side products of a GRU cell)
 int egx_launch_linear_pair(hipStream_t st, const EgxLin& A, const EgxLin& B) {
   LinArgs2 two;
-  two.p0 = make_lin_args(A.M, A.N, A.segs, A.nseg, A.W, A.ldw, A.b, A.act, A.slope, A.res, A.ldr, A.out, A.ldo);
-  two.p1 = make_lin_args(B.M, B.N, B.segs, B.nseg, B.W, B.ldw, B.b, B.act, B.slope, B.res, B.ldr, B.out, B.ldo);
+  two.p0 = make_lin_args(A.M, A.N, A.segs, A.nseg, A.W, A.ldw, A.b, A.act, A.slope, A.res, A.ldr, A.out, A.ldo, A.bf16);
+  two.p1 = make_lin_args(B.M, B.N, B.segs, B.nseg, B.W, B.ldw, B.b, B.act, B.slope, B.res, B.ldr, B.out, B.ldo, B.bf16);
   two.blocks0 = lin_blocks(two.p0);
   hipLaunchKernelGGL(egx_linear_kernel, dim3(two.blocks0 + lin_blocks(two.p1)), dim3(256), 0, st, two);
   return EGX_OK;

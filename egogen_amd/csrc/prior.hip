@@ -1,5 +1,6 @@
 // Whole-network entry points: the motion prior (C-VAE decode + body regressor), the policy networks and
 // the VPoser encoder, each as one C call that enqueues its chain of fused dense-layer kernels.
+#include <atomic>
 #include "egx_nets.h"
 
 namespace {
@@ -135,6 +136,16 @@ extern "C" size_t egx_policy_workspace_bytes(int n) {
                       m * 1536, m * 1536, m * 512, m * 1152, m * 1152, m * 1152});
 }
 
+namespace {
+std::atomic<int> g_policy_bf16{0};
+}
+extern "C" int egx_policy_set_precision(int bf16) {
+  EGX_REQUIRE(bf16 == 0 || bf16 == 1, "precision must be 0 (fp32 MFMA) or 1 (bf16 operands, fp32 accumulate)");
+  g_policy_bf16.store(bf16);
+  return EGX_OK;
+}
+extern "C" int egx_policy_get_precision(void) { return g_policy_bf16.load(); }
+
 extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* state, const float* ego, const float* dist,
                                   const float* time, int n, float* out_mu, float* out_logvar, float* out_value,
                                   void* workspace, size_t workspace_bytes, void* stream_) {
@@ -158,12 +169,14 @@ extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* stat
   float* a2 = cv.take(m * 1152);
   float* zp = cv.take(m * 256);
   constexpr int HD = 512;
-  auto lin = [](int M, int N, std::initializer_list<EgxSeg> segs, const float* W, const float* b, int act, float slope,
-                const float* res, int ldr, float* out, int ldo) {
+  const int bf = g_policy_bf16.load();
+  auto lin = [bf](int M, int N, std::initializer_list<EgxSeg> segs, const float* W, const float* b, int act, float slope,
+                  const float* res, int ldr, float* out, int ldo) {
     EgxLin l;
     l.M = M; l.N = N; l.nseg = 0;
     for (const EgxSeg& sg : segs) l.segs[l.nseg++] = sg;
     l.W = W; l.ldw = 0; l.b = b; l.act = act; l.slope = slope; l.res = res; l.ldr = ldr; l.out = out; l.ldo = ldo;
+    l.bf16 = bf;
     return l;
   };
   // two independent 2-step GRUs (markers+features 402 -> 512, egosensing 32 -> 512): their products share launches
@@ -197,8 +210,8 @@ extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* stat
   // h = hx; for blk: h = lrelu(fc2(lrelu(fc1(h)))) + h ; y = out_fc(h)   - actor and critic layer i share a launch
   auto run = [&](const EgxLin& la, const EgxLin& lc) {
     if (do_a && do_c) egx_launch_linear_pair(st, la, lc);
-    else if (do_a) egx_launch_linear(st, la.M, la.N, la.segs, la.nseg, la.W, la.b, la.act, la.slope, la.res, la.ldr, la.out, la.ldo);
-    else egx_launch_linear(st, lc.M, lc.N, lc.segs, lc.nseg, lc.W, lc.b, lc.act, lc.slope, lc.res, lc.ldr, lc.out, lc.ldo);
+    else if (do_a) egx_launch_linear_one(st, la);
+    else egx_launch_linear_one(st, lc);
   };
   run(layer(hxcat, w->actor_w[0], w->actor_b[0], 1152, 3, nullptr, a1, 1152), layer(hxcat, w->critic_w[0], w->critic_b[0], 1152, 3, nullptr, c1, 1152));
   run(layer(a1, w->actor_w[1], w->actor_b[1], 1152, 3, hxcat, a2, 1152), layer(c1, w->critic_w[1], w->critic_b[1], 1152, 3, hxcat, c2, 1152));

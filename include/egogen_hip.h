@@ -221,6 +221,13 @@ typedef struct egx_policy_weights {
   const float *critic_out_w, *critic_out_b; /* critic.vnet.out_fc 1x1152                     */
 } egx_policy_weights;
 
+/* Arithmetic of the dense layers inside egx_policy_forward (process-wide): 0 = fp32 MFMA (default; 1e-4 parity with the
+ * reference's fp32 policy), 1 = operands rounded to bf16, products on the bf16 MFMA, fp32 accumulation - BASELINE config 5
+ * ("main_crowd_eval ... bf16 MFMA policy"), whose parity is statistical.  Gate math, biases, activations
+ * and outputs stay fp32. */
+int egx_policy_set_precision(int bf16);
+int egx_policy_get_precision(void);
+
 size_t egx_policy_workspace_bytes(int num_rows);
 
 /*   state [n,2,402], egosensing [n,2,32], dist [n], time [n]   (the obs dict, crowd_env_2f.py:311-312)

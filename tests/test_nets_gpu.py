@@ -132,3 +132,32 @@ def test_vposer_encoder_matches_oracle():
     out = enc.encode_mean(x.cuda())
     ref = nets.vposer_encode({k: v.float() for k, v in vals.items()}, x)
     assert max_abs(out.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_policy_bf16_mode_is_close_to_fp32_and_restorable():
+    """BASELINE config 5: bf16 operands / fp32 accumulate in the policy's dense layers.  Parity is statistical (SURVEY 8(d)
+    C5): over 256 observations the outputs stay within bf16 round-off of the fp32 policy, and switching back restores the
+    fp32 results bit for bit."""
+    from egogen_amd import _lib
+    from egogen_amd.models import GAMMAActor, GAMMACritic, GAMMAPolicyBase, POLICY_CFG, PolicyHipRunner
+    lib = _lib.load()
+    torch.manual_seed(0)
+    shared, actor, critic = GAMMAPolicyBase(POLICY_CFG).cuda(), GAMMAActor(POLICY_CFG).cuda(), GAMMACritic(POLICY_CFG).cuda()
+    run = PolicyHipRunner(shared, actor, critic)
+    g = torch.Generator().manual_seed(1)
+    n = 256
+    obs = {"state": (torch.randn(n, 2, 402, generator=g) * 0.3).cuda(), "egosensing": (torch.rand(n, 2, 32, generator=g) * 2 - 1).cuda(),
+           "dist": torch.rand(n, generator=g).cuda(), "time": torch.rand(n, generator=g).cuda()}
+    ref = {k: v.clone() for k, v in run.forward(obs).items()}
+    try:
+        _lib.check(lib.egx_policy_set_precision(1), "egx_policy_set_precision")
+        assert lib.egx_policy_get_precision() == 1
+        low = {k: v.clone() for k, v in run.forward(obs).items()}
+    finally:
+        _lib.check(lib.egx_policy_set_precision(0), "egx_policy_set_precision")
+    again = run.forward(obs)
+    for k in ("mu", "logvar", "value"):
+        assert torch.equal(again[k], ref[k]), k
+        scale = float(ref[k].abs().mean()) + 1e-6
+        err = float((low[k] - ref[k]).abs().mean()) / scale
+        assert 1e-6 < err < 3e-2, (k, err)   # different from fp32, but by bf16 round-off only

@@ -233,6 +233,28 @@ def test_main_crowd_eval_entry_point(tmp_path):
     assert d["motion"][0]["blended_marker"].shape == (20, 67, 3) and d["wpath"].shape == (2, 3)
 
 
+def test_crowd_eval_bf16_policy_is_statistically_equivalent(tmp_path):
+    """Config 5 (bf16 policy): episode statistics over 64 four-human scenes (256 humans) against the fp32 policy, same
+    seeds - statistical parity, not 1e-4."""
+    import re
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    res = {}
+    for dt in ("fp32", "bf16"):
+        wd = tmp_path / dt
+        wd.mkdir()
+        cmd = [sys.executable, os.path.join(ROOT, "crowd_ppo", "main_crowd_eval.py"), "--test-num", "256", "--num-verts", "1024",
+               "--seed", "3", "--num-scenes", "64", "--policy-dtype", dt]
+        r = subprocess.run(cmd, cwd=wd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        m = re.search(r"Final reward: ([-0-9.eE+]+), length: ([-0-9.eE+]+)", r.stdout)
+        assert m, r.stdout[-1000:]
+        res[dt] = (float(m.group(1)), float(m.group(2)))
+        assert ("bf16 operands" in r.stdout) == (dt == "bf16")
+    (r32, l32), (r16, l16) = res["fp32"], res["bf16"]
+    assert abs(l32 - l16) <= 0.5, res                                   # mean episode length (steps)
+    assert abs(r32 - r16) <= 0.1 * max(1.0, abs(r32)), res              # mean episode reward
+
+
 def test_update_glue_kernels():
     """egx_gather_rows / egx_adv_stats / egx_track_episode / egx_act_fwd / egx_act_bwd_colsum against torch."""
     from egogen_amd import _lib
