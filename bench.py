@@ -52,6 +52,8 @@ def get_args():
     p.add_argument("--sdf-res", type=int, default=256)
     p.add_argument("--vec-steps", type=int, default=4, help="vector steps per collect")
     p.add_argument("--batch-size", type=int, default=256, help="minibatch per rank")
+    p.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"],
+                   help="weak: --agents and --batch-size per GPU (BASELINE configs[3]); strong: both are totals split over the ranks")
     p.add_argument("--num-verts", type=int, default=10475)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-agent-steps", type=int, default=6)
@@ -186,6 +188,10 @@ def main():
     from egogen_amd.trainer import Collector
     lib = _lib.load()
 
+    if args.scaling == "strong":  # fixed total work: 512 agents and one 256-sample minibatch over all ranks
+        assert args.agents % world == 0 and args.batch_size % world == 0, "--agents / --batch-size must divide by the rank count"
+        args.agents //= world
+        args.batch_size //= world
     A = args.agents
     pa = PolicyArgs()
     pa.update_graph = bool(args.update_graph)
@@ -290,7 +296,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32" if blend == 0 else "f32 (blend GEMM operands as 3-term bf16 splits, fp32 accumulate)",
         "data": "synthetic",
