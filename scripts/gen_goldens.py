@@ -133,6 +133,22 @@ def main():
     np.savez_compressed(os.path.join(OUT, "canon_ref.npz"), jts=jts.numpy(), R=R.numpy(), T=T.numpy())
     print("canon_ref", R.shape, T.shape)
 
+    # ---- axis-angle -> rotation matrix: the in-tree kornia-derived copy (experiments/HMR/prohmr/utils/konia_transform.py:234-310).
+    # torchgeometry 0.1.2 (what motion/ calls, baseops.py:560-575) is not in the tree; this copy evaluates the same formulas
+    # (theta^2 > 1e-6 switch to the first-order form) and differs only by a clamp inside the branch that the switch masks
+    # out, so its outputs pin the oracle's restatement for every input.
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "konia_transform", os.path.join(REF, "..", "experiments", "HMR", "prohmr", "utils", "konia_transform.py"))
+    kt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kt)
+    ga = torch.Generator().manual_seed(77)  # own generator: the fixtures generated after this block keep their inputs
+    aa = torch.randn(64, 3, generator=ga) * torch.logspace(-5, 0.5, 64).unsqueeze(1)  # 1e-5 .. 3 rad, both branches
+    aa[0] = 0.0
+    Raa = kt.angle_axis_to_rotation_matrix(aa.clone())
+    np.savez_compressed(os.path.join(OUT, "aa2rot_ref.npz"), aa=aa.numpy(), R=Raa.numpy())
+    print("aa2rot_ref", Raa.shape)
+
     # ---- policy ---------------------------------------------------------------------------------
     from models.models_policy_ppo import GAMMAPolicyBase, GAMMAActor, GAMMACritic
     cfg = {"h_dim": 512, "z_dim": 128, "n_blocks": 2, "n_recur": -1, "body_repr": "ssm2_67_condi_marker_map",

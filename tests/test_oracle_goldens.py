@@ -61,3 +61,14 @@ def test_canonical_frame_matches_reference():
     R, T = oenv.get_new_coordinate(torch.from_numpy(g["jts"]))
     assert max_abs(R.numpy(), g["R"]) < 1e-6
     assert max_abs(T.numpy(), g["T"]) == 0.0
+
+
+def test_angle_axis_to_rotation_matrix_matches_in_tree_copy():
+    """rot.tgm_angle_axis_to_rotation_matrix against the outputs of the reference tree's kornia-derived
+    angle_axis_to_rotation_matrix (experiments/HMR/prohmr/utils/konia_transform.py:234-310; same formulas and the same
+    theta^2 > 1e-6 switch as torchgeometry 0.1.2), angles from 1e-5 to 3 rad and the zero vector."""
+    from oracle import rot
+    g = load_golden("aa2rot_ref.npz")
+    R = rot.tgm_angle_axis_to_rotation_matrix(torch.from_numpy(g["aa"]))
+    assert max_abs(R.numpy(), g["R"]) < 1e-6
+    # and the HIP-side convention (egx_tgm_aa_to_rotmat mirrors the same function) is covered by tests/test_env_gpu.py
