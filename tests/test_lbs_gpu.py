@@ -207,12 +207,13 @@ def test_lbs_invariants_full_size():
     assert (dist1 - dist4).abs().max() < 2e-5
 
 
-def test_lbs_batch_independence_full_size(blend_mode):
+@pytest.mark.parametrize("A", [512, 1100])
+def test_lbs_batch_independence_full_size(A, blend_mode):
     """BASELINE scale (512 agents x 20 frames, V = 10475): a body's picks and penetration count do not depend on what else
     is in the launch - the first 37 agents evaluated alone are bit-identical to their rows of the 10240-body launch."""
     from egogen_amd.body_model import SdfScene
     bm, mk, feet, h, _ = _setup(10475)
-    A, T, As = 512, 20, 37
+    T, As = 20, 37   # A = 1100: 22 000 bodies, 86 body groups (ragged last group, uneven split over the 8 XCD chunks)
     xb, betas = _poses(A, T, seed=3)
     xb[:, 2] = 0.3
     xb, betas = xb.cuda(), betas.cuda()
