@@ -8,25 +8,34 @@ One "step" = one on-policy cycle over one batch of synthetic input:
     update   critic values + GAE, then all minibatches of the clipped-PPO update (AdamW, grad-norm clip)
 value = transitions of all ranks / wall time of K such steps (max over ranks), inputs resident in HBM.
 
-Workload (BASELINE.json: metric quoted on 512 parallel SMPL-X agents; configs[1]/[2]): A = 512 agents per GPU,
-synthetic seeded SMPL-X-shaped body (V = 10475), single-box SDF scene 256^3 by default (`--scene box` = random-box
-scene set with the walkability-map penetration term), random-init networks, 4 vector steps per collect (2048
-transitions), minibatch 256 per rank -> 8 optimiser steps per collect, repeat 1.
+Workload (BASELINE.json: metric quoted on 512 parallel SMPL-X agents; configs[1]/[2]): 512 agents in total, synthetic
+seeded SMPL-X-shaped body (V = 10475), single-box SDF scene 256^3 by default (`--scene box` = random-box scene set with
+the walkability-map penetration term), random-init networks, 4 vector steps per collect (2048 transitions), global
+minibatch 256 -> 8 optimiser steps per collect, repeat 1.
 
-N > 1 (weak scaling): every rank owns A agents and its own scene replica; the only collectives are the
-advantage-moment all-reduce (3 doubles) and one flat 52.7 MB gradient all-reduce per optimiser step.
+`--gpus N` (N > 1): when not already running under torch.distributed.run, bench.py re-launches itself with N ranks (one
+process per GPU, RCCL).  Default `--scaling strong` (SURVEY 8(d) C4 headline): the 512 agents and the 256-sample
+minibatch are split over the ranks; `--scaling weak` keeps 512 agents and a 256-sample minibatch PER rank (reported as
+the `weak` object of the same JSON line when N > 1).  The only collectives are one float64 all-reduce of the advantage
+moments of all minibatches per collect and one flat 52.7 MB gradient all-reduce per optimiser step (`allreduce` object:
+time inside the loop, stand-alone time, bus bandwidth).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = egx_lbs_fused_kernel (fp32-MFMA blend GEMM + skinning + SDF epilogue);
-                achieved = 2*469*31425 FLOP/body * bodies per launch / average launch duration measured with HIP events
-                recorded around that kernel inside the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md)
-  cpu_baseline  the CPU oracle (port of the reference's per-agent, x4-replicated structure) timed on the host cores
-                on a bounded sample (rank 0, N = 1 only)
+  roofline      dominant kernel = fused LBS kernel (blend GEMM + skinning + SDF epilogue); achieved = 2*469*31425
+                FLOP/body * bodies per launch / average launch duration measured with HIP events recorded around that
+                kernel inside the timed region; peak stated for the blend mode in use; `in_scene` = the same launch timed
+                with every body inside the scene (SDF queue path live)
+  cpu_baseline  the CPU oracle (port of the reference's per-agent, x4-replicated structure) timed on the host cores on a
+                bounded sample (rank 0, N = 1 only): all threads, one thread, and a batched-CPU (A = 64) variant
+  other_configs (N = 1) the same loop on BASELINE configs[2] (`--scene box`) and on the reference-default shape
+                (256 agents, 1024 transitions per collect)
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,7 +48,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_BODY = 2.0 * 469 * 31425          # blend GEMM only: K = 10 betas + 9 x 51 movable joints (jaw/eye columns are exactly 0)
 PEAK_F32_MFMA_TFLOPS = 157.3               # dense fp32 MFMA peak (MI355X_MICROARCH.md)
-PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 MFMA peak (same guide); the bf16x3 blend issues 6 bf16 products per fp32 product
+PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 MFMA peak (same guide)
+BLEND_PRODUCTS = {0: None, 1: 6, 2: 3}     # bf16 partial products per fp32 product of the split blend modes
 
 
 def get_args():
@@ -47,16 +57,20 @@ def get_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=6)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--agents", type=int, default=512, help="agents per GPU")
+    p.add_argument("--agents", type=int, default=512, help="agents (total with --scaling strong, per GPU with weak)")
     p.add_argument("--scene", type=str, default="single_box", choices=["single_box", "room0", "box"])
     p.add_argument("--sdf-res", type=int, default=256)
     p.add_argument("--vec-steps", type=int, default=4, help="vector steps per collect")
-    p.add_argument("--batch-size", type=int, default=256, help="minibatch per rank")
-    p.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"],
-                   help="weak: --agents and --batch-size per GPU (BASELINE configs[3]); strong: both are totals split over the ranks")
+    p.add_argument("--batch-size", type=int, default=256, help="minibatch (global with --scaling strong, per GPU with weak)")
+    p.add_argument("--scaling", type=str, default="strong", choices=["weak", "strong"],
+                   help="strong: --agents / --batch-size are totals split over the ranks (512 agents: the BASELINE metric); "
+                        "weak: both are per GPU")
+    p.add_argument("--also-weak", type=int, default=1, help="N > 1 with --scaling strong: time the weak-scaling shape as well")
     p.add_argument("--num-verts", type=int, default=10475)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-agent-steps", type=int, default=6)
+    p.add_argument("--cpu-seconds", type=float, default=20.0, help="time cap of each CPU-baseline leg")
+    p.add_argument("--cpu-agent-steps", type=int, default=200, help="agent-steps of each sequential CPU-baseline leg (or the time cap)")
+    p.add_argument("--extra-configs", type=int, default=1, help="N = 1: also time configs[2] and the reference-default shape")
     p.add_argument("--graph", type=int, default=0, help="capture the env step into a HIP graph")
     p.add_argument("--update-graph", type=int, default=1, help="replay the PPO minibatch update as HIP graphs")
     return p.parse_args()
@@ -80,17 +94,28 @@ class PolicyArgs:
     deterministic_eval = False
 
 
-def cpu_baseline(args, scene, n_agent_steps, budget_s=20.0):
-    """Reference-structured CPU path (oracle): one agent at a time, batch replicated x4 (crowd_env_2f.py:29-32), host ray
-    casting, plus the CPU cost of the PPO update per transition."""
+def _physical_cores():
+    try:
+        out = subprocess.run(["lscpu", "-p=core,socket"], capture_output=True, text=True, timeout=10).stdout
+        return len({ln for ln in out.splitlines() if ln and not ln.startswith("#")}) or None
+    except Exception:
+        return None
+
+
+def cpu_baseline(args, scene):
+    """Reference-structured CPU path (oracle), SURVEY 8(d): one agent at a time with the batch replicated x4
+    (crowd_env_2f.py:29-32), host ray casting, DummyVectorEnv-style sequential loop - timed after warm-up on all host
+    threads and on one thread - plus a batched-CPU variant (64 agents in one tensor) so that the gain from batching and
+    the gain from the GPU are separable, plus the CPU cost of the PPO update per transition (mean of warm minibatches)."""
     from egogen_amd import synth
     from egogen_amd.models import (ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase, GAMMAPrimitiveCombo, POLICY_CFG,
                                    PREDICTOR_CFG, REGRESSOR_CFG, VPoserEncoder)
     from oracle.env import OracleCrowdEnv
     from oracle.smplx_lbs import BodyModel
     from oracle import nets as onets, ppo as oppo
-    cores = min(os.cpu_count() or 1, 32)   # more threads only add fork/join overhead at these tensor sizes
-    torch.set_num_threads(cores)
+    logical = os.cpu_count() or 1
+    physical = _physical_cores()
+    n_all = min(logical, physical or logical)
     V = args.num_verts
     bm = synth.make_body_model(0, num_verts=V)
     torch.manual_seed(0)
@@ -98,79 +123,279 @@ def cpu_baseline(args, scene, n_agent_steps, budget_s=20.0):
     vp = VPoserEncoder().eval()
     psd = {k: v.detach() for k, v in combo.state_dict().items()}
     vsd = {k: v.detach().float() for k, v in vp.state_dict().items()}
-    if scene["scene_kind"] == "sdf":
+    sdf_scene = scene["scene_kind"] == "sdf"
+    if sdf_scene:
         sd = {k: torch.as_tensor(np.asarray(scene["sdf_dict"][k])) for k in ("sdf", "center", "scale")}
         okw = dict(scene_kind="sdf", sdf_dict=sd, edges=synth.rings_to_edges(scene["rings"]))
-        pairs = np.asarray(scene["pairs"][:n_agent_steps], np.float32)
+        pairs_all = np.asarray(scene["pairs"], np.float32)
     else:
         okw = dict(scene_kind="box", box_scenes=scene["box_scenes"])
-        pairs = np.asarray(scene["box_scenes"][0]["pairs"][:n_agent_steps], np.float32)
+        pairs_all = np.asarray(scene["box_scenes"][0]["pairs"], np.float32)
     o = OracleCrowdEnv(BodyModel(bm), psd, vsd, synth.marker_ids(V), synth.feet_vids(V), synth.feet_marker_idx(), **okw)
     ms = synth.load_assets()
-    rep = 4
-    poses = torch.tensor(ms["seed_poses"][5:7, :66], dtype=torch.float32)[None].repeat(rep, 1, 1)
-    trans = torch.tensor(ms["seed_trans"][5:7], dtype=torch.float32)[None].repeat(rep, 1, 1)
-    betas = torch.tensor(ms["seed_betas"], dtype=torch.float32).reshape(1, 10).repeat(rep, 1)
     ac = ActorCritic(GAMMAActor(POLICY_CFG), GAMMACritic(POLICY_CFG), GAMMAPolicyBase(POLICY_CFG))
     pol_sd = {k: v.detach() for k, v in ac.state_dict().items()}
-    t_env = 0.0
     g = torch.Generator().manual_seed(0)
-    with torch.no_grad():
-        t_begin = time.perf_counter()
-        done = 0
-        for i in range(n_agent_steps):
-            if done >= 2 and time.perf_counter() - t_begin > budget_s:
-                break
-            done += 1
-            st = torch.as_tensor(pairs[i:i + 1, 0]).repeat(rep, 1)
-            tg = torch.as_tensor(pairs[i:i + 1, 1]).repeat(rep, 1)
+
+    def seeds(rep):
+        return (torch.tensor(ms["seed_poses"][5:7, :66], dtype=torch.float32)[None].repeat(rep, 1, 1),
+                torch.tensor(ms["seed_trans"][5:7], dtype=torch.float32)[None].repeat(rep, 1, 1),
+                torch.tensor(ms["seed_betas"], dtype=torch.float32).reshape(1, 10).repeat(rep, 1))
+
+    def one_vector_step(pair_rows, rep_each):
+        """reset (amortised over ~max_depth steps) + policy + env step for len(pair_rows) * rep_each batch rows."""
+        rep = len(pair_rows) * rep_each
+        poses, trans, betas = seeds(rep)
+        st = torch.as_tensor(pairs_all[pair_rows, 0]).repeat_interleave(rep_each, 0)
+        tg = torch.as_tensor(pairs_all[pair_rows, 1]).repeat_interleave(rep_each, 0)
+        t0 = time.perf_counter()
+        tr, go, bp, wp = o.next_body(st, tg, poses, trans, betas, yaw_jitter=None if sdf_scene else torch.zeros(rep))
+        obs, _ = o.reset_from(tr, go, bp, betas, wp, scene_idx=None if sdf_scene else [0] * rep)
+        t_reset = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        hx = onets.policy_base(pol_sd, obs)
+        mu, lv = onets.policy_actor(pol_sd, hx)
+        onets.policy_critic(pol_sd, hx)
+        z = mu + torch.exp(lv.clamp(-2.5, 2.5)) ** 0.5 * torch.randn(rep, 128, generator=g)
+        o.step(z)
+        return time.perf_counter() - t0 + t_reset / 11.0   # one reset per ~max_depth steps
+
+    def sequential(threads, warm, n_steps, budget_s):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            for i in range(warm):
+                one_vector_step([i % len(pairs_all)], 4)
+            t_env, done, t_begin = 0.0, 0, time.perf_counter()
+            while done < n_steps and (done < 3 or time.perf_counter() - t_begin < budget_s):
+                t_env += one_vector_step([(warm + done) % len(pairs_all)], 4)
+                done += 1
+        return t_env / done, done
+
+    def batched(threads, A, budget_s):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            one_vector_step(list(range(A)), 1)
+            t_env, done, t_begin = 0.0, 0, time.perf_counter()
+            while done < 2 or (time.perf_counter() - t_begin < budget_s and done < 20):
+                t_env += one_vector_step([(done * A + i) % len(pairs_all) for i in range(A)], 1)
+                done += 1
+        return t_env / (done * A), done * A
+
+    def update_leg(threads, n_mb=6):
+        """one 256-sample minibatch forward + loss + backward + clip + AdamW on the CPU; the first call is warm-up"""
+        torch.set_num_threads(threads)
+        ac.train()
+        opt = torch.optim.AdamW(ac.parameters(), lr=3e-4, weight_decay=0.01)
+        B = 256
+        ts = []
+        for i in range(n_mb):
+            gg = torch.Generator().manual_seed(10 + i)
+            obs = {"state": torch.randn(B, 2, 402, generator=gg), "egosensing": torch.rand(B, 2, 32, generator=gg),
+                   "dist": torch.rand(B, generator=gg), "time": torch.rand(B, generator=gg)}
+            act, adv, ret = torch.randn(B, 128, generator=gg), torch.randn(B, generator=gg), torch.randn(B, generator=gg)
+            lpo = torch.randn(B, generator=gg) - 180
             t0 = time.perf_counter()
-            tr, go, bp, wp = o.next_body(st, tg, poses, trans, betas,
-                                         yaw_jitter=None if scene["scene_kind"] == "sdf" else torch.zeros(rep))
-            obs, _ = o.reset_from(tr, go, bp, betas, wp, scene_idx=None if scene["scene_kind"] == "sdf" else [0] * rep)
-            t_reset = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            hx = onets.policy_base(pol_sd, obs)
-            mu, lv = onets.policy_actor(pol_sd, hx)
-            onets.policy_critic(pol_sd, hx)
-            z = mu + torch.exp(lv.clamp(-2.5, 2.5)) ** 0.5 * torch.randn(rep, 128, generator=g)
-            o.step(z)
-            t_env += time.perf_counter() - t0 + t_reset / 11.0   # one reset per ~max_depth steps
-    n_agent_steps = done
-    per_step = t_env / n_agent_steps
-    # PPO update cost per transition: one minibatch of 256 forward+backward+AdamW on the CPU
-    ac.train()
-    opt = torch.optim.AdamW(ac.parameters(), lr=3e-4, weight_decay=0.01)
-    B = 256
-    obs = {"state": torch.randn(B, 2, 402), "egosensing": torch.rand(B, 2, 32), "dist": torch.rand(B), "time": torch.rand(B)}
-    act, adv, ret, lpo = torch.randn(B, 128), torch.randn(B), torch.randn(B), torch.randn(B) - 180
-    t0 = time.perf_counter()
-    hx = ac.shared_net(obs)
-    (mu, lv), _ = ac.actor(hx)
-    loss, _ = oppo.ppo_loss(mu, lv, ac.critic(hx), act, adv, ret, lpo)
-    opt.zero_grad()
-    loss.backward()
-    torch.nn.utils.clip_grad_norm_(list(ac.actor.parameters()) + list(ac.critic.parameters()), 0.1)
-    opt.step()
-    per_trans_update = (time.perf_counter() - t0) / B
-    return {"value": 1.0 / (per_step + per_trans_update), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_agent_steps} agent-steps of the oracle env (V={V}, batch x4 per agent as in the reference, "
-                      f"{per_step * 1e3:.0f} ms each) + one 256-sample PPO minibatch on CPU ({per_trans_update * 1e3:.2f} ms/transition)"}
+            hx = ac.shared_net(obs)
+            (mu, lv), _ = ac.actor(hx)
+            loss, _ = oppo.ppo_loss(mu, lv, ac.critic(hx), act, adv, ret, lpo)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(list(ac.actor.parameters()) + list(ac.critic.parameters()), 0.1)
+            opt.step()
+            ts.append(time.perf_counter() - t0)
+        return float(np.mean(ts[1:])) / B, n_mb - 1
+
+    warm = max(2, min(20, args.cpu_agent_steps // 10))
+    upd_all, n_upd = update_leg(n_all)
+    upd_1, _ = update_leg(1, n_mb=3)
+    seq_all, n_seq_all = sequential(n_all, warm, args.cpu_agent_steps, args.cpu_seconds)
+    seq_1, n_seq_1 = sequential(1, max(1, warm // 4), args.cpu_agent_steps, args.cpu_seconds)
+    bat_all, n_bat = batched(n_all, 64, args.cpu_seconds)
+    seq_32 = None
+    if n_all > 32:  # small tensors: more threads than this mostly add fork/join overhead - report the 32-thread rate beside it
+        upd_32, _ = update_leg(32, n_mb=4)
+        seq_32, n_seq_32 = sequential(32, max(1, warm // 4), args.cpu_agent_steps, args.cpu_seconds / 2)
+    torch.set_num_threads(n_all)
+    legs = {
+        "sequential_all_threads": {"value": 1.0 / (seq_all + upd_all), "threads": n_all, "agent_steps": n_seq_all, "warmup": warm,
+                                   "ms_per_agent_step": seq_all * 1e3, "update_ms_per_transition": upd_all * 1e3},
+        "sequential_1_thread": {"value": 1.0 / (seq_1 + upd_1), "threads": 1, "agent_steps": n_seq_1, "warmup": max(1, warm // 4),
+                                "ms_per_agent_step": seq_1 * 1e3, "update_ms_per_transition": upd_1 * 1e3},
+        "batched_64_all_threads": {"value": 1.0 / (bat_all + upd_all), "threads": n_all, "agent_steps": n_bat, "warmup": 64,
+                                   "ms_per_agent_step": bat_all * 1e3, "update_ms_per_transition": upd_all * 1e3},
+    }
+    if seq_32 is not None:
+        legs["sequential_32_threads"] = {"value": 1.0 / (seq_32 + upd_32), "threads": 32, "agent_steps": n_seq_32,
+                                         "warmup": max(1, warm // 4), "ms_per_agent_step": seq_32 * 1e3,
+                                         "update_ms_per_transition": upd_32 * 1e3}
+    return {"value": legs["sequential_all_threads"]["value"], "unit": "env-steps/s", "cores": n_all, "kind": "port",
+            "host": {"os_cpu_count": logical, "lscpu_physical_cores": physical},
+            "sample": f"oracle env (V={V}, scene={args.scene}) one agent at a time with the reference's x4-replicated batch: "
+                      f"{n_seq_all} agent-steps after {warm} warm-up on {n_all} threads ({seq_all * 1e3:.0f} ms each) + the CPU PPO update "
+                      f"({n_upd} warm 256-sample minibatches, {upd_all * 1e3:.3f} ms/transition); legs: same on 1 thread, and 64 agents "
+                      f"batched in one tensor",
+            "legs": legs}
 
 
 def _log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks on this node (one process per GPU)."""
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and os.environ.get("EGX_SINGLE_DEVICE") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} HIP device(s) visible - refusing to report a {args.gpus}-GPU "
+                         f"number from fewer devices (EGX_SINGLE_DEVICE=1 EGX_DIST_BACKEND=gloo runs the ranks on one device, "
+                         f"for testing the multi-rank path only)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    _log("launching " + " ".join(cmd))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_lbs_events=True):
+    """Build env + policy for `A` agents on this rank, run `warmup` untimed and `steps` timed on-policy cycles."""
+    from egogen_amd import _lib, setup_world as sw
+    from egogen_amd.trainer import Collector
+    lib = _lib.load()
+    body, prior, vposer = ops
+    pa = PolicyArgs()
+    pa.update_graph = bool(args.update_graph)
+    env = sw.build_env(A, scene, body, prior, vposer, seed=rank, use_graph=bool(args.graph))
+    policy = sw.build_policy(pa)
+    policy.train()
+    collector = Collector(policy, env)
+    collector.reset()
+    n_vec = args.vec_steps
+    global_bs = batch_local * world
+    n_mb = max(1, (n_vec * A) // batch_local)
+
+    def one_step():
+        batch = collector.collect(n_vec)
+        policy.process_fn(batch)
+        return policy.learn(batch, global_bs, 1)
+
+    for i in range(warmup):
+        one_step()
+        torch.cuda.synchronize()
+        _log(f"[A={A}] warmup step {i} done")
+
+    # HIP events around the fused LBS kernel of every vector step in the timed region (recorded by the library on the
+    # stream the kernel is launched on)
+    evs = []
+    if with_lbs_events:
+        for _ in range(steps * n_vec):
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            _lib.check(lib.egx_event_create(C.byref(e0)), "event")
+            _lib.check(lib.egx_event_create(C.byref(e1)), "event")
+            evs.append((e0, e1))
+        if not args.graph:
+            env.profile_events = list(evs)
+    if world > 1:  # events around every gradient all-reduce of the timed region
+        policy.allreduce_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                   for _ in range(steps * n_mb + 8)]
+        policy._allreduce_done = []
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if args.graph and evs:
+        # a captured step cannot carry per-launch events: time the same kernel on eager passes right after the region
+        env.profile_events = list(evs)
+        z = torch.zeros(A, 128, device="cuda")
+        for _ in range(len(evs)):
+            env.z.copy_(z)
+            env._step_core()
+        torch.cuda.synchronize()
+    ms_list = []
+    for e0, e1 in evs:
+        ms = C.c_float()
+        _lib.check(lib.egx_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
+        ms_list.append(ms.value)
+        lib.egx_event_destroy(e0)
+        lib.egx_event_destroy(e1)
+    ar = None
+    if world > 1:
+        in_loop = [a.elapsed_time(b) for a, b in policy._allreduce_done]
+        policy.allreduce_events, policy._allreduce_done = [], []
+        flat = policy._flat_grad
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        alone_ms = (time.perf_counter() - t1) / 10 * 1e3
+        nbytes = flat.numel() * 4
+        ar = {"bytes": nbytes, "calls_per_step": n_mb, "in_loop_avg_ms": float(np.mean(in_loop)) if in_loop else None,
+              "in_loop_ms_per_step": float(np.sum(in_loop)) / steps if in_loop else None, "standalone_ms": alone_ms,
+              "standalone_algbw_GBps": nbytes / (alone_ms * 1e-3) / 1e9,
+              "standalone_busbw_GBps": nbytes / (alone_ms * 1e-3) / 1e9 * 2 * (world - 1) / world,
+              "note": "in_loop includes the wait for the slowest rank; busbw = algbw * 2(N-1)/N (ring all-reduce)"}
+    graphs_ok = bool(args.update_graph) and not any(v.get("failed") for v in policy._graph_cache.values())
+    return {"elapsed": elapsed, "lbs_ms": ms_list, "env": env, "policy": policy, "allreduce": ar, "graphs_ok": graphs_ok,
+            "transitions": steps * n_vec * A * world}
+
+
+def _lbs_in_scene_ms(env, lib, reps=8):
+    """The fused LBS launch with every body INSIDE the scene (freshly reset agents, their two seed frames tiled to 20):
+    the bracket table cannot decide vertices next to the floor / obstacles, so the queue path of the SDF epilogue is live
+    (the random-init motion prior of the timed loop throws most bodies out of the grid)."""
+    from egogen_amd import _lib
+    if env.sdf is None:
+        return None
+    env.reset()
+    A = env.A
+    xb = env.seed[:, [0, 1] * 10, :].contiguous().reshape(A * 20, 93)
+    out = []
+    for _ in range(reps):
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.egx_event_create(C.byref(e0)), "event")
+        _lib.check(lib.egx_event_create(C.byref(e1)), "event")
+        _lib.check(lib.egx_profile_next_lbs(e0, e1), "egx_profile_next_lbs")
+        env.bm.forward(xb, env.betas, 20, want_verts=False, sdf=env.sdf, R0=env.R0, T0=env.T0, out=env._lbs_out)
+        ms = C.c_float()
+        _lib.check(lib.egx_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
+        out.append(ms.value)
+        lib.egx_event_destroy(e0)
+        lib.egx_event_destroy(e1)
+    inside = float((env._lbs_out["pene_count"].reshape(A, 20).sum(1) == 0).float().mean().item())
+    return {"avg_launch_ms": float(np.mean(out[1:])), "launches": len(out) - 1, "bodies_per_launch": A * 20,
+            "fraction_of_agents_with_zero_penetration": inside}
+
+
 def main():
     import faulthandler
     faulthandler.enable()
-    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
+    faulthandler.dump_traceback_later(600, repeat=True, file=sys.stderr)
     args = get_args()
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the two must agree")
     # test knobs (never set by the driver): run several ranks on ONE device over gloo to exercise the multi-rank code path
     backend = os.environ.get("EGX_DIST_BACKEND", "nccl")
     if os.environ.get("EGX_SINGLE_DEVICE") == "1":
@@ -185,111 +410,59 @@ def main():
 
     from egogen_amd import _lib, setup_world as sw, synth
     from egogen_amd.body_model import BodyModelHandle
-    from egogen_amd.trainer import Collector
     lib = _lib.load()
 
     if args.scaling == "strong":  # fixed total work: 512 agents and one 256-sample minibatch over all ranks
         assert args.agents % world == 0 and args.batch_size % world == 0, "--agents / --batch-size must divide by the rank count"
-        args.agents //= world
-        args.batch_size //= world
-    A = args.agents
-    pa = PolicyArgs()
-    pa.update_graph = bool(args.update_graph)
+        A, bs_local = args.agents // world, args.batch_size // world
+    else:
+        A, bs_local = args.agents, args.batch_size
     bm, _ = sw.load_body_model("male", seed=0, num_verts=args.num_verts)
     body = BodyModelHandle(bm, synth.marker_ids(args.num_verts), synth.feet_vids(args.num_verts))
-    prior = sw.build_motion_prior(seed=0)
-    vposer = sw.build_vposer(seed=0)
+    ops = (body, sw.build_motion_prior(seed=0), sw.build_vposer(seed=0))
     scene = sw.build_scene(args.scene, sdf_res=args.sdf_res, seed=0)
     _log("assets built")
-    env = sw.build_env(A, scene, body, prior, vposer, seed=rank, use_graph=bool(args.graph))
-    _log(f"env built ({'%d valid start pairs' % env.valid_pairs.shape[0] if env.valid_pairs is not None else 'box scenes'})")
-    policy = sw.build_policy(pa)
-    policy.train()
-    collector = Collector(policy, env)
-    collector.reset()
-    n_vec = args.vec_steps
-    global_bs = args.batch_size * world
-
-    def one_step():
-        batch = collector.collect(n_vec)
-        policy.process_fn(batch)
-        return policy.learn(batch, global_bs, 1)
-
-    for i in range(args.warmup):
-        one_step()
-        torch.cuda.synchronize()
-        _log(f"warmup step {i} done")
-
-    # HIP events around the fused LBS kernel of every vector step in the timed region
-    n_ev = args.steps * n_vec
-    evs = []
-    for _ in range(n_ev):
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        _lib.check(lib.egx_event_create(C.byref(e0)), "event")
-        _lib.check(lib.egx_event_create(C.byref(e1)), "event")
-        evs.append((e0, e1))
-    if not args.graph:
-        env.profile_events = list(evs)
-
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if args.graph:
-        # a captured step cannot carry per-launch events: time the same kernel on eager passes right after the region
-        env.profile_events = list(evs)
-        z = torch.zeros(A, 128, device="cuda")
-        for _ in range(n_ev):
-            env.z.copy_(z)
-            env._step_core()
-        torch.cuda.synchronize()
-    ms_list = []
-    for e0, e1 in evs:
-        ms = C.c_float()
-        _lib.check(lib.egx_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
-        ms_list.append(ms.value)
-        lib.egx_event_destroy(e0)
-        lib.egx_event_destroy(e1)
+    m = _measure(args, world, rank, A, bs_local, scene, ops, args.steps, args.warmup)
+    elapsed, ms_list = m["elapsed"], m["lbs_ms"]
     _log(f"timed region done: {elapsed:.3f}s")
     lbs_ms = float(np.mean(ms_list))
-    # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (profiles/r01_lbs_pmc.json);
-    # it applies only to the configuration that pass was taken on
+    blend = int(lib.egx_lbs_get_blend_mode())
+    # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (profiles/*_lbs_pmc*.json); it
+    # applies only to the configuration that pass was taken on
     traffic = None
     try:
-        blend = int(lib.egx_lbs_get_blend_mode())
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lbs_pmc_bf16x3.json" if blend == 1 else "r01_lbs_pmc.json")))
-        c = pmc["config"]
-        if c["agents"] == A and c["num_verts"] == args.num_verts and args.scene == "single_box" and args.sdf_res == 256:
-            traffic = pmc["derived"]["hbm_side_bytes_per_launch"]
+        for name in (f"r02_lbs_pmc_mode{blend}.json", "r01_lbs_pmc_bf16x3.json" if blend == 1 else "r01_lbs_pmc.json"):
+            f = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(f):
+                continue
+            pmc = json.load(open(f))
+            c = pmc["config"]
+            if c["agents"] == A and c["num_verts"] == args.num_verts and args.scene == "single_box" and args.sdf_res == 256:
+                traffic = pmc["derived"]["hbm_side_bytes_per_launch"]
+            break
     except Exception:
         pass
     bodies = A * 20
     achieved = FLOP_PER_BODY * bodies / (lbs_ms * 1e-3) / 1e12
-    blend = int(lib.egx_lbs_get_blend_mode())
-    if blend == 1:
-        # 3-term bf16 split: six bf16 MFMA products per fp32 product -> the matrix-pipe ceiling of the ALGORITHMIC fp32
-        # flops is the dense bf16 peak / 6
-        kernel_name, peak = "egx_lbs_fused3_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0
-        peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product (bf16x3 split, fp32 accumulate)"
-        executed = 6 * 2.0 * 480 * (328 * 32 * 3) * bodies / (lbs_ms * 1e-3) / 1e12 if args.num_verts == 10475 else None
+    if blend in (1, 2):
+        # n-term bf16 split: BLEND_PRODUCTS bf16 MFMA products per fp32 product -> the matrix-pipe ceiling of the
+        # ALGORITHMIC fp32 flops is the dense bf16 peak / that count
+        npr = BLEND_PRODUCTS[blend]
+        kernel_name, peak = "egx_lbs_fused3_kernel", PEAK_BF16_MFMA_TFLOPS / npr
+        peak_note = (f"dense bf16 MFMA peak 2500 TFLOP/s / {npr} partial products per fp32 product "
+                     f"(bf16x{3 if blend == 1 else 2} split, fp32 accumulate)")
+        executed = npr * 2.0 * 480 * (328 * 32 * 3) * bodies / (lbs_ms * 1e-3) / 1e12 if args.num_verts == 10475 else None
     else:
         kernel_name, peak, peak_note, executed = "egx_lbs_fused_kernel", PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA peak", None
+    in_scene = _lbs_in_scene_ms(m["env"], lib)
+    if in_scene is not None:
+        in_scene["achieved"] = FLOP_PER_BODY * bodies / (in_scene["avg_launch_ms"] * 1e-3) / 1e12
+        in_scene["frac"] = in_scene["achieved"] / peak
 
-    transitions = args.steps * n_vec * A * world
+    total_agents = A * world
     result = {
-        "metric": f"PPO env-steps/sec ({A} parallel SMPL-X agents per GPU)",
-        "value": transitions / elapsed,
+        "metric": f"PPO env-steps/sec ({total_agents} parallel SMPL-X agents)",
+        "value": m["transitions"] / elapsed,
         "unit": "env-steps/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -298,24 +471,51 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32" if blend == 0 else "f32 (blend GEMM operands as 3-term bf16 splits, fp32 accumulate)",
+        "dtype": "f32" if blend == 0 else f"f32 (blend GEMM operands as {3 if blend == 1 else 2}-term bf16 splits, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": f"crowd_ppo PPO loop: {A} agents/GPU, scene={args.scene}"
+        "config": {"workload": f"crowd_ppo PPO loop: {total_agents} agents over {world} GPU(s) ({A}/GPU), scene={args.scene}"
                                f"{'' if args.scene == 'box' else f' SDF {args.sdf_res}^3'}, synthetic SMPL-X body V={args.num_verts}, "
-                               f"{n_vec} vector steps/collect ({n_vec * A} transitions/GPU), minibatch {args.batch_size}/GPU, repeat 1",
-                   "agents_per_gpu": A, "scene": args.scene, "vec_steps_per_collect": n_vec, "minibatch_per_gpu": args.batch_size,
+                               f"{args.vec_steps} vector steps/collect ({args.vec_steps * total_agents} transitions), "
+                               f"global minibatch {bs_local * world}, repeat 1",
+                   "agents_total": total_agents, "agents_per_gpu": A, "scene": args.scene, "vec_steps_per_collect": args.vec_steps,
+                   "minibatch_global": bs_local * world, "minibatch_per_gpu": bs_local,
                    "parallelism": f"dp{world}" if world > 1 else "single", "hip_graph_env": bool(args.graph),
-                   "hip_graph_update": bool(args.update_graph) and not any(v.get("failed") for v in policy._graph_cache.values())},
+                   "hip_graph_update": m["graphs_ok"]},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
                      "flop_per_body": FLOP_PER_BODY, "peak_note": peak_note, "executed_bf16_tflops": executed,
-                     "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS},
+                     "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene},
     }
+    if world > 1:
+        result["allreduce"] = m["allreduce"]
+    del m
+    torch.cuda.empty_cache()
+    if world > 1 and args.scaling == "strong" and args.also_weak:
+        mw = _measure(args, world, rank, args.agents, args.batch_size, scene, ops, args.steps, args.warmup, with_lbs_events=False)
+        result["weak"] = {"value": mw["transitions"] / mw["elapsed"], "unit": "env-steps/s", "ms_per_step": mw["elapsed"] / args.steps * 1e3,
+                          "agents_per_gpu": args.agents, "minibatch_per_gpu": args.batch_size, "allreduce": mw["allreduce"]}
+        del mw
+        torch.cuda.empty_cache()
+    if world == 1 and args.extra_configs and args.scene == "single_box" and args.agents == 512:
+        others = []
+        for label, sc_name, a_tot in (("BASELINE configs[2]: 512 agents, random-box scene set (walkability-map penetration term)", "box", 512),
+                                      ("reference default shape: 256 agents, 1024 transitions per collect, single-box SDF scene", "single_box", 256)):
+            try:
+                sc = scene if sc_name == args.scene else sw.build_scene(sc_name, sdf_res=args.sdf_res, seed=0)
+                mo = _measure(args, 1, 0, a_tot, args.batch_size, sc, ops, args.steps, max(1, args.warmup), with_lbs_events=True)
+                others.append({"workload": label, "value": mo["transitions"] / mo["elapsed"], "unit": "env-steps/s",
+                               "ms_per_step": mo["elapsed"] / args.steps * 1e3, "lbs_avg_launch_ms": float(np.mean(mo["lbs_ms"])),
+                               "steps": args.steps})
+                del mo
+                torch.cuda.empty_cache()
+            except Exception as e:
+                others.append({"workload": label, "value": None, "error": f"{type(e).__name__}: {e}"})
+        result["other_configs"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _log("cpu baseline ...")
         try:
-            result["cpu_baseline"] = cpu_baseline(args, scene, args.cpu_agent_steps)
+            result["cpu_baseline"] = cpu_baseline(args, scene)
         except Exception as e:  # the baseline is a report, never a reason to lose the measurement
             result["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
                                       "sample": f"failed: {type(e).__name__}: {e}"}

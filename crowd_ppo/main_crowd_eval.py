@@ -28,11 +28,12 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
     torch.cuda.set_device(local_rank)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
-    sw.create_dirs("MPVAEPolicy_samp_collision")
+    cfg = sw.load_model(box=True)    # main_crowd_eval.py:222-224 -> load_model(box=True) (crowd_ppo/primitive_model.py:74-96)
     bm, _ = sw.load_body_model("male", seed=args.seed, num_verts=args.num_verts)
     body = BodyModelHandle(bm, synth.marker_ids(args.num_verts), synth.feet_vids(args.num_verts))
-    prior, vposer = sw.build_motion_prior(seed=args.seed), sw.build_vposer(seed=args.seed)
-    policy = sw.build_policy(args)
+    prior = sw.build_motion_prior(seed=args.seed, ckpt_dirs=sw.prior_checkpoint_dirs(cfg, "male"))
+    vposer = sw.build_vposer(seed=args.seed)
+    policy = sw.build_policy(args, policy_cfg=sw.policy_cfg_from_yaml(cfg))
     # BASELINE config 5: the policy's dense layers on the bf16 MFMA (operands rounded to bf16, fp32 accumulate) unless
     # --policy-dtype fp32; everything else (motion prior, SMPL-X, collision) stays fp32
     from egogen_amd import _lib
@@ -52,7 +53,7 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
         pts[:, 0], pts[:, 1] = 2 * np.cos(t), 2 * np.sin(t)
         for k in range(G):
             st[k, s, 0], st[k, s, 1] = pts[k], pts[(k + G // 2) % G]
-    grp = CrowdGroupEnv(S, st, body, prior, vposer, seed=args.seed + 100 * local_rank, keep_rollout=True)
+    grp = CrowdGroupEnv(S, st, body, prior, vposer, cfg=sw.env_cfg_from_yaml(cfg), seed=args.seed + 100 * local_rank, keep_rollout=True)
     obs = grp.reset()
     episodes = [[[] for _ in range(S)] for _ in range(G)]
     ep_ret = torch.zeros(G, S, device="cuda")

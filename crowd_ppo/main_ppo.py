@@ -94,7 +94,9 @@ def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True
     _apply_policy_dtype(args)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dirs = sw.create_dirs(cfg_name)
+    # load_model (crowd_ppo/primitive_model.py:74-96): yaml -> results/crowd_ppo/<cfg_name>/<run>/ tree + config.yaml
+    cfg = sw.load_model(box=cfg_name.endswith("_2"))
+    env_cfg = sw.env_cfg_from_yaml(cfg)
     scene_kind = args.scene or scene_kind
 
     # seed (main_ppo.py:100-105)
@@ -103,12 +105,12 @@ def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True
 
     bm, real = sw.load_body_model("male", seed=args.seed, num_verts=args.num_verts)
     body = BodyModelHandle(bm, synth.marker_ids(args.num_verts), synth.feet_vids(args.num_verts))
-    prior = sw.build_motion_prior(seed=args.seed)
+    prior = sw.build_motion_prior(seed=args.seed, ckpt_dirs=sw.prior_checkpoint_dirs(cfg, "male"))
     vposer = sw.build_vposer(seed=args.seed)
     scene = sw.build_scene(scene_kind, sdf_res=args.sdf_res, seed=args.seed)
     save_rollout = args.watch if args.save_rollout is None else bool(args.save_rollout)
 
-    policy = sw.build_policy(args)
+    policy = sw.build_policy(args, policy_cfg=sw.policy_cfg_from_yaml(cfg))
     if args.resume_path:
         ckpt = torch.load(args.resume_path, map_location="cuda")
         policy.load_state_dict(ckpt["model"])
@@ -116,7 +118,7 @@ def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True
 
     n_train = max(1, args.training_num // world)
     test_env = sw.build_env(args.test_num, scene, body, prior, vposer, finetuning=args.finetune, seed=args.seed + 1000 + rank,
-                            keep_rollout=save_rollout)
+                            keep_rollout=save_rollout, cfg=env_cfg)
     test_collector = Collector(policy, test_env, rollout_dir="./log/eval_results/" if save_rollout else None)
 
     now = datetime.datetime.now().strftime("%y%m%d-%H%M%S")
@@ -125,17 +127,17 @@ def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True
     logger = ScalarLogger(log_path) if rank == 0 else None
 
     def save_best_fn(pol):
-        state = {"model": pol.state_dict(), "optim": pol.optim.state_dict()} if ckpt_with_optim else {"model": pol.state_dict()}
+        state = {"model": pol.state_dict(), "optim": pol.optim_state_dict()} if ckpt_with_optim else {"model": pol.state_dict()}
         torch.save(state, os.path.join(log_path, "policy.pth"))
 
     def save_checkpoint_fn(epoch, env_step, gradient_step):
         ckpt_path = os.path.join(log_path, f"checkpoint_{epoch}.pth")
-        state = {"model": policy.state_dict(), "optim": policy.optim.state_dict()} if ckpt_with_optim else {"model": policy.state_dict()}
+        state = {"model": policy.state_dict(), "optim": policy.optim_state_dict()} if ckpt_with_optim else {"model": policy.state_dict()}
         torch.save(state, ckpt_path)
         return ckpt_path
 
     if not args.watch:
-        train_env = sw.build_env(n_train, scene, body, prior, vposer, finetuning=args.finetune, seed=args.seed + rank)
+        train_env = sw.build_env(n_train, scene, body, prior, vposer, finetuning=args.finetune, seed=args.seed + rank, cfg=env_cfg)
         train_collector = Collector(policy, train_env)
         result = onpolicy_trainer(policy, train_collector, test_collector, args.epoch, args.step_per_epoch,
                                   args.repeat_per_collect, args.test_num, args.batch_size,

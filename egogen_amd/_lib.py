@@ -109,6 +109,9 @@ SIGNATURES = {
     "egx_lbs_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(SdfGrid), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egx_lbs_joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egx_canonical_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egx_update_transl_glorot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "egx_sdf_sample": (C.c_int, [C.POINTER(SdfGrid), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "egx_sdf_coarse_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "egx_sdf_build_coarse": (C.c_int, [C.POINTER(SdfGrid), C.c_void_p, C.c_void_p]),
@@ -127,6 +130,9 @@ SIGNATURES = {
                                     C.c_int, C.c_void_p]),
     "egx_env_reset": (C.c_int, [C.POINTER(EnvConfig), C.POINTER(EnvScenes), C.POINTER(EnvState), C.POINTER(EnvResetIO),
                                 C.c_int, C.c_void_p]),
+    "egx_env_get_feature": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p] * 3),
+    "egx_env_get_map": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     "egx_sample_action": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "egx_gae": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p,

@@ -154,6 +154,24 @@ class BodyModelHandle:
         return out
 
 
+    def joints55(self, xb: torch.Tensor, betas: torch.Tensor, frames_per_agent: int) -> torch.Tensor:
+        """The 55 kinematic-tree joints [B,55,3] without the vertex pass (egx_lbs_joints)."""
+        lib = _lib.load()
+        B = int(xb.shape[0])
+        A = int(betas.shape[0])
+        if xb.dim() != 2 or xb.shape[1] != 93 or B == 0:
+            raise ValueError(f"xb must be a non-empty [B,93], got {tuple(xb.shape)}")
+        if betas.dim() != 2 or betas.shape[1] != 10 or A * frames_per_agent != B:
+            raise ValueError(f"betas must be [B/frames_per_agent,10]; got {tuple(betas.shape)} for B={B}, fpa={frames_per_agent}")
+        xb = xb.to(dtype=torch.float32).contiguous()
+        betas = betas.to(dtype=torch.float32).contiguous()
+        out = torch.empty(B, 55, 3, dtype=torch.float32, device=xb.device)
+        ws = self.workspace(B)
+        _lib.check(lib.egx_lbs_joints(self.handle, _lib.ptr(xb), _lib.ptr(betas), B, int(frames_per_agent), _lib.ptr(out),
+                                      _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr()), "egx_lbs_joints")
+        return out
+
+
 class SMPLXOutput:
     """What `bm(return_verts=True, ...)` returns in the reference (fields used on this path)."""
 
@@ -215,3 +233,60 @@ class SMPLXParser:
 
     def get_markers(self, betas, gender, xb, to_numpy=True):
         return self.forward_smplx(betas, gender, xb, to_numpy, "markers")
+
+    def get_new_coordinate(self, betas, gender, xb, to_numpy=True):
+        """baseops.py:465-490: canonical frame of every body of the batch -> (new_rotmat [b,3,3], new_transl [b,1,3]).
+        The reference evaluates the whole body model for joints 0..2; here only the kinematic chain runs
+        (egx_lbs_joints) followed by egx_canonical_frame (CanonicalCoordinateExtractor, baseops.py:214-225)."""
+        lib = _lib.load()
+        betas, xb = self._prep(betas, xb)
+        B = xb.shape[0]
+        j = self._bm(gender).joints55(xb, betas, B // betas.shape[0])
+        R = torch.empty(B, 3, 3, dtype=torch.float32, device=xb.device)
+        T = torch.empty(B, 1, 3, dtype=torch.float32, device=xb.device)
+        _lib.check(lib.egx_canonical_frame(_lib.ptr(j), 55, B, _lib.ptr(R), _lib.ptr(T), _lib.current_stream_ptr()),
+                   "egx_canonical_frame")
+        return (R.cpu().numpy(), T.cpu().numpy()) if to_numpy else (R, T)
+
+    def calc_calibrate_offset(self, bm, betas, body_pose, to_numpy=True):
+        """baseops.py:494-534: delta_T [b,3] = pelvis of the body at zero global_orient / transl.  `bm` is a
+        BodyModelHandle (the reference passes its smplx module)."""
+        if isinstance(body_pose, np.ndarray):
+            body_pose = torch.from_numpy(np.ascontiguousarray(body_pose, dtype=np.float32)).cuda()
+        b = body_pose.shape[0]
+        xb = torch.zeros(b, 93, dtype=torch.float32, device=body_pose.device)
+        xb[:, 6:69] = body_pose.to(torch.float32)
+        betas, xb = self._prep(betas, xb)
+        d = bm.joints55(xb, betas, b // betas.shape[0])[:, 0].contiguous()
+        return d.cpu().numpy() if to_numpy else d
+
+    def update_transl_glorot(self, transf_rotmat, transf_transl, betas, gender, xb, to_numpy=True, inplace=True):
+        """baseops.py:537-598: body parameters xb [b,93] re-expressed in the frame (transf_rotmat [b,3,3], transf_transl
+        [b,1,3]).  Both of the reference's branches (scipy Rotation for numpy input, torchgeometry for tensors) compute
+        glorot' = log(R^T exp(glorot)); here both go through egx_update_transl_glorot (the torchgeometry formulas)."""
+        lib = _lib.load()
+        src = xb
+        betas_t, xbt = self._prep(betas, xb)
+        xbt = xbt.contiguous()
+        b = xbt.shape[0]
+        dev = xbt.device
+        as_t = lambda a: (torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)) if isinstance(a, np.ndarray) else a).to(dev, torch.float32)
+        R = as_t(transf_rotmat).reshape(-1, 3, 3).contiguous()
+        T = as_t(transf_transl).reshape(-1, 3).contiguous()
+        if R.shape[0] not in (1, b) or T.shape[0] != R.shape[0]:
+            raise ValueError(f"transf_rotmat / transf_transl must hold 1 or {b} frames, got {R.shape[0]} / {T.shape[0]}")
+        delta = self.calc_calibrate_offset(self._bm(gender), betas_t, xbt[:, 6:69], to_numpy=False)
+        same = torch.is_tensor(src) and src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()
+        out = xbt if (inplace and same) else torch.empty_like(xbt)
+        _lib.check(lib.egx_update_transl_glorot(_lib.ptr(R), _lib.ptr(T), int(R.shape[0]), _lib.ptr(delta), _lib.ptr(xbt), b,
+                                                _lib.ptr(out), _lib.current_stream_ptr()), "egx_update_transl_glorot")
+        if to_numpy:
+            res = out.cpu().numpy()
+            if inplace and isinstance(src, np.ndarray):   # xb[:, :3] = transl; xb[:, 3:6] = glorot (baseops.py:583-585)
+                src[:, :6] = res[:, :6]
+                return src
+            return res
+        if inplace and torch.is_tensor(src) and not same:
+            src[:, :6] = out[:, :6].to(src.device, src.dtype)
+            return src
+        return out

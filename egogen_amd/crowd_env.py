@@ -57,7 +57,7 @@ class VecCrowdEnv:
         self.dev = torch.device(device)
         self.bm, self.prior, self.vposer = body_model, prior, vposer
         self.scene_kind = scene_kind
-        self.cfg = dict(cfg or (BOX_CFG if scene_kind == "box" else DEFAULT_CFG))
+        self.cfg = dict(cfg or (BOX_CFG if scene_kind in ("box", "crowd") else DEFAULT_CFG))  # main_crowd_eval.py:224 load_model(box=True)
         self.crowd_bbox, self.crowd_member = crowd_bbox, int(crowd_member)
         self.finetuning = finetuning
         self.use_graph = use_graph
@@ -351,9 +351,13 @@ class VecCrowdEnv:
         _lib.check(lib.egx_env_step_post(C.byref(self._ec), C.byref(self._sc), C.byref(self._st), C.byref(self._io), A, st),
                    "egx_env_step_post")
 
-    def check_finite(self):
+    def check_finite(self, all_ranks: bool = False):
         """Raise if any step since the last call produced a non-finite reward / target distance (one host sync; the
-        reference stops in pdb at the NaN/Inf checks of crowd_env_2f.py:287-297)."""
+        reference stops in pdb at the NaN/Inf checks of crowd_env_2f.py:287-297).  `all_ranks`: MAX-reduce the counter over
+        the data-parallel ranks first, so that all of them raise together."""
+        if all_ranks:
+            import torch.distributed as dist
+            dist.all_reduce(self.nonfinite, op=dist.ReduceOp.MAX)
         n = int(self.nonfinite.item())
         if n:
             self.nonfinite.zero_()

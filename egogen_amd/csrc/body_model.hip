@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
                                                              float* __restrict__ feat,   // packed B operand (fp32 blend) or null
                                                              unsigned short* __restrict__ feat3,  // bf16x3 planes or null
                                                              f32x4* __restrict__ A4,     // [bt][55][3][32]
-                                                             float* __restrict__ out_joints) {
+                                                             float* __restrict__ out_joints, int joints_ld) {
   __shared__ float sR[4][NJ][9];
   __shared__ float sJ[4][NJ][3];
   __shared__ float sG[4][NJ][12];
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       A4[(((size_t)bt * NJ + j) * 3 + r) * 32 + n] = row;
     }
     if (out_joints) {
-      float* o = out_joints + ((size_t)b * EGX_NUM_JOINTS_OUT + j) * 3;
+      float* o = out_joints + ((size_t)b * joints_ld + j) * 3;
       o[0] = G[3] + x[0]; o[1] = G[7] + x[1]; o[2] = G[11] + x[2];
     }
   }
@@ -875,8 +875,11 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
         if (d->lbs_weights_host[(size_t)v * NJ + j] != 0.f) key[v].push_back(j);
     std::vector<int> order(V);
     for (int v = 0; v < V; ++v) order[v] = v;
-    const char* e = getenv("EGX_LBS_VERTEX_ORDER");
-    if (!(e && std::string(e) == "natural"))
+    bool natural = false;
+#ifdef EGX_LBS_DEVELOPMENT
+    if (const char* e = getenv("EGX_LBS_VERTEX_ORDER")) natural = std::string(e) == "natural";
+#endif
+    if (!natural)
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
     for (int v = 0; v < V; ++v) perm[v] = order[v];
   }
@@ -1100,6 +1103,23 @@ extern "C" size_t egx_lbs_workspace_bytes(const egx_body_model* m, int num_bodie
   return ws_layout(m, num_bodies).total;
 }
 
+extern "C" int egx_lbs_joints(const egx_body_model* m, const float* xb, const float* betas, int B, int fpa, float* out_joints55,
+                              void* workspace, size_t workspace_bytes, void* stream_) {
+  EGX_REQUIRE(m && xb && betas && out_joints55, "null model/xb/betas/out");
+  EGX_REQUIRE(B > 0 && fpa > 0, "num_bodies and frames_per_agent must be positive");
+  const WsLayout wl = ws_layout(m, B);
+  if (!workspace || workspace_bytes < wl.total) {
+    egx_set_error("workspace too small: need " + std::to_string(wl.total) + " bytes");
+    return EGX_ERR_WORKSPACE;
+  }
+  char* ws = static_cast<char*>(workspace);
+  hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream_), m->pc, xb,
+                     betas, B, fpa, static_cast<float*>(nullptr), static_cast<unsigned short*>(nullptr),
+                     reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
 extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const float* betas, int B, int fpa,
                                float* out_verts, float* out_joints, float* out_markers, const egx_sdf_grid* sdf,
                                const float* R0, const float* T0, int32_t* out_pene_count, void* workspace,
@@ -1123,7 +1143,8 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
 
   const bool split3 = blend_mode() == 1 && !out_verts;
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, stream, m->pc, xb, betas, B, fpa,
-                     split3 ? nullptr : feat, split3 ? reinterpret_cast<unsigned short*>(feat) : nullptr, A4, out_joints);
+                     split3 ? nullptr : feat, split3 ? reinterpret_cast<unsigned short*>(feat) : nullptr, A4, out_joints,
+                     EGX_NUM_JOINTS_OUT);
   if (out_verts || need_picks || sdf) {
     LbsParams p;
     p.dirs = m->dirs; p.tj_off = m->tj_off; p.tj_idx = m->tj_idx; p.tj_w = m->tj_w; p.pick_slot = m->pick_slot;
@@ -1132,10 +1153,14 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     p.vflags = m->vflags; p.feat = reinterpret_cast<const f32x4*>(feat); p.A4 = A4; p.xb = xb;
     p.B = B; p.V = m->V; p.NVT = m->NVT; p.NW = m->NW; p.NP = m->NP; p.fpa = fpa;
     p.nbg = egx_ceil_div(B, BODY_PAD);
+#ifdef EGX_LBS_DEVELOPMENT   // ablation switches of development builds only (make CXXFLAGS+=-DEGX_LBS_DEVELOPMENT)
     {
       const char* e = getenv("EGX_LBS_DBG");
       p.dbg = e ? atoi(e) : 0;
     }
+#else
+    p.dbg = 0;
+#endif
     p.verts = out_verts; p.picked = picked; p.R0 = R0; p.T0 = T0; p.pene = out_pene_count;
     std::memset(&p.sdf, 0, sizeof(p.sdf));
     if (sdf) {
@@ -1164,10 +1189,10 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_meta));
       num_cu = prop.multiProcessorCount;
     }
-    {
-      const char* e = getenv("EGX_LBS_BG_BLOCK");
-      p.bg_block = e ? atoi(e) : 2;
-    }
+    p.bg_block = 2;
+#ifdef EGX_LBS_DEVELOPMENT
+    if (const char* e = getenv("EGX_LBS_BG_BLOCK")) p.bg_block = atoi(e);
+#endif
     const int n_items = p.nbg * m->NVT;
     const int grid = std::max(1, std::min(num_cu, (n_items + 1) / 2));
     const size_t lds = out_verts ? lds_verts : (sdf ? lds_sdf : lds_meta);

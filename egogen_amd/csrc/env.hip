@@ -162,39 +162,66 @@ __device__ void egosensing_frame(const SceneDev& sc, int scene, const float* j23
   }
 }
 
-// get_map for one agent: walkability of the res x res local grid (1 / -1) and the bbox penetration count
+// same-side test of a scene-frame point against navmesh triangles [f0, f1) (batch_gen_amass.py:949-961)
+__device__ __forceinline__ bool point_in_navmesh(const float* tris, int f0, int f1, float px, float py) {
+  bool walk = false;
+  for (int f = f0; f < f1 && !walk; ++f) {
+    const float* t = tris + (size_t)f * 6;
+    const float d1 = (px - t[2]) * (t[1] - t[3]) - (t[0] - t[2]) * (py - t[3]);
+    const float d2 = (px - t[4]) * (t[3] - t[5]) - (t[2] - t[4]) * (py - t[5]);
+    const float d3 = (px - t[0]) * (t[5] - t[1]) - (t[4] - t[0]) * (py - t[1]);
+    const bool neg = (d1 < 0.f) || (d2 < 0.f) || (d3 < 0.f);
+    const bool pos = (d1 > 0.f) || (d2 > 0.f) || (d3 > 0.f);
+    walk = !(neg && pos);
+  }
+  return walk;
+}
+
+// get_map (batch_gen_amass.py:934-968) for one point of the local grid: local (lx, ly, 0) -> scene frame, then the same-side
+// test against every navmesh triangle (crowd scenes: floor square minus the other members' boxes)
+__device__ __forceinline__ bool walk_cell(const SceneDev& sc, int scene, const float* R0, const float* T0, float lx, float ly,
+                                          float* world_xy /*[2] or null*/) {
+  // einsum('bij,bpj->bpi') with the z component of the local point = 0
+  const float px = (R0[0] * lx + R0[1] * ly + R0[2] * 0.f) + T0[0];
+  const float py = (R0[3] * lx + R0[4] * ly + R0[5] * 0.f) + T0[1];
+  if (world_xy) { world_xy[0] = px; world_xy[1] = py; }
+  bool walk = false;
+  if (sc.crowd_bbox) {  // crowd_env_crowd_eval.py:742-764: polygon(floor, holes).contains(point), z forced to 0
+    walk = (fabsf(px) < sc.crowd_half) && (fabsf(py) < sc.crowd_half);
+    for (int o = 0; o < sc.crowd_G && walk; ++o) {
+      if (o == sc.crowd_k) continue;
+      const float* b = sc.crowd_bbox + ((size_t)o * sc.crowd_S + scene) * 4;
+      if (px >= b[0] && px <= b[2] && py >= b[1] && py <= b[3]) walk = false;
+    }
+    return walk;
+  }
+  return point_in_navmesh(sc.tris, sc.tri_off[scene], sc.tri_off[scene + 1], px, py);
+}
+
+// walkability of the res x res local grid (1 / -1) of one agent reduced to the bbox penetration count
 __device__ float walk_map_penalty(const SceneDev& sc, int scene, const float* R0, const float* T0, float bminx, float bminy,
                                   float bmaxx, float bmaxy, float* sh) {
   const int res = sc.map_res;
-  const int f0 = sc.crowd_bbox ? 0 : sc.tri_off[scene], f1 = sc.crowd_bbox ? 0 : sc.tri_off[scene + 1];
   float cnt = 0.f;
   for (int p = threadIdx.x; p < res * res; p += BLK) {
     const float lx = sc.map_lin[p / res], ly = sc.map_lin[p % res];
-    // einsum('bij,bpj->bpi') with the z component of the local point = 0
-    const float px = (R0[0] * lx + R0[1] * ly + R0[2] * 0.f) + T0[0];
-    const float py = (R0[3] * lx + R0[4] * ly + R0[5] * 0.f) + T0[1];
-    bool walk = false;
-    if (sc.crowd_bbox) {  // crowd_env_crowd_eval.py:742-764: polygon(floor, holes).contains(point), z forced to 0
-      walk = (fabsf(px) < sc.crowd_half) && (fabsf(py) < sc.crowd_half);
-      for (int o = 0; o < sc.crowd_G && walk; ++o) {
-        if (o == sc.crowd_k) continue;
-        const float* b = sc.crowd_bbox + ((size_t)o * sc.crowd_S + scene) * 4;
-        if (px >= b[0] && px <= b[2] && py >= b[1] && py <= b[3]) walk = false;
-      }
-    }
-    for (int f = f0; f < f1 && !walk; ++f) {
-      const float* t = sc.tris + (size_t)f * 6;
-      const float d1 = (px - t[2]) * (t[1] - t[3]) - (t[0] - t[2]) * (py - t[3]);
-      const float d2 = (px - t[4]) * (t[3] - t[5]) - (t[2] - t[4]) * (py - t[5]);
-      const float d3 = (px - t[0]) * (t[5] - t[1]) - (t[4] - t[0]) * (py - t[1]);
-      const bool neg = (d1 < 0.f) || (d2 < 0.f) || (d3 < 0.f);
-      const bool pos = (d1 > 0.f) || (d2 > 0.f) || (d3 > 0.f);
-      walk = !(neg && pos);
-    }
+    const bool walk = walk_cell(sc, scene, R0, T0, lx, ly, nullptr);
     const bool inbox = (lx >= bminx) && (ly >= bminy) && (lx <= bmaxx) && (ly <= bmaxy);
     if (inbox && !walk) cnt += 1.f;  // inside * (1 - (-1)) * 0.5
   }
   return block_reduce(cnt, sh, 0);
+}
+
+// _get_feature (crowd_env_2f.py:680-727), the part the observation keeps: unit vector from a canonical marker to the target
+__device__ __forceinline__ void marker_target_feature(const float* target_l, const float* marker, float* out3) {
+  const float fx = target_l[0] - marker[0], fy = target_l[1] - marker[1], fz = target_l[2] - marker[2];
+  const float dn = fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);
+  out3[0] = fx / dn; out3[1] = fy / dn; out3[2] = fz / dn;
+}
+// ... and the clipped 3-D distance pelvis -> target
+__device__ __forceinline__ float target_distance(const float* target_l, const float* pelvis) {
+  const float fx = target_l[0] - pelvis[0], fy = target_l[1] - pelvis[1], fz = target_l[2] - pelvis[2];
+  return fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);
 }
 
 struct EnvCfg {
@@ -369,8 +396,7 @@ __global__ __launch_bounds__(BLK) void egx_env_step_post_kernel(StepArgs p) {
     e0 /= nrm; e1 /= nrm;
     const float r_look = ((f0 * (-e1) + f1 * e0) + 1.f) / 2.0f;
     // target distance
-    const float dx = tl[0] - j19[0], dy = tl[1] - j19[1], dz = tl[2] - j19[2];
-    const float d2t = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    const float d2t = target_distance(tl, j19);
     const float r_td = p.dist[a] - d2t;
     const float r_goal = (d2t < c.goal_thresh) ? 1.f : 0.f;
     // new frame from frame 18 joints
@@ -409,9 +435,7 @@ __global__ __launch_bounds__(BLK) void egx_env_step_post_kernel(StepArgs p) {
     mat3T_vec(Rn, v, ms);
     float* st = p.state + ((size_t)a * 2 + t) * SD;
     st[m * 3 + 0] = ms[0]; st[m * 3 + 1] = ms[1]; st[m * 3 + 2] = ms[2];
-    const float fx = tln[0] - ms[0], fy = tln[1] - ms[1], fz = tln[2] - ms[2];
-    const float dn = fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);
-    st[201 + m * 3 + 0] = fx / dn; st[201 + m * 3 + 1] = fy / dn; st[201 + m * 3 + 2] = fz / dn;
+    marker_target_feature(tln, ms, st + 201 + m * 3);
     bool use = c.pene_body != 0;
     if (!use)
       for (int k = 0; k < 6; ++k) use |= (p.feet_marker_idx[k] == m);
@@ -668,9 +692,7 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
       to_canonical(t, TM + (size_t)i * 3, ms);
       float* st = p.state + ((size_t)a * 2 + t) * SD;
       st[m * 3 + 0] = ms[0]; st[m * 3 + 1] = ms[1]; st[m * 3 + 2] = ms[2];
-      const float fx = tl[0] - ms[0], fy = tl[1] - ms[1], fz = tl[2] - ms[2];
-      const float dn = fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);
-      st[201 + m * 3 + 0] = fx / dn; st[201 + m * 3 + 1] = fy / dn; st[201 + m * 3 + 2] = fz / dn;
+      marker_target_feature(tl, ms, st + 201 + m * 3);
     }
     // seed params in the canonical frame: transl' = R0^T (t + J0 - T0) - J0 ; glorot' = aa(R0^T Rg)
     if (tid < 2) {
@@ -720,8 +742,7 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
     if (tid == 0) {
       float pel[3];
       to_canonical(0, TJ, pel);
-      const float dx = tl[0] - pel[0], dy = tl[1] - pel[1], dz = tl[2] - pel[2];
-      const float d = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+      const float d = target_distance(tl, pel);
       p.dist[a] = d;
       p.obs_dist[a] = 1.f / (d + 1.f);
       p.obs_time[a] = 1.f;
@@ -808,6 +829,116 @@ extern "C" int egx_env_reset(const egx_env_config* cfg, const egx_env_scenes* sc
   p.wpath = st->wpath; p.scene_idx = st->scene_idx;
   p.obs_ego = io->obs_ego; p.obs_dist = io->obs_dist; p.obs_time = io->obs_time; p.out_choice = io->out_choice;
   hipLaunchKernelGGL(egx_env_reset_kernel, dim3(A), dim3(BLK), 0, static_cast<hipStream_t>(stream_), p);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SMPLXParser.get_new_coordinate / update_transl_glorot as stand-alone operators (models/baseops.py:465-490, 537-598):
+// the step / reset kernels above use the same device functions inline.
+// ------------------------------------------------------------------------------------------------
+__global__ void egx_canonical_frame_kernel(const float* __restrict__ joints, int jpb, int B, float* __restrict__ R, float* __restrict__ T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* j = joints + (size_t)b * jpb * 3;
+  float r[9], t[3];
+  canonical_frame(j, j + 3, j + 6, r, t);
+  for (int e = 0; e < 9; ++e) R[(size_t)b * 9 + e] = r[e];
+  for (int e = 0; e < 3; ++e) T[(size_t)b * 3 + e] = t[e];
+}
+
+__global__ void egx_update_transl_glorot_kernel(const float* __restrict__ R, const float* __restrict__ T, int rt_rows,
+                                                const float* __restrict__ delta, const float* __restrict__ xb, int B,
+                                                float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int rb = rt_rows == 1 ? 0 : b;  // one frame for all bodies, or one per body
+  float x6[6], o6[6], r[9], t[3], d[3];
+  for (int e = 0; e < 6; ++e) x6[e] = xb[(size_t)b * XB + e];
+  for (int e = 0; e < 9; ++e) r[e] = R[(size_t)rb * 9 + e];
+  for (int e = 0; e < 3; ++e) { t[e] = T[(size_t)rb * 3 + e]; d[e] = delta[(size_t)b * 3 + e]; }
+  update_transl_glorot(r, t, d, x6, o6);
+  if (out != xb)
+    for (int e = 6; e < XB; ++e) out[(size_t)b * XB + e] = xb[(size_t)b * XB + e];
+  for (int e = 0; e < 6; ++e) out[(size_t)b * XB + e] = o6[e];
+}
+
+extern "C" int egx_canonical_frame(const float* joints, int joints_per_body, int num_bodies, float* out_R, float* out_T, void* stream) {
+  EGX_REQUIRE(joints && out_R && out_T, "null argument");
+  EGX_REQUIRE(joints_per_body >= 3 && num_bodies > 0, "need >= 3 joints per body and a non-empty batch");
+  hipLaunchKernelGGL(egx_canonical_frame_kernel, dim3(egx_ceil_div(num_bodies, 128)), dim3(128), 0, static_cast<hipStream_t>(stream),
+                     joints, joints_per_body, num_bodies, out_R, out_T);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_update_transl_glorot(const float* R, const float* T, int num_frames, const float* delta_T, const float* xb,
+                                        int num_bodies, float* out, void* stream) {
+  EGX_REQUIRE(R && T && delta_T && xb && out, "null argument");
+  EGX_REQUIRE(num_bodies > 0 && (num_frames == 1 || num_frames == num_bodies), "num_frames must be 1 or num_bodies");
+  hipLaunchKernelGGL(egx_update_transl_glorot_kernel, dim3(egx_ceil_div(num_bodies, 128)), dim3(128), 0,
+                     static_cast<hipStream_t>(stream), R, T, num_frames, delta_T, xb, num_bodies, out);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CrowdEnv._get_feature and get_map as stand-alone operators (crowd_env_2f.py:680-727, crowd_env_2f_box.py:733-776,
+// batch_gen_amass.py:934-968), built from the device functions the step / reset kernels use.
+// ------------------------------------------------------------------------------------------------
+__global__ void egx_env_get_feature_kernel(const float* __restrict__ Y_l, const float* __restrict__ pel, const float* __restrict__ R0,
+                                           const float* __restrict__ T0, const float* __restrict__ wpath, int wpath_rows, int nb,
+                                           int nt, int nm, float* __restrict__ dist_xyz, float* __restrict__ fea_marker) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (body, frame, marker); marker index nm = the pelvis
+  if (i >= nb * nt * (nm + 1)) return;
+  const int m = i % (nm + 1), bt = i / (nm + 1), b = bt / nt;
+  const float* w = wpath + (size_t)(wpath_rows == 1 ? 0 : b) * 3;
+  const float v[3] = {w[0] - T0[(size_t)b * 3 + 0], w[1] - T0[(size_t)b * 3 + 1], w[2] - T0[(size_t)b * 3 + 2]};
+  float tl[3];
+  mat3T_vec(R0 + (size_t)b * 9, v, tl);
+  if (m == nm) {
+    if (dist_xyz) dist_xyz[bt] = target_distance(tl, pel + (size_t)bt * 3);
+  } else if (fea_marker) {
+    marker_target_feature(tl, Y_l + ((size_t)bt * nm + m) * 3, fea_marker + ((size_t)bt * nm + m) * 3);
+  }
+}
+
+__global__ void egx_env_get_map_kernel(const float* __restrict__ tris, int num_tris, const float* __restrict__ map_lin, int res,
+                                       float floor_h, const float* __restrict__ R, const float* __restrict__ T, int nb,
+                                       float* __restrict__ points_scene, float* __restrict__ local_map) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb * res * res) return;
+  const int b = i / (res * res), p = i % (res * res);
+  SceneDev sc;
+  sc.tris = tris; sc.map_lin = map_lin; sc.map_res = res; sc.crowd_bbox = nullptr;
+  const int off[2] = {0, num_tris};
+  sc.tri_off = off;
+  float wxy[2];
+  const bool walk = walk_cell(sc, 0, R + (size_t)b * 9, T + (size_t)b * 3, map_lin[p / res], map_lin[p % res], wxy);
+  if (points_scene) { points_scene[(size_t)i * 3 + 0] = wxy[0]; points_scene[(size_t)i * 3 + 1] = wxy[1]; points_scene[(size_t)i * 3 + 2] = floor_h; }
+  local_map[i] = walk ? 1.f : -1.f;
+}
+
+extern "C" int egx_env_get_feature(const float* Y_l, const float* pel, const float* R0, const float* T0, const float* wpath,
+                                   int wpath_rows, int num_bodies, int num_frames, int num_markers, float* out_dist_xyz,
+                                   float* out_fea_marker, void* stream) {
+  EGX_REQUIRE(Y_l && pel && R0 && T0 && wpath, "null argument");
+  EGX_REQUIRE(num_bodies > 0 && num_frames > 0 && num_markers > 0, "empty batch");
+  EGX_REQUIRE(wpath_rows == 1 || wpath_rows == num_bodies, "wpath must hold 1 or num_bodies targets");
+  const int n = num_bodies * num_frames * (num_markers + 1);
+  hipLaunchKernelGGL(egx_env_get_feature_kernel, dim3(egx_ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), Y_l, pel,
+                     R0, T0, wpath, wpath_rows, num_bodies, num_frames, num_markers, out_dist_xyz, out_fea_marker);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_env_get_map(const float* tris, int num_tris, float floor_height, const float* map_lin, int res, const float* R,
+                               const float* T, int num_bodies, float* out_points_scene, float* out_local_map, void* stream) {
+  EGX_REQUIRE(tris && map_lin && R && T && out_local_map, "null argument");
+  EGX_REQUIRE(num_tris > 0 && res > 0 && num_bodies > 0, "empty input");
+  const int n = num_bodies * res * res;
+  hipLaunchKernelGGL(egx_env_get_map_kernel, dim3(egx_ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), tris,
+                     num_tris, map_lin, res, floor_height, R, T, num_bodies, out_points_scene, out_local_map);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

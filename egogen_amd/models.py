@@ -40,11 +40,14 @@ class _Workspace:
 
     def __init__(self):
         self.bufs: Dict[int, torch.Tensor] = {}
+        self._retired = []  # outgrown buffers stay alive: a captured HIP graph may still hold their addresses
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         key = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes or buf.device != torch.device(device):
+            if buf is not None:
+                self._retired.append(buf)
             buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
             self.bufs[key] = buf
         return buf

@@ -95,6 +95,8 @@ class GAMMAPPOPolicy(nn.Module):
         self.use_flat_optimizer = bool(_ignored.get("use_flat_optimizer", os.environ.get("EGX_FLAT_OPTIMIZER", "1") != "0"))
         self._flat_opt_state = None
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.allreduce_events: list = []   # [(start, stop)] torch.cuda.Event pairs, one consumed per gradient all-reduce
+        self._allreduce_done: list = []
 
     # ---- rollout side (HIP) -------------------------------------------------------------------------
     @torch.no_grad()
@@ -108,7 +110,9 @@ class GAMMAPPOPolicy(nn.Module):
         if not deterministic and noise is None:
             if self._noise_gen is None:
                 self._noise_gen = torch.Generator(device=dev)
-                self._noise_gen.manual_seed(self._seed + 1)
+                # exploration noise differs between data-parallel ranks (parameters and the minibatch permutation do not)
+                rank = dist.get_rank() if self.world_size > 1 else 0
+                self._noise_gen.manual_seed(self._seed + 1 + 9973 * rank)
             noise = torch.randn(n, 128, generator=self._noise_gen, device=dev)
         if "act" not in out:
             out["act"] = torch.empty(n, 128, dtype=torch.float32, device=dev)
@@ -231,6 +235,12 @@ class GAMMAPPOPolicy(nn.Module):
         loss, terms = self.minibatch_loss(obs, act, adv, ret, lpo, gstats)
         self._flat_grad.zero_()
         loss.backward()
+        if adv.is_cuda and self.use_fused_loss and self.use_fused_linear:
+            # the ego encoder / critic branches of the fused forward ran on the side stream and autograd replays their
+            # backward nodes there; what follows (all-reduce, clip, AdamW) reads the flat gradient on THIS stream
+            from . import models as _m
+            if _m._TWO_STREAM_UPDATE:
+                torch.cuda.current_stream().wait_stream(_m._side_stream(adv.device))
         packed = terms.get("_packed")
         if packed is not None:  # the fused loss already holds the six terms in one tensor
             log_out.copy_(packed)
@@ -302,11 +312,58 @@ class GAMMAPPOPolicy(nn.Module):
             self._graph_cache.clear()
         return True
 
-    def _adv_moments(self, batch, idx, out):
-        adv = batch.adv.reshape(-1).index_select(0, idx).double()
-        out[0] = adv.sum()
-        out[1] = (adv * adv).sum()
-        out[2] = float(adv.numel())
+    def optim_state_dict(self) -> dict:
+        """`optim.state_dict()` in the stock torch.optim.AdamW layout the reference writes (main_ppo.py:207-216): with the
+        flat optimiser every parameter's `step` is one shared device scalar and exp_avg / exp_avg_sq are views of flat
+        buffers; a checkpoint must hold one CPU fp32 step tensor per parameter and independent moment tensors, or a stock
+        AdamW that loads it would advance the shared step once per parameter."""
+        sd = self.optim.state_dict()
+        out_state = {}
+        for k, st in sd["state"].items():
+            ns = {}
+            for name, v in st.items():
+                if name == "step":
+                    ns[name] = torch.tensor(float(v), dtype=torch.float32)
+                elif torch.is_tensor(v):
+                    ns[name] = v.detach().clone()
+                else:
+                    ns[name] = v
+            out_state[k] = ns
+        return {"state": out_state, "param_groups": sd["param_groups"]}
+
+    def _global_adv_stats(self, batch: RolloutBatch, perm: torch.Tensor, spans) -> torch.Tensor:
+        """[n_minibatches, 3] float32 = (mean, unbiased std, n) of every GLOBAL minibatch of one pass over the data
+        (ppo_policy.py:192-195 evaluated on the concatenation of all ranks' rows): the float64 moments of all local
+        minibatches go through ONE all-reduce per pass, nothing synchronises with the host."""
+        adv = batch.adv.reshape(-1).double()
+        sizes = {e - s for s, e in spans}
+        if len(sizes) == 1:
+            a = adv.index_select(0, perm[spans[0][0]:spans[-1][1]]).reshape(len(spans), -1)
+            mom = torch.stack([a.sum(1), (a * a).sum(1), torch.full_like(a[:, 0], float(a.shape[1]))], dim=1)
+        else:  # merge_last made the final minibatch longer
+            rows = []
+            for s, e in spans:
+                a = adv.index_select(0, perm[s:e])
+                rows.append(torch.stack([a.sum(), (a * a).sum(), torch.full_like(a[0], float(e - s))]))
+            mom = torch.stack(rows)
+        mom = mom.contiguous()
+        dist.all_reduce(mom)
+        ng = mom[:, 2]
+        mean = mom[:, 0] / ng
+        var = (mom[:, 1] - ng * mean * mean) / (ng - 1)            # unbiased, like Tensor.std()
+        return torch.stack([mean, var.clamp(min=0).sqrt(), ng], dim=1).float()
+
+    def _all_reduce_grad(self):
+        """Sum of the flat gradient over the ranks, in place (RCCL over xGMI; every rank already scaled its loss by
+        1 / n_global, so the sum IS the gradient of the global minibatch mean).  Timed by bench.py through
+        `allreduce_events`."""
+        ev = self.allreduce_events.pop() if self.allreduce_events else None
+        if ev is not None:
+            ev[0].record()
+        dist.all_reduce(self._flat_grad)
+        if ev is not None:
+            ev[1].record()
+            self._allreduce_done.append(ev)
 
     def _graphs_for(self, batch: RolloutBatch, local_bs: int):
         """Capture (gather + forward + loss + backward) and (clip + AdamW) for a fixed minibatch size.  With one rank
@@ -317,7 +374,7 @@ class GAMMAPPOPolicy(nn.Module):
             return g
         dev = batch.act.device
         st = {"idx": torch.zeros(local_bs, dtype=torch.long, device=dev), "log": torch.zeros(6, device=dev),
-              "gstats": torch.zeros(3, device=dev), "use_gstats": self.world_size > 1}
+              "gstats": torch.tensor([0.0, 1.0, float(local_bs * self.world_size)], device=dev), "use_gstats": self.world_size > 1}
         gs = (lambda: (st["gstats"][0], st["gstats"][1], st["gstats"][2])) if st["use_gstats"] else (lambda: None)
         try:
             # warm-up on a side stream (lazy library init, allocator pools) - it performs real optimiser steps on a
@@ -416,39 +473,28 @@ class GAMMAPPOPolicy(nn.Module):
             if len(bounds) > 1 and N - bounds[-1] < local_bs:
                 bounds.pop()
             last_log = None
-            for i, s in enumerate(bounds):
-                e = bounds[i + 1] if i + 1 < len(bounds) else N
+            spans = [(s, bounds[i + 1] if i + 1 < len(bounds) else N) for i, s in enumerate(bounds)]
+            gstats_all = self._global_adv_stats(batch, perm, spans) if ws > 1 else None
+            for i, (s, e) in enumerate(spans):
                 idx = perm[s:e]
                 st = self._graphs_for(batch, local_bs) if (use_graph and e - s == local_bs) else None
                 if st is not None and st.get("g1") is not None:
                     st["idx"].copy_(idx)
                     if ws > 1:
-                        mom = torch.zeros(3, dtype=torch.float64, device=dev)
-                        self._adv_moments(batch, st["idx"], mom)
-                        dist.all_reduce(mom)
-                        ng = mom[2]
-                        mean = mom[0] / ng
-                        var = (mom[1] - ng * mean * mean) / (ng - 1)
-                        st["gstats"].copy_(torch.stack([mean, var.clamp(min=0).sqrt(), ng]).float())
+                        st["gstats"].copy_(gstats_all[i])
                     st["g1"].replay()
                     if ws > 1:
-                        dist.all_reduce(self._flat_grad)
+                        self._all_reduce_grad()
                         st["g2"].replay()
                     last_log = st["log"].clone()
                 else:
                     gstats = None
                     if ws > 1:
-                        mom = torch.zeros(3, dtype=torch.float64, device=dev)
-                        self._adv_moments(batch, idx, mom)
-                        dist.all_reduce(mom)
-                        ng = mom[2]
-                        mean = mom[0] / ng
-                        var = (mom[1] - ng * mean * mean) / (ng - 1)       # unbiased, like Tensor.std()
-                        gstats = (mean.float(), var.clamp(min=0).sqrt().float(), ng.float())
+                        gstats = (gstats_all[i, 0], gstats_all[i, 1], gstats_all[i, 2])
                     log = torch.zeros(6, device=dev)
                     self._fwd_bwd(batch, idx, gstats, log)
                     if ws > 1:
-                        dist.all_reduce(self._flat_grad)
+                        self._all_reduce_grad()
                     self._clip_and_step()
                     last_log = log
                 logs.append(last_log[:5])

@@ -34,6 +34,75 @@ def create_dirs(cfg_name: str, run_name: str = "collision_test") -> Dict[str, st
     return d
 
 
+_PKG_CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cfg_samp20")
+CFG_DIR = os.path.join("crowd_ppo", "cfg_samp20")   # the reference's location, relative to the working directory (motion/)
+
+
+def _read_yaml(name: str, cfg_dir: Optional[str] = None) -> dict:
+    import yaml
+    for d in ([cfg_dir] if cfg_dir else [CFG_DIR, _PKG_CFG_DIR]):
+        f = os.path.join(d, name)
+        if os.path.exists(f):
+            with open(f, "r") as fh:
+                cfg = yaml.safe_load(fh)
+            if not isinstance(cfg, dict):
+                raise ValueError(f"{f}: expected a mapping at the top level")
+            return cfg
+    raise FileNotFoundError(f"config {name!r} not found under {cfg_dir or CFG_DIR + ' or ' + _PKG_CFG_DIR}")
+
+
+def load_model(box: bool = False, cfg_dir: Optional[str] = None) -> dict:
+    """crowd_ppo/primitive_model.py:74-96 `load_model`, configuration half: read
+    cfg_samp20/MPVAEPolicy_samp_collision(_2).yaml (plain yaml instead of OmegaConf), create
+    results/crowd_ppo/<cfg_name>/<wandb.name>/{results,checkpoints,logs}, set trainconfig.save_dir / log_dir and write the
+    resolved configuration to <exp_dir>/config.yaml (:78-82).  The motion-prior half (configure_model, :56-72) is
+    `build_motion_prior`, whose checkpoint directories come from the combo config named by trainconfig.cfg_2frame_male.
+    Raises FileNotFoundError where the reference calls sys.exit() (:19-21)."""
+    import yaml
+    cfg = _read_yaml("MPVAEPolicy_samp_collision_2.yaml" if box else "MPVAEPolicy_samp_collision.yaml", cfg_dir)
+    for sec in ("modelconfig", "lossconfig", "trainconfig"):
+        if not isinstance(cfg.get(sec), dict):
+            raise KeyError(f"config has no {sec!r} section")
+    run = (cfg.get("wandb") or {}).get("name", "collision_test")
+    dirs = create_dirs(cfg["cfg_name"], run)
+    cfg.update(dirs)
+    cfg["trainconfig"]["save_dir"] = dirs["cfg_ckpt_dir"]
+    cfg["trainconfig"]["log_dir"] = dirs["cfg_log_dir"]
+    with open(os.path.join(dirs["cfg_exp_dir"], "config.yaml"), "w") as fh:
+        yaml.safe_dump(cfg, fh, sort_keys=False)
+    return cfg
+
+
+def env_cfg_from_yaml(cfg: dict) -> dict:
+    """The fields CrowdEnv.step / reset read from the yaml (crowd_env_2f.py:151-152,235,268-281,331; crowd_env_2f_box.py:285-303)
+    as the flat dict VecCrowdEnv takes."""
+    from .crowd_env import DEFAULT_CFG
+    m, l, t = cfg["modelconfig"], cfg["lossconfig"], cfg["trainconfig"]
+    out = dict(DEFAULT_CFG)
+    out.update(reproj_factor=float(m["reproj_factor"]), map_res=int(m.get("map_res", 16)), map_extent=float(m.get("map_extent", 0.8)),
+               goal_thresh=float(t["goal_thresh"]), max_depth=int(t["max_depth"]), pene_thres=float(t.get("pene_thres", 3)),
+               pene_type=str(l.get("pene_type", "body")))
+    for k in ("weight_vp", "weight_floor", "weight_skate", "weight_target_dist", "weight_face_target", "weight_look_target",
+              "weight_pene", "weight_success"):
+        out[k] = float(l[k])
+    return out
+
+
+def policy_cfg_from_yaml(cfg: dict) -> dict:
+    """modelconfig of the policy yaml -> constructor config of GAMMAPolicyBase / GAMMAActor / GAMMACritic (main_ppo.py:108-113)."""
+    out = dict(POLICY_CFG)
+    out.update({k: cfg["modelconfig"][k] for k in POLICY_CFG if k in cfg["modelconfig"]})
+    return out
+
+
+def prior_checkpoint_dirs(cfg: dict, gender: str = "male", cfg_dir: Optional[str] = None, ckpt_root: str = RESULTS_ROOT):
+    """configure_model (primitive_model.py:56-72): trainconfig.cfg_2frame_<gender> names the combo config whose modelconfig
+    names the predictor / regressor configs; their checkpoints live under results/crowd_ppo/<name>/checkpoints."""
+    combo = _read_yaml(cfg["trainconfig"][f"cfg_2frame_{gender}"] + ".yml", cfg_dir)
+    mc = combo["modelconfig"]
+    return (os.path.join(ckpt_root, mc["predictor_config"], "checkpoints"), os.path.join(ckpt_root, mc["regressor_config"], "checkpoints"))
+
+
 def load_body_model(gender: str = "male", seed: int = 0, num_verts: int = synth.NUM_VERTS, model_dir: str = "data/smplx/models"):
     """Real SMPLX_<GENDER>.npz when available (smplx.create(...) arguments of baseops.py:291-320), else synthetic."""
     path = os.path.join(model_dir, "smplx", f"SMPLX_{gender.upper()}.npz")
@@ -76,13 +145,15 @@ def _load_real_smplx(path: str) -> Dict[str, np.ndarray]:
     }
 
 
-def build_motion_prior(device="cuda", seed: int = 0, ckpt_root: str = RESULTS_ROOT) -> GAMMAPrimitiveCombo:
+def build_motion_prior(device="cuda", seed: int = 0, ckpt_root: str = RESULTS_ROOT, ckpt_dirs=None) -> GAMMAPrimitiveCombo:
     """GAMMAPrimitiveComboGenOP.build_model (models_GAMMA_primitive.py:1116-1148): predictor epoch-400.ckp (else
     epoch-200.ckp), regressor epoch-100.ckp, key 'model_state_dict'.  Random init (seeded) when the files are absent."""
     torch.manual_seed(seed)
     combo = GAMMAPrimitiveCombo(PREDICTOR_CFG, REGRESSOR_CFG)
     pdir = os.path.join(ckpt_root, "MPVAE_samp20_2frame_rollout", "checkpoints")
     rdir = os.path.join(ckpt_root, "MoshRegressor_v3_male", "checkpoints")
+    if ckpt_dirs is not None:
+        pdir, rdir = ckpt_dirs
     for name in ("epoch-400.ckp", "epoch-200.ckp"):
         f = os.path.join(pdir, name)
         if os.path.exists(f):
@@ -111,11 +182,12 @@ def build_vposer(device="cuda", seed: int = 0, model_dir: str = "data/smplx/mode
     return enc.to(device).eval()
 
 
-def build_policy(args, device="cuda") -> GAMMAPPOPolicy:
+def build_policy(args, device="cuda", policy_cfg: Optional[dict] = None) -> GAMMAPPOPolicy:
     """crowd_ppo/main_ppo.py:108-162: nets, orthogonal(sqrt 2) init of every nn.Linear, last-policy-layer x0.01,
     AdamW(lr, weight_decay 0.01), GAMMAPPOPolicy."""
     torch.manual_seed(args.seed)
-    actor, critic, shared_net = GAMMAActor(POLICY_CFG), GAMMACritic(POLICY_CFG), GAMMAPolicyBase(POLICY_CFG)
+    pc = policy_cfg or POLICY_CFG
+    actor, critic, shared_net = GAMMAActor(pc), GAMMACritic(pc), GAMMAPolicyBase(pc)
     actor_critic = ActorCritic(actor, critic, shared_net)
     for m in actor_critic.modules():
         if isinstance(m, torch.nn.Linear):
@@ -173,6 +245,6 @@ def build_scene(kind: str, sdf_res: int = 256, seed: int = 0, data_dir: str = "d
 
 
 def build_env(num_agents: int, scene: dict, body: BodyModelHandle, prior: GAMMAPrimitiveCombo, vposer: VPoserEncoder,
-              finetuning=False, seed=0, keep_rollout=False, use_graph=False) -> VecCrowdEnv:
+              finetuning=False, seed=0, keep_rollout=False, use_graph=False, cfg: Optional[dict] = None) -> VecCrowdEnv:
     return VecCrowdEnv(num_agents, body, prior, vposer, finetuning=finetuning, seed=seed, keep_rollout=keep_rollout,
-                       use_graph=use_graph, **scene)
+                       use_graph=use_graph, cfg=cfg, **scene)

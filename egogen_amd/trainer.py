@@ -188,7 +188,9 @@ def onpolicy_trainer(policy: GAMMAPPOPolicy, train_collector: Collector, test_co
         steps_in_epoch = 0
         while steps_in_epoch < step_per_epoch:
             batch = train_collector.collect(n_vec)
-            train_collector.env.check_finite()  # device-side NaN/Inf counter, polled once per collect
+            # device-side NaN/Inf counter, polled once per collect; with several ranks the counter is MAX-reduced first so
+            # that every rank raises together instead of one leaving the others inside the next all-reduce
+            train_collector.env.check_finite(all_ranks=world > 1)
             n_new = n_vec * A_global
             env_step += n_new
             steps_in_epoch += n_new
@@ -200,8 +202,8 @@ def onpolicy_trainer(policy: GAMMAPPOPolicy, train_collector: Collector, test_co
                 if cnt > 0:
                     logger.write("train", env_step, {"reward": float(train_collector.done_ret.item()) / cnt,
                                                      "length": float(train_collector.done_len.item()) / cnt, "n/ep": cnt})
-                train_collector.reset_stat()
                 logger.write("update", env_step, {k: float(np.mean(v)) for k, v in losses.items() if v})
+            train_collector.reset_stat()  # on every rank
         result = None
         if test_collector is not None:
             policy.eval()

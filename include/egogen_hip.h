@@ -124,6 +124,33 @@ int egx_lbs_forward(const egx_body_model* m, const float* xb, const float* betas
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * egx_lbs_joints - the 55 kinematic-tree joints of B bodies without the vertex pass: out_joints55 [B,55,3] =
+ * bm(**bparam).joints[:, :55].  This is all SMPLXParser.get_new_coordinate (models/baseops.py:485: joints 0,1,2) and
+ * calc_calibrate_offset (:529: joint 0 at zero global_orient / transl) take from their full SMPL-X evaluation.
+ * workspace as for egx_lbs_forward.
+ */
+int egx_lbs_joints(const egx_body_model* m, const float* xb, const float* betas, int num_bodies, int frames_per_agent,
+                   float* out_joints55, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * egx_canonical_frame - CanonicalCoordinateExtractor.get_new_coordinate_torch (models/baseops.py:214-225), the tail of
+ * SMPLXParser.get_new_coordinate (:465-490): joints [B, joints_per_body >= 3, 3] -> out_R [B,3,3] (columns x, y, z with
+ * x = normalise((j2 - j1) with z zeroed) - no epsilon, like the reference -, z = (0,0,1), y = normalise(z cross x)),
+ * out_T [B,3] = joint 0 (the reference returns it as [B,1,3]).
+ */
+int egx_canonical_frame(const float* joints, int joints_per_body, int num_bodies, float* out_R, float* out_T, void* stream);
+
+/*
+ * egx_update_transl_glorot - SMPLXParser.update_transl_glorot, torch branch (models/baseops.py:537-598): re-express
+ * transl / global_orient of xb [B,93] in the frame (R,T):  glorot' = aa(R^T aa2R(glorot))  (torchgeometry 0.1.2
+ * angle_axis_to_rotation_matrix / rotation_matrix_to_angle_axis [upstream]),  transl' = R^T (transl + delta_T - T) - delta_T.
+ * R [F,3,3], T [F,3] with F = num_frames in {1, B}; delta_T [B,3] = calc_calibrate_offset (:494-534) = joint 0 of
+ * egx_lbs_joints at zero global_orient / transl.  out [B,93]; out == xb is the reference's inplace=True.
+ */
+int egx_update_transl_glorot(const float* R, const float* T, int num_frames, const float* delta_T, const float* xb, int num_bodies,
+                             float* out, void* stream);
+
+/*
  * egx_sdf_sample - calc_sdf(vertices, sdf_dict) (crowd_ppo/utils.py:54-84): trilinear, border clamp,
  * align_corners=False, negated.  pts [n,3] -> out [n].
  */
@@ -341,6 +368,21 @@ int egx_env_step_post(const egx_env_config* cfg, const egx_env_scenes* scenes, c
 /* scene sampler next_body (environments.py:65-335 / 371-627) + CrowdEnv.reset (crowd_env_2f.py:320-415) */
 int egx_env_reset(const egx_env_config* cfg, const egx_env_scenes* scenes, const egx_env_state* st,
                   const egx_env_reset_io* io, int num_agents, void* stream);
+
+/* CrowdEnv._get_feature (crowd_ppo/crowd_env_2f.py:680-727), the two outputs the environment consumes (:261-265,399,412):
+ *   Y_l [nb,nt,M,3] canonical markers, pel [nb,nt,3], R0 [nb,3,3], T0 [nb,3], wpath [wpath_rows in {1,nb}, 3] (world target)
+ *   out_dist_xyz [nb,nt] = clip(||R0^T (wpath - T0) - pel||, 1e-12)            (may be NULL)
+ *   out_fea_marker [nb,nt,M*3] = unit vectors marker -> target (`fea_marker_3d_n`) (may be NULL)
+ * The step / reset kernels evaluate the same device functions inline. */
+int egx_env_get_feature(const float* Y_l, const float* pel, const float* R0, const float* T0, const float* wpath, int wpath_rows,
+                        int num_bodies, int num_frames, int num_markers, float* out_dist_xyz, float* out_fea_marker, void* stream);
+
+/* get_map (exp_GAMMAPrimitive/utils/batch_gen_amass.py:934-968) + the {1,-1} re-coding of crowd_env_2f_box.py:768-769:
+ *   tris [F,3,2] navmesh triangles (xy), map_lin [res] = linspace(-extent, extent, res), R [nb,3,3], T [nb,3]
+ *   out_points_scene [nb,res*res,3] (z = floor_height; may be NULL), out_local_map [nb,res*res] = 1 walkable / -1 not
+ * (meshgrid with 'ij' indexing: point p = (lin[p / res], lin[p % res], 0)). */
+int egx_env_get_map(const float* tris, int num_tris, float floor_height, const float* map_lin, int res, const float* R, const float* T,
+                    int num_bodies, float* out_points_scene, float* out_local_map, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PPO rollout glue

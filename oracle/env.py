@@ -69,6 +69,14 @@ def get_feature(Y_l, pel, R0, T0, pt_wpath):
     return dist_xy, dist_xyz, fea_wpath, fea_marker_3d_n, fea_marker_h
 
 
+def blend_params(body_params: torch.Tensor, t_his: int = T_HIS) -> torch.Tensor:
+    """crowd_env_2f.py:729-739 _blend_params: body_params[t,b,93] modified IN PLACE - frames t_his and t_his+1 become the
+    mean of their neighbours, pose part ([6:]) only, sequentially (the second uses the already smoothed first)."""
+    for t in (t_his, t_his + 1):
+        body_params[t, :, 6:] = (body_params[t - 1, :, 6:] + body_params[t + 1, :, 6:]) / 2.0
+    return body_params
+
+
 def get_map(tris: torch.Tensor, R, T, res=16, extent=0.8, floor_height=0.0):
     """exp_GAMMAPrimitive/utils/batch_gen_amass.py:934-968.  tris[F,3,2] (navmesh triangles, xy),
     R[b,3,3], T[b,1,3] -> points_local[b,res*res,3], points_scene, map bool[b,res*res]."""
@@ -176,7 +184,7 @@ class OracleCrowdEnv:
         self.sdf_dict = sdf_dict
         self.edges = edges
         self.box_scenes = box_scenes
-        self.cfg = dict(cfg or (BOX_CFG if scene_kind == "box" else DEFAULT_CFG))
+        self.cfg = dict(cfg or (BOX_CFG if scene_kind in ("box", "crowd") else DEFAULT_CFG))  # main_crowd_eval.py:224 load_model(box=True)
         self.finetuning = finetuning
         self.last = {}
 
@@ -278,9 +286,7 @@ class OracleCrowdEnv:
         Y_gen, Yb_gen = nets.sample_prior(self.prior_sd, X, betas18, action_z.to(dt))
         Y = torch.cat([X, Y_gen], dim=0)                                  # [20,A,201]
         Yb = torch.cat([Xb, Yb_gen], dim=0).clone()                       # [20,A,93]
-        # _blend_params (:729-739): sequential, in place, pose part only
-        Yb[2, :, 6:] = (Yb[1, :, 6:] + Yb[3, :, 6:]) / 2.0
-        Yb[3, :, 6:] = (Yb[2, :, 6:] + Yb[4, :, 6:]) / 2.0
+        Yb = blend_params(Yb, T_HIS)                                      # :120-123
         pred_markers = Y.reshape(T_ALL, A, -1, 3).permute(1, 0, 2, 3)     # [A,20,67,3]
         pred_params = Yb.permute(1, 0, 2).contiguous()                    # [A,20,93]
         betas_rows = self.betas[:, None, :].expand(A, T_ALL, 10).reshape(A * T_ALL, 10)
@@ -300,6 +306,9 @@ class OracleCrowdEnv:
             sv[:, :, self.feet_vids] = 0.0
             inside = sv.lt(0.0)
             cnt = inside.sum(dim=-1)                                      # [A,20]
+            near = sv.abs() < 2e-5                                        # test diagnostics: vertices within fp32 round-off of
+            near[:, :, self.feet_vids] = False                            # the zero level set (their sign is not reproducible)
+            self.last["pene_near_zero"] = near.sum(dim=-1)
             num_inside = cnt.sum(dim=1).to(dt) / T_ALL / 10
             penetration = cnt.max(dim=1).values >= 40
             r_pene = torch.exp(-num_inside)

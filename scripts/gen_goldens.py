@@ -10,6 +10,12 @@ imported, never called, on these code paths - SURVEY.md section 8(c)):
   models/models_GAMMA_primitive.py::MoshRegressor._forward, RotConverter.cont2rotmat -> regressor_ref.npz
   models/models_policy_ppo.py::{GAMMAPolicyBase,GAMMAActor,GAMMACritic} -> policy_ref.npz
   models/baseops.py::CanonicalCoordinateExtractor.get_new_coordinate_torch -> canon_ref.npz
+  crowd_ppo/crowd_env_2f.py::CrowdEnv._get_feature, _blend_params (unbound: neither reads `self`) -> feature_ref.npz
+  crowd_ppo/crowd_env_2f_box.py::CrowdEnv._get_feature (with the walkability map) and
+  exp_GAMMAPrimitive/utils/batch_gen_amass.py::get_map                   -> getmap_ref.npz
+  crowd_ppo/utils.py::save_rollout_results                               -> rollout_ref.npz + rollout_ref.pkl
+get_map hard-codes device='cuda' / torch.cuda.FloatTensor; `cuda_to_cpu()` below redirects exactly those two spellings to the
+CPU for the duration of the call (placement only - the arithmetic executed is the reference's).
 """
 import os
 import sys
@@ -45,6 +51,49 @@ def install_stubs():
     except Exception:
         mp = _stub("matplotlib")
         mp.pyplot = _stub("matplotlib.pyplot")
+
+
+def install_env_stubs():
+    """Packages crowd_env_2f*.py / batch_gen_amass.py import at module level but do not touch on the functions exercised."""
+    class _Env:
+        pass
+    gym = _stub("gymnasium", Env=_Env)
+    gym.spaces = _stub("gymnasium.spaces", Dict=object, Box=object)
+    for name in ("trimesh", "pyrender", "pytorch3d", "pytorch3d.structures", "pytorch3d.transforms", "human_body_prior",
+                 "human_body_prior.tools"):
+        _stub(name)
+    _stub("human_body_prior.tools.model_loader", load_vposer=None)
+    # utils_canonicalize_babel builds two body models at import time (licensed SMPL-X files, absent here) that none of the
+    # functions exercised below touch
+    sys.modules["smplx"].create = lambda *a, **k: None
+    sh = _stub("shapely", LineString=object)
+    sh.geometry = _stub("shapely.geometry", MultiPoint=object, Point=object)
+    try:
+        import sklearn.neighbors  # noqa
+    except Exception:
+        sk = _stub("sklearn")
+        sk.neighbors = _stub("sklearn.neighbors", NearestNeighbors=object)
+
+
+class cuda_to_cpu:
+    """Run reference code that spells its device as 'cuda' on the CPU: Tensor.to(device='cuda') and
+    torch.cuda.FloatTensor(...) are redirected; nothing else changes."""
+
+    def __enter__(self):
+        self._to, self._ft = torch.Tensor.to, torch.cuda.FloatTensor
+        orig = self._to
+
+        def to(t, *a, **k):
+            if k.get("device") == "cuda":
+                k = dict(k, device="cpu")
+            a = tuple("cpu" if (isinstance(x, str) and x == "cuda") else x for x in a)
+            return orig(t, *a, **k)
+        torch.Tensor.to = to
+        torch.cuda.FloatTensor = torch.FloatTensor
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.to, torch.cuda.FloatTensor = self._to, self._ft
 
 
 def sd_to_np(sd, prefix=""):
@@ -178,6 +227,79 @@ def main():
     n_pol = sum(p.numel() for m in (actor, critic, base) for p in m.parameters())
     print("policy_ref", hx.shape, mu.shape, val.shape, n_pol, "state_dict keys",
           len(base.state_dict()) + len(actor.state_dict()) + len(critic.state_dict()))
+    # ---- env features / pose smoothing (crowd_env_2f.py:680-739) ------------------------------------
+    install_env_stubs()
+    import types as _types
+    from crowd_ppo import crowd_env_2f, crowd_env_2f_box
+    gf = torch.Generator().manual_seed(55)
+    nb, nt = 5, 2
+    Y_l = torch.randn(nb, nt, 201, generator=gf) * 0.6
+    pel = torch.randn(nb, nt, 3, generator=gf) * 0.3
+    ang = torch.rand(nb, generator=gf) * 6.28
+    R0 = torch.zeros(nb, 3, 3)
+    R0[:, 0, 0], R0[:, 0, 1], R0[:, 1, 0], R0[:, 1, 1], R0[:, 2, 2] = torch.cos(ang), -torch.sin(ang), torch.sin(ang), torch.cos(ang), 1.0
+    T0 = torch.randn(nb, 1, 3, generator=gf)
+    wp = torch.randn(1, 3, generator=gf) * 2
+    # one marker exactly at the target and the pelvis exactly at the target for b = 0: the clip(min=1e-12) branches
+    wl = torch.einsum("ij,j->i", R0[0].T, wp[0] - T0[0, 0])
+    Y_l[0, 0, 0:3] = wl
+    pel[0, 0] = wl
+    outs = crowd_env_2f.CrowdEnv._get_feature(None, Y_l.clone(), pel.clone(), R0, T0, wp, None)
+    bp = torch.randn(20, 4, 93, generator=gf)
+    bp_out = crowd_env_2f.CrowdEnv._blend_params(None, bp.clone(), 2)
+    np.savez_compressed(os.path.join(OUT, "feature_ref.npz"), Y_l=Y_l.numpy(), pel=pel.numpy(), R0=R0.numpy(), T0=T0.numpy(),
+                        wpath=wp.numpy(), dist_xy=outs[0].numpy(), dist_xyz=outs[1].numpy(), fea_wpath=outs[2].numpy(),
+                        fea_marker_3d_n=outs[3].numpy(), fea_marker_h=outs[4].numpy(), blend_in=bp.numpy(), blend_out=bp_out.numpy())
+    print("feature_ref", [tuple(o.shape) for o in outs], tuple(bp_out.shape))
+
+    # ---- walkability map (batch_gen_amass.py:934-968) and the box env's _get_feature (crowd_env_2f_box.py:733-776) ----
+    from exp_GAMMAPrimitive.utils.batch_gen_amass import get_map
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from egogen_amd import synth
+    sc = synth.make_box_scenes(2, 8, seed=11)[1]
+    tris = np.asarray(sc["tris"], np.float32).reshape(-1, 3, 2)
+    verts = np.concatenate([tris.reshape(-1, 2), np.full((tris.shape[0] * 3, 1), float(sc["floor_height"]), np.float32)], axis=1)
+    verts = verts.astype(np.float64)  # trimesh keeps float64 vertices
+    nav = _types.SimpleNamespace(vertices=verts, faces=np.arange(tris.shape[0] * 3).reshape(-1, 3))
+    # frame origins: on the obstacle's edges and corner, at the floor's edge, in free space
+    lo, hi = np.asarray(sc["box_lo"], np.float32), np.asarray(sc["box_hi"], np.float32)
+    org = np.array([[lo[0], (lo[1] + hi[1]) / 2], [hi[0] + 0.3, hi[1] + 0.3], [(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2],
+                    [3.7, -3.6], [-3.0, 3.0]], np.float32)[:nb]
+    Tm = torch.cat([torch.from_numpy(org).reshape(nb, 1, 2), torch.rand(nb, 1, 1, generator=gf)], dim=-1)
+    with cuda_to_cpu():
+        pts, pts_scene, mp = get_map(nav, R0, Tm, res=16, extent=0.8, return_type="torch")
+        me = _types.SimpleNamespace(cfg=_types.SimpleNamespace(modelconfig=_types.SimpleNamespace(map_res=16, map_extent=0.8)))
+        bouts = crowd_env_2f_box.CrowdEnv._get_feature(me, Y_l.clone(), pel.clone(), R0, Tm, wp, {"navmesh": nav})
+    np.savez_compressed(os.path.join(OUT, "getmap_ref.npz"), tris=tris, floor_height=np.float32(sc["floor_height"]), R=R0.numpy(),
+                        T=Tm.numpy(), points=pts.numpy(), points_scene=pts_scene.numpy(), map=mp.numpy(),
+                        box_points_local=bouts[5].numpy(), box_local_map=bouts[6].numpy(), box_fea_marker=bouts[3].numpy(),
+                        box_dist_xyz=bouts[1].numpy(), Y_l=Y_l.numpy(), pel=pel.numpy(), wpath=wp.numpy())
+    print("getmap_ref", tuple(mp.shape), int(mp.sum()), "walkable of", mp.numel())
+
+    # ---- rollout writer (crowd_ppo/utils.py:10-51) ----------------------------------------------------------
+    import pickle
+    import tempfile
+    from crowd_ppo.utils import save_rollout_results
+    gr = torch.Generator().manual_seed(66)
+    n_mp = 3
+    mps = []
+    for i in range(n_mp):
+        mps.append([torch.randn(4, 20, 67, 3, generator=gr), torch.randn(4, 20, 93, generator=gr), torch.randn(10, generator=gr), "male",
+                    torch.randn(3, 3, generator=gr), torch.randn(1, 3, generator=gr), torch.randn(4, 20, 3, generator=gr), "2-frame"])
+    scene = {"wpath": torch.randn(2, 3, generator=gr), "navmesh_path": "data/scenes/room0_navmesh.ply", "scene_path": "data/scenes/room0.ply"}
+    with tempfile.TemporaryDirectory() as td:
+        save_rollout_results(scene, mps, td, man_id="ref")
+        with open(os.path.join(td, "motion_ref.pkl"), "rb") as f:
+            ref_obj = pickle.load(f)
+    with open(os.path.join(OUT, "rollout_ref.pkl"), "wb") as f:   # plain dict / list / ndarray / str only
+        pickle.dump(ref_obj, f, protocol=4)
+    flat = {"wpath": scene["wpath"].numpy()}
+    for i, mp_ in enumerate(mps):
+        for j, v in enumerate(mp_):
+            if torch.is_tensor(v):
+                flat[f"mp{i}_{j}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "rollout_ref.npz"), n_mp=np.int64(n_mp), **flat)
+    print("rollout_ref", list(ref_obj.keys()), list(ref_obj["motion"][0].keys()))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -1,0 +1,277 @@
+"""GPU tests of the drop-in boundary beyond the step loop: the SMPLXParser methods the environment's callers
+use (get_new_coordinate, calc_calibrate_offset, update_transl_glorot), the stand-alone _get_feature / get_map operators
+against reference-generated goldens, and BASELINE configs[0] - the real Replica room0 walkable polygon (6 rings, concave
+exterior, holes) and its start/target pairs through the single-agent CrowdEnv view."""
+import ctypes as C
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from egogen_amd import synth
+from tests.helpers import build_world, load_golden, max_abs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _parser(V=1536, seed=0):
+    from egogen_amd.body_model import BodyModelHandle, SMPLXParser
+    from oracle.smplx_lbs import BodyModel
+    bm = synth.make_body_model(seed, num_verts=V)
+    mk, feet = synth.marker_ids(V), synth.feet_vids(V)
+    h = BodyModelHandle(bm, mk, feet)
+    p = SMPLXParser({"n_batch": 8, "device": "cuda", "marker_placement": "ssm2_67", "body_models": {"male": h, "female": h}})
+    return p, h, BodyModel(bm), mk
+
+
+def _xb(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    xb = torch.zeros(B, 93)
+    xb[:, :3] = torch.randn(B, 3, generator=g)
+    xb[:, 3:6] = torch.randn(B, 3, generator=g) * 0.9
+    xb[:, 6:69] = torch.randn(B, 63, generator=g) * 0.25
+    xb[:, 69:] = torch.randn(B, 24, generator=g) * 0.4
+    return xb, torch.randn(10, generator=g)
+
+
+def test_canonical_frame_kernel_matches_reference_golden():
+    """egx_canonical_frame against CanonicalCoordinateExtractor.get_new_coordinate_torch's own outputs (canon_ref.npz)."""
+    from egogen_amd import _lib
+    lib = _lib.load()
+    g = load_golden("canon_ref.npz")
+    j = torch.from_numpy(g["jts"]).cuda().contiguous()
+    B = j.shape[0]
+    R, T = torch.empty(B, 3, 3, device="cuda"), torch.empty(B, 3, device="cuda")
+    _lib.check(lib.egx_canonical_frame(_lib.ptr(j), int(j.shape[1]), B, _lib.ptr(R), _lib.ptr(T), _lib.current_stream_ptr()), "frame")
+    assert max_abs(R.cpu(), g["R"]) < 1e-6
+    assert max_abs(T.cpu(), g["T"].reshape(B, 3)) == 0.0
+    with pytest.raises(_lib.EgxError):
+        _lib.check(lib.egx_canonical_frame(_lib.ptr(j), 2, B, _lib.ptr(R), _lib.ptr(T), None), "frame")
+
+
+def test_smplx_parser_get_new_coordinate_and_update_transl_glorot():
+    """SMPLXParser.get_new_coordinate / calc_calibrate_offset / update_transl_glorot (baseops.py:465-598) vs the oracle."""
+    from oracle import env as oenv
+    from oracle.rot import tgm_angle_axis_to_rotation_matrix as aa2R
+    from oracle.smplx_lbs import smplx_forward
+    p, h, ob, mk = _parser()
+    B = 9
+    xb, betas = _xb(B, 4)
+    _, j = smplx_forward(ob, xb, betas[None].repeat(B, 1))
+    Ro, To = oenv.get_new_coordinate(j[:, :22])
+    # tensors in, tensors out (to_numpy=False): [b,3,3], [b,1,3]
+    R, T = p.get_new_coordinate(betas.cuda(), "male", xb.cuda(), to_numpy=False)
+    assert R.shape == (B, 3, 3) and T.shape == (B, 1, 3) and R.is_cuda
+    assert max_abs(R.cpu(), Ro) < 2e-5 and max_abs(T.cpu(), To) < 2e-5
+    # numpy in, numpy out
+    Rn, Tn = p.get_new_coordinate(betas.numpy(), "male", xb.numpy(), to_numpy=True)
+    assert isinstance(Rn, np.ndarray) and max_abs(Rn, Ro) < 2e-5 and max_abs(Tn, To) < 2e-5
+    # joints / markers getters share the forward (instantiation coverage of the pass-through methods)
+    assert max_abs(p.get_jts(betas.cuda(), "male", xb.cuda(), to_numpy=False).cpu(), j[:, :22]) < 2e-5
+    assert p.get_markers(betas.numpy(), "male", xb.numpy()).shape == (B, len(mk), 3)
+    assert p.marker == [int(v) for v in mk]
+    # calc_calibrate_offset: pelvis at zero orient / transl
+    xz = xb.clone(); xz[:, :6] = 0
+    _, jz = smplx_forward(ob, xz, betas[None].repeat(B, 1))
+    d = p.calc_calibrate_offset(h, betas.cuda(), xb[:, 6:69].cuda(), to_numpy=False)
+    assert max_abs(d.cpu(), jz[:, 0]) < 2e-5
+    # update_transl_glorot into the frame of body 0 (one frame for all) and per-body frames
+    for Rf, Tf in ((Ro[:1], To[:1]), (Ro, To)):
+        ref = oenv.update_transl_glorot(Rf.expand(B, 3, 3), Tf.expand(B, 1, 3), jz[:, 0], xb)
+        src = xb.clone().cuda()
+        out = p.update_transl_glorot(Rf.cuda(), Tf.cuda(), betas.cuda(), "male", src, to_numpy=False, inplace=False)
+        assert out.data_ptr() != src.data_ptr() and torch.equal(src.cpu(), xb)          # inplace=False leaves xb alone
+        assert max_abs(out[:, :3].cpu(), ref[:, :3]) < 2e-5
+        assert max_abs(aa2R(out[:, 3:6].cpu()), aa2R(ref[:, 3:6])) < 2e-5
+        assert torch.equal(out[:, 6:].cpu(), xb[:, 6:])
+        out2 = p.update_transl_glorot(Rf.cuda(), Tf.cuda(), betas.cuda(), "male", src, to_numpy=False, inplace=True)
+        assert out2.data_ptr() == src.data_ptr() and max_abs(src[:, :6].cpu(), out[:, :6].cpu()) == 0.0
+        arr = xb.numpy().copy()
+        out3 = p.update_transl_glorot(Rf.numpy(), Tf.numpy(), betas.numpy(), "male", arr, to_numpy=True, inplace=True)
+        assert out3 is arr and max_abs(arr[:, :6], out[:, :6].cpu()) < 1e-6
+    # the transformed parameters describe the same body in the new frame: joints' = R^T (joints - T)
+    out = p.update_transl_glorot(Ro[:1].cuda(), To[:1].cuda(), betas.cuda(), "male", xb.cuda(), to_numpy=False, inplace=False)
+    j_new = p.get_jts(betas.cuda(), "male", out, to_numpy=False).cpu()
+    want = torch.einsum("ij,bpj->bpi", Ro[0].T, j[:, :22] - To[0])
+    assert max_abs(j_new, want) < 5e-5
+
+
+def test_get_feature_kernel_matches_reference_golden():
+    """egx_env_get_feature (the device functions of the step / reset kernels) against CrowdEnv._get_feature's own outputs."""
+    from egogen_amd import _lib
+    lib = _lib.load()
+    g = load_golden("feature_ref.npz")
+    c = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).cuda()
+    nb, nt = g["pel"].shape[:2]
+    dist = torch.empty(nb, nt, device="cuda")
+    fea = torch.empty(nb, nt, 201, device="cuda")
+    T0 = c("T0").reshape(nb, 3).contiguous()
+    _lib.check(lib.egx_env_get_feature(_lib.ptr(c("Y_l")), _lib.ptr(c("pel")), _lib.ptr(c("R0")), _lib.ptr(T0), _lib.ptr(c("wpath")), 1,
+                                       nb, nt, 67, _lib.ptr(dist), _lib.ptr(fea), _lib.current_stream_ptr()), "feature")
+    assert max_abs(dist.cpu(), g["dist_xyz"].reshape(nb, nt)) < 1e-6
+    # unit vectors; the marker sitting exactly on the target yields 0/1e-12 = 0 on both sides
+    assert max_abs(fea.cpu(), g["fea_marker_3d_n"]) < 2e-6
+
+
+def test_get_map_kernel_matches_reference_golden():
+    """egx_env_get_map against batch_gen_amass.get_map / the box env's {1,-1} map (frames on the obstacle's edges)."""
+    from egogen_amd import _lib
+    lib = _lib.load()
+    g = load_golden("getmap_ref.npz")
+    tris = torch.from_numpy(g["tris"].reshape(-1, 6)).cuda().contiguous()
+    R = torch.from_numpy(g["R"]).cuda().contiguous()
+    T = torch.from_numpy(g["T"].reshape(-1, 3)).cuda().contiguous()
+    nb = R.shape[0]
+    lin = torch.linspace(-0.8, 0.8, 16).cuda()
+    ps = torch.empty(nb, 256, 3, device="cuda")
+    mp = torch.empty(nb, 256, device="cuda")
+    _lib.check(lib.egx_env_get_map(_lib.ptr(tris), int(tris.shape[0]), float(g["floor_height"]), _lib.ptr(lin), 16, _lib.ptr(R), _lib.ptr(T), nb,
+                                   _lib.ptr(ps), _lib.ptr(mp), _lib.current_stream_ptr()), "map")
+    assert max_abs(ps.cpu(), g["points_scene"]) < 1e-6
+    got, want = mp.cpu().numpy(), g["box_local_map"]
+    # a grid point within round-off of a triangle edge may flip; everything else is exact
+    diff = np.argwhere(got != want)
+    for b, pidx in diff:
+        px, py = g["points_scene"][b, pidx, :2]
+        t = g["tris"]
+        dmin = min(abs((px - t[f, (k + 1) % 3, 0]) * (t[f, k, 1] - t[f, (k + 1) % 3, 1]) - (t[f, k, 0] - t[f, (k + 1) % 3, 0]) * (py - t[f, (k + 1) % 3, 1]))
+                   for f in range(t.shape[0]) for k in range(3))
+        assert dmin < 1e-5, (b, pidx, dmin)
+    assert len(diff) <= 2
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[0]: Replica room0
+# ---------------------------------------------------------------------------------------------
+
+def _room0_world(A, V=1536, sdf_res=48, finetuning=False, keep_rollout=False):
+    """GPU VecCrowdEnv + CPU oracle on the REAL room0 walkable polygon / start-target pairs (egogen_assets.npz) with a
+    room0-shaped synthetic SDF (room0_sdf.pkl is not redistributable)."""
+    from egogen_amd.body_model import BodyModelHandle
+    from egogen_amd.crowd_env import VecCrowdEnv
+    from egogen_amd.models import GAMMAPrimitiveCombo, PREDICTOR_CFG, REGRESSOR_CFG, VPoserEncoder
+    from oracle.env import OracleCrowdEnv
+    from oracle.smplx_lbs import BodyModel
+    from tests.helpers import seeded_prior_state_dict, seeded_vposer_state_dict
+    bm = synth.make_body_model(0, num_verts=V)
+    mk, feet, fmi = synth.marker_ids(V), synth.feet_vids(V), synth.feet_marker_idx()
+    prior_sd, vposer_sd = seeded_prior_state_dict(), seeded_vposer_state_dict()
+    scene = synth.make_sdf_scene(sdf_res, room="room0")
+    rings = synth.room0_polygon()
+    assert len(rings) == 6 and sum(len(r) for r in rings) == 95
+    pairs = np.asarray(synth.load_assets()["room0_pairs"][:256], np.float32)
+    sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
+    o = OracleCrowdEnv(BodyModel(bm), prior_sd, {k: v.float() for k, v in vposer_sd.items()}, mk, feet, fmi, scene_kind="sdf",
+                       sdf_dict=sd, edges=synth.rings_to_edges(rings), finetuning=finetuning)
+    h = BodyModelHandle(bm, mk, feet)
+    combo = GAMMAPrimitiveCombo(PREDICTOR_CFG, REGRESSOR_CFG)
+    combo.load_state_dict(prior_sd)
+    vp = VPoserEncoder()
+    vp.load_state_dict(vposer_sd)
+    env = VecCrowdEnv(A, h, combo.cuda().eval(), vp.cuda().eval(), scene_kind="sdf", sdf_dict=scene, rings=rings, pairs=pairs,
+                      finetuning=finetuning, keep_rollout=keep_rollout, seed=0)
+    return {"env": env, "oracle": o, "A": A, "pairs": pairs, "bm": bm}
+
+
+def test_room0_reset_and_steps_match_oracle():
+    """reset + 3 steps on room0: egosensing rays against 89 edges of a concave polygon with 5 holes."""
+    from tests.test_env_gpu import _close, _compare_state, _oracle_reset, _sync_oracle_from_gpu
+    A = 6
+    w = _room0_world(A)
+    env, o = w["env"], w["oracle"]
+    assert env.edges.shape[0] == 89
+    vp = env.valid_pairs[:A].cpu().numpy()
+    env.set_candidates(vp.reshape(A, 1, 2, 3))
+    obs = env.reset()
+    oobs, accept = _oracle_reset(w, vp, [0] * A)
+    assert bool(accept.all())
+    _compare_state(w)
+    _close(obs["egosensing"], oobs["egosensing"], 2e-4, "room0 reset egosensing")
+    ego = obs["egosensing"].cpu().numpy()
+    assert (ego < 0.999).any() and (ego > -0.999).any(), "rays should both hit walls and run free in room0"
+    g = torch.Generator().manual_seed(11)
+    for it in range(3):
+        _sync_oracle_from_gpu(w)
+        z = torch.randn(A, 128, generator=g) * 0.5
+        obs, rew, term = env.step(z.cuda(), auto_reset=False)
+        oobs, orew, oterm = o.step(z)
+        _close(env.Y_gen, o.last["Y_gen"], 1e-4, "Y_gen")
+        _close(env.joints.reshape(A, 20, -1, 3), o.last["joints"], 2e-4, "joints")
+        _close(obs["egosensing"], oobs["egosensing"], 2e-4, f"room0 egosensing step {it}")
+        _close(rew, orew, 3e-3, "reward")
+        assert term.cpu().bool().tolist() == oterm.tolist()
+        _compare_state(w, 3e-4)
+
+
+def test_single_agent_crowd_env_view_rollout_matches_oracle(tmp_path):
+    """configs[0] shape: ONE agent behind the reference's gym interface (CrowdEnv.reset / step, crowd_env_2f.py:78,320) on
+    room0, actions injected, the episode written with save_rollout_results (crowd_env_2f.py:154-155,305-309) and compared
+    with an oracle rollout on the same actions: blended_marker, smplx_params, pelvis_loc, transf_* at 1e-4."""
+    from egogen_amd.crowd_env import CrowdEnv
+    from egogen_amd.utils import save_rollout_results
+    from tests.test_env_gpu import _oracle_reset
+    w = _room0_world(1, keep_rollout=True)
+    vec, o = w["env"], w["oracle"]
+    env = CrowdEnv(vec)
+    assert env.action_space["shape"] == (128,) and env.observation_space["state"] == (2, 402)
+    pair = vec.valid_pairs[3:4].cpu().numpy()
+    vec.set_candidates(pair.reshape(1, 1, 2, 3))
+    obs, info = env.reset()
+    assert info == {} and obs["state"].shape == (2, 402) and obs["egosensing"].shape == (2, 32)
+    assert obs["dist"].shape == (1,) and obs["time"].shape == (1,)
+    oobs, _ = _oracle_reset(w, pair, [0])
+    assert max_abs(obs["state"].cpu(), oobs["state"][0]) < 1e-4
+    g = torch.Generator().manual_seed(5)
+    mps, ref = [], []
+    wpath0 = vec.wpath[0].clone()
+    for it in range(4):                        # no re-synchronisation: the oracle runs its own state for the whole episode
+        z = (torch.randn(128, generator=g) * 0.5).numpy().astype(np.float32)      # the reference passes numpy (crowd_env_2f.py:102)
+        R_prev, T_prev = o.R0.clone(), o.T0.clone()
+        obs, rew, term, trunc, info = env.step(z)
+        oobs, orew, oterm = o.step(torch.from_numpy(z)[None])
+        assert isinstance(rew, float) and isinstance(term, bool) and trunc is False and info == {}
+        assert abs(rew - float(orew[0])) < 3e-3 and term == bool(oterm[0])
+        pel = vec.joints.reshape(1, 20, -1, 3)[:, :, 0]
+        fr = vec.prev_frame[0]
+        mps.append([vec.marker_b[0:1].clone(), vec.pred_params[0:1].clone(), vec.betas[0].clone(), "male", fr[:9].reshape(3, 3).clone(),
+                    fr[9:].reshape(1, 3).clone(), pel.clone(), "2-frame"])
+        ref.append({"blended_marker": o.last["marker_b"][0].numpy(), "smplx_params": o.last["pred_params"][0:1].numpy(),
+                    "pelvis_loc": o.last["pelvis"][0].numpy(), "transf_rotmat": R_prev[0].numpy(), "transf_transl": T_prev[0].numpy()})
+        if term:
+            break
+    path = save_rollout_results({"wpath": wpath0, "navmesh_path": "room0"}, mps, str(tmp_path), man_id="view")
+    with open(path, "rb") as f:
+        node = pickle.load(f)
+    assert list(node.keys()) == ["motion", "wpath", "navmesh_path"] and len(node["motion"]) == len(ref)
+    drift = []
+    for mp, r in zip(node["motion"], ref):
+        assert mp["blended_marker"].shape == (20, 67, 3) and mp["smplx_params"].shape == (1, 20, 93) and mp["pelvis_loc"].shape == (20, 3)
+        assert mp["gender"] == "male" and mp["mp_type"] == "2-frame" and mp["betas"].shape == (10,)
+        for k in ("blended_marker", "pelvis_loc", "transf_rotmat", "transf_transl"):
+            scale = max(1.0, float(np.abs(r[k]).max()))
+            assert max_abs(mp[k], r[k]) <= 1e-4 * scale, (k, max_abs(mp[k], r[k]))
+        assert max_abs(mp["smplx_params"][..., :3], r["smplx_params"][..., :3]) <= 2e-4
+        assert max_abs(mp["smplx_params"][..., 6:], r["smplx_params"][..., 6:]) <= 2e-4
+        drift.append(max_abs(mp["blended_marker"], r["blended_marker"]))
+    print("un-synchronised marker drift per primitive:", ["%.2e" % d for d in drift])
+
+
+def test_main_ppo_watch_room0_one_agent(tmp_path):
+    """configs[0] command line: main_ppo.py --watch --test-num 1 on room0 writes motion_*.pkl and config.yaml."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "crowd_ppo", "main_ppo.py"), "--watch", "--deterministic-eval", "--test-num", "1",
+           "--scene", "room0", "--num-verts", "1024", "--sdf-res", "32", "--logdir", str(tmp_path / "log")]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "Final reward:" in r.stdout
+    assert os.path.isfile(tmp_path / "results" / "crowd_ppo" / "MPVAEPolicy_samp_collision" / "collision_test" / "config.yaml")
+    pk = sorted((tmp_path / "log" / "eval_results").glob("motion_*.pkl"))
+    assert pk, "no rollout written"
+    with open(pk[0], "rb") as f:
+        node = pickle.load(f)
+    assert node["wpath"].shape == (2, 3) and node["motion"][0]["blended_marker"].shape == (20, 67, 3)

@@ -107,11 +107,17 @@ def test_step_sdf_matches_oracle(finetuning):
             if nme == "r_pene":
                 continue
             _close(env.rterms[:, i], L[nme], 2e-4, nme)
-        # integer penetration counts: exact up to vertices within round-off of the zero level set
+        # integer penetration counts: exact except for vertices within fp32 round-off (2e-5 m) of the zero level set; the
+        # tolerance of r_pene = exp(-sum(count) / 20 / 10) and of the reward follows from that bound, nothing is added to it
         dcnt = (env.pene_count.reshape(A, 20).cpu().long() - L["pene_count"]).abs()
-        assert dcnt.max() <= 3, dcnt.max()
-        _close(env.rterms[:, 6], L["r_pene"], 2e-3, "r_pene")
-        _close(rew, orew, 3e-3, "reward")
+        near = L["pene_near_zero"]
+        assert (dcnt <= near).all(), (dcnt - near).max()
+        slack = near.sum(1).double() / 200.0                       # |d r_pene| <= r_pene * |d num_inside| <= sum(near) / 200
+        d_pene = (env.rterms[:, 6].cpu().double() - L["r_pene"].double()).abs()
+        assert (d_pene <= slack + TOL).all(), (d_pene - slack).max()
+        w_pene = 0.1 if finetuning else 1.0
+        d_rew = (rew.cpu().double() - orew.double()).abs()
+        assert (d_rew <= w_pene * slack + 2e-4 * max(1.0, float(orew.abs().max()))).all(), d_rew.max()
         assert term.cpu().bool().tolist() == oterm.tolist()
         _compare_state(w, 3e-4)
         _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
@@ -229,7 +235,7 @@ def test_crowd_group_matches_oracle_with_sequential_hole_updates():
     oracles = []
     for k in range(G):
         o = OracleCrowdEnv(BodyModel(w["bm"]), w["prior_sd"], {kk: v.float() for kk, v in w["vposer_sd"].items()}, w["mk"], w["feet"],
-                           synth.feet_marker_idx(), scene_kind="crowd", cfg=dict(DEFAULT_CFG))
+                           synth.feet_marker_idx(), scene_kind="crowd")   # both sides: the _2 yaml (main_crowd_eval.py:224)
         oracles.append(o)
     boxes = np.zeros((G, S, 4))
     for k, o in enumerate(oracles):
@@ -311,3 +317,39 @@ def test_nonfinite_counter_raises():
     with pytest.raises(FloatingPointError):
         env.check_finite()
     env.check_finite()  # the counter was cleared
+
+
+def test_episode_without_resync_reports_drift():
+    """A whole 13-step episode (max_depth) with the oracle running its OWN state - no re-synchronisation from the GPU between
+    steps: accumulated drift of the quantities north_star names (marker trajectories, joints, rewards) stays within 1e-4
+    relative per step early on and is reported for every step; integer counts stay inside the level-set band."""
+    A = 4
+    w = build_world(A=A, scene_kind="sdf", finetuning=False)
+    env, o = w["env"], w["oracle"]
+    env.set_candidates(env.valid_pairs[:A].reshape(A, 1, 2, 3))
+    env.reset()
+    _sync_oracle_from_gpu(w)            # common start; from here on the two sides never exchange state
+    g = torch.Generator().manual_seed(17)
+    rows = []
+    for it in range(13):
+        z = torch.randn(A, 128, generator=g) * 0.7
+        obs, rew, term = env.step(z.cuda(), auto_reset=False)
+        oobs, orew, oterm = o.step(z)
+        L = o.last
+        e_mk = max_abs(env.Y_gen.cpu(), L["Y_gen"])
+        e_jt = max_abs(env.joints.reshape(A, 20, -1, 3).cpu(), L["joints"])
+        e_st = max_abs(env.state.cpu(), o.state)
+        near = L["pene_near_zero"]
+        dcnt = (env.pene_count.reshape(A, 20).cpu().long() - L["pene_count"]).abs()
+        e_rw = float((rew.cpu().double() - orew.double()).abs().max())
+        rows.append((it, e_mk, e_jt, e_st, e_rw, int(dcnt.max()), int(near.max())))
+        assert term.cpu().bool().tolist() == oterm.tolist(), f"termination differs at step {it}"
+        # markers / joints are metre-scale values with magnitudes up to ~10 m after a dozen primitives
+        scale = max(1.0, float(L["joints"].abs().max()))
+        assert e_mk <= 1e-4 * max(1.0, float(L["Y_gen"].abs().max())) * (1 + it), (it, e_mk)
+        assert e_jt <= 1e-4 * scale * (1 + it), (it, e_jt)
+    print("\nstep  |dY_gen|   |djoints|  |dstate|   |dreward|  max|dcount|  near-zero")
+    for r in rows:
+        print("%4d  %.2e  %.2e  %.2e  %.2e  %6d  %6d" % r)
+    # drift does not explode over the episode
+    assert rows[-1][1] < 2e-3 and rows[-1][2] < 2e-3

@@ -239,3 +239,82 @@ def test_bad_arguments_raise():
         h.forward(torch.zeros(0, 93, device="cuda"), torch.zeros(0, 10, device="cuda"), 1)
     with pytest.raises(ValueError):
         h.forward(torch.zeros(5, 93, device="cuda"), torch.zeros(2, 10, device="cuda"), 2)
+
+
+def _dense_weights_model(V, seed, nnz_lo, nnz_hi):
+    """Synthetic body whose skinning weights have nnz_lo..nnz_hi non-zeros per vertex (the released SMPL-X weights reach 8-16
+    around the torso / hands; synth.make_body_model is exactly 4-nnz) spread over distant joints, so tile joint lists get long."""
+    bm = synth.make_body_model(seed, num_verts=V)
+    rng = np.random.default_rng(seed + 91)
+    W = np.zeros((V, 55), np.float32)
+    for v in range(V):
+        k = int(rng.integers(nnz_lo, nnz_hi + 1))
+        idx = rng.choice(55, size=k, replace=False)
+        W[v, idx] = rng.dirichlet(np.ones(k)).astype(np.float32)
+    W /= W.sum(1, keepdims=True)
+    bm = dict(bm)
+    bm["lbs_weights"] = W
+    return bm
+
+
+@pytest.mark.parametrize("nnz", [(8, 16), (20, 55)])
+def test_lbs_long_joint_lists(nnz, blend_mode):
+    """8-16 (and up to all 55) skinning weights per vertex: the per-tile joint list of the epilogue runs to its full length
+    (55 joints), which the 4-nnz synthetic body never exercises."""
+    from egogen_amd.body_model import BodyModelHandle, SdfScene
+    from oracle.sdf import calc_sdf
+    from oracle.smplx_lbs import BodyModel, smplx_forward
+    V, A, T = 1500, 9, 4
+    bm = _dense_weights_model(V, 3, *nnz)
+    mk, feet = synth.marker_ids(V), synth.feet_vids(V)
+    h, ob = BodyModelHandle(bm, mk, feet), BodyModel(bm)
+    assert h.nnz >= nnz[0]
+    xb, betas = _poses(A, T, seed=77)
+    xb[:, 2] = 0.1
+    scene = synth.make_sdf_scene(32)
+    out = h.forward(xb.cuda(), betas.cuda(), T, want_verts=True, sdf=SdfScene(scene))
+    out2 = h.forward(xb.cuda(), betas.cuda(), T, want_verts=False, sdf=SdfScene(scene))
+    torch.cuda.synchronize()
+    v, j = smplx_forward(ob, xb, betas.repeat_interleave(T, 0))
+    assert max_abs(out["vertices"].cpu(), v) < 2e-5
+    assert max_abs(out["joints"].cpu(), j) < 2e-5 and max_abs(out2["joints"].cpu(), j) < 2e-5
+    assert max_abs(out2["markers"].cpu(), v[:, torch.as_tensor(mk).long()]) < 2e-5
+    sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
+    s = calc_sdf(v, sd)
+    s[:, torch.as_tensor(feet).long()] = 1.0
+    ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
+    for o_ in (out, out2):
+        assert ((o_["pene_count"].cpu().long() - ref).abs() <= near).all()
+
+
+def test_lbs_full_size_many_body_groups_vs_oracle(blend_mode):
+    """V = 10475 with 2400 bodies = 10 body groups (>= 8: XCD-partitioned, L2-blocked item order with a ragged last group)
+    against the ORACLE (not a self-comparison): joints, markers and the fused SDF counts of every body.  The oracle runs in
+    chunks to bound host memory."""
+    from egogen_amd.body_model import SdfScene
+    from oracle.sdf import calc_sdf
+    from oracle.smplx_lbs import smplx_forward
+    V, A, T = 10475, 120, 20
+    bm, mk, feet, h, ob = _setup(V)
+    xb, betas = _poses(A, T, seed=2400)
+    xb[:, 2] = 0.3
+    scene = synth.make_sdf_scene(48)
+    out = h.forward(xb.cuda(), betas.cuda(), T, sdf=SdfScene(scene))
+    torch.cuda.synchronize()
+    sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
+    mkl, ftl = torch.as_tensor(mk).long(), torch.as_tensor(feet).long()
+    betas_rows = betas.repeat_interleave(T, 0)
+    worst_j = worst_m = 0.0
+    got = out["pene_count"].cpu().long()
+    any_pene = 0
+    for s0 in range(0, A * T, 200):
+        v, j = smplx_forward(ob, xb[s0:s0 + 200], betas_rows[s0:s0 + 200])
+        worst_j = max(worst_j, max_abs(out["joints"][s0:s0 + 200].cpu(), j))
+        worst_m = max(worst_m, max_abs(out["markers"][s0:s0 + 200].cpu(), v[:, mkl]))
+        s = calc_sdf(v, sd)
+        s[:, ftl] = 1.0
+        ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
+        any_pene = max(any_pene, int(ref.max()))
+        assert ((got[s0:s0 + 200] - ref).abs() <= near).all(), (s0, (got[s0:s0 + 200] - ref).abs().max())
+    assert worst_j < 2e-5 and worst_m < 2e-5, (worst_j, worst_m)
+    assert any_pene > 50

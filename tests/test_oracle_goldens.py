@@ -1,6 +1,9 @@
 """Pin the CPU oracle against vectors produced by the reference's own code
 (scripts/gen_goldens.py imported the reference classes in the build container)."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from oracle import nets, rot, sdf
@@ -72,3 +75,75 @@ def test_angle_axis_to_rotation_matrix_matches_in_tree_copy():
     R = rot.tgm_angle_axis_to_rotation_matrix(torch.from_numpy(g["aa"]))
     assert max_abs(R.numpy(), g["R"]) < 1e-6
     # and the HIP-side convention (egx_tgm_aa_to_rotmat mirrors the same function) is covered by tests/test_env_gpu.py
+
+
+def test_get_feature_and_blend_params_match_reference():
+    """oracle.env.get_feature / blend_params against crowd_env_2f.CrowdEnv._get_feature / _blend_params run unbound
+    (scripts/gen_goldens.py); the fixture holds a marker and a pelvis exactly on the target (the clip(min=1e-12) branch)."""
+    from oracle import env as oenv
+    g = load_golden("feature_ref.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    nb = g["pel"].shape[0]
+    outs = oenv.get_feature(t("Y_l"), t("pel"), t("R0"), t("T0"), t("wpath")[None].repeat(nb, 1, 1))
+    for o, k in zip(outs, ("dist_xy", "dist_xyz", "fea_wpath", "fea_marker_3d_n", "fea_marker_h")):
+        assert max_abs(o.numpy(), g[k]) == 0.0, k
+    assert float(g["dist_xyz"].min()) == pytest.approx(1e-12)
+    out = oenv.blend_params(t("blend_in").clone(), 2)
+    assert max_abs(out.numpy(), g["blend_out"]) == 0.0
+    assert max_abs(out.numpy()[:, :, :6], g["blend_in"][:, :, :6]) == 0.0
+
+
+def test_get_map_matches_reference():
+    """oracle.env.get_map against batch_gen_amass.get_map and the box env's _get_feature map tail (crowd_env_2f_box.py:762-770),
+    frames placed on the obstacle's edges / the floor's border so that both map values occur."""
+    from oracle import env as oenv
+    g = load_golden("getmap_ref.npz")
+    pts, ps, inside = oenv.get_map(torch.from_numpy(g["tris"]), torch.from_numpy(g["R"]), torch.from_numpy(g["T"]), 16, 0.8,
+                                   float(g["floor_height"]))
+    assert max_abs(pts.numpy(), g["points"]) == 0.0
+    assert max_abs(ps.numpy(), g["points_scene"]) < 1e-6
+    assert np.array_equal(inside.numpy(), g["map"])
+    assert 0 < int(g["map"].sum()) < g["map"].size
+    assert np.array_equal(np.where(inside.numpy(), 1.0, -1.0), g["box_local_map"])
+    assert max_abs(pts.numpy(), g["box_points_local"]) == 0.0
+
+
+def _equal_tree(a, b, path=""):
+    assert type(a) is type(b), (path, type(a), type(b))
+    if isinstance(a, dict):
+        assert list(a.keys()) == list(b.keys()), (path, list(a.keys()), list(b.keys()))
+        for k in a:
+            _equal_tree(a[k], b[k], f"{path}/{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _equal_tree(x, y, f"{path}[{i}]")
+    elif isinstance(a, np.ndarray):
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), path
+    else:
+        assert a == b, path
+
+
+def test_save_rollout_results_matches_reference(tmp_path):
+    """egogen_amd.utils.save_rollout_results writes, for the same inputs, the very pickle payload the reference's
+    crowd_ppo/utils.py::save_rollout_results wrote (tests/golden/rollout_ref.pkl): keys in the same order, same dtypes /
+    shapes / values (this is what vis.py and gen_egobody_* read)."""
+    import pickle
+    from egogen_amd.utils import save_rollout_results
+    from tests.helpers import GOLDEN
+    g = load_golden("rollout_ref.npz")
+    with open(os.path.join(GOLDEN, "rollout_ref.pkl"), "rb") as f:
+        ref = pickle.load(f)
+    mps = []
+    for i in range(int(g["n_mp"])):
+        t = lambda j: torch.from_numpy(g[f"mp{i}_{j}"])
+        mps.append([t(0), t(1), t(2), "male", t(4), t(5), t(6), "2-frame"])
+    scene = {"wpath": torch.from_numpy(g["wpath"]), "navmesh_path": ref["navmesh_path"], "scene_path": ref["scene_path"]}
+    path = save_rollout_results(scene, mps, str(tmp_path / "out"), man_id="ref")
+    assert os.path.basename(path) == "motion_ref.pkl"
+    with open(path, "rb") as f:
+        got = pickle.load(f)
+    _equal_tree(got, ref)
+    # the time-stamped name of the default call (utils.py:43-46)
+    p2 = save_rollout_results(scene, mps[:1], str(tmp_path / "out"))
+    assert os.path.basename(p2).startswith("motion_") and p2.endswith(".pkl") and p2 != path
