@@ -228,7 +228,10 @@ def cpu_baseline(args, scene):
         legs["sequential_32_threads"] = {"value": 1.0 / (seq_32 + upd_32), "threads": 32, "agent_steps": n_seq_32,
                                          "warmup": max(1, warm // 4), "ms_per_agent_step": seq_32 * 1e3,
                                          "update_ms_per_transition": upd_32 * 1e3}
-    return {"value": legs["sequential_all_threads"]["value"], "unit": "env-steps/s", "cores": n_all, "kind": "port",
+    # headline = the fastest sequential (reference-structured) leg: on a 128-core host the all-cores leg is SLOWER than 32
+    # threads (fork/join overhead on small tensors), and quoting it would flatter the GPU
+    best = max((k for k in legs if k.startswith("sequential")), key=lambda k: legs[k]["value"])
+    return {"value": legs[best]["value"], "unit": "env-steps/s", "cores": legs[best]["threads"], "kind": "port", "headline_leg": best,
             "host": {"os_cpu_count": logical, "lscpu_physical_cores": physical},
             "sample": f"oracle env (V={V}, scene={args.scene}) one agent at a time with the reference's x4-replicated batch: "
                       f"{n_seq_all} agent-steps after {warm} warm-up on {n_all} threads ({seq_all * 1e3:.0f} ms each) + the CPU PPO update "

@@ -84,7 +84,7 @@ def test_two_rank_graph_replayed_update_equals_single_process(tmp_path):
     big = RolloutBatch(n_steps, n_local * world, "cuda")
 
     def flat(b, name):
-        t = getattr(b, name)
+        t = getattr(b, name)[:b.n]        # observations hold n + 1 time rows (the one after the last step)
         return t.reshape((b.n * b.A,) + tuple(t.shape[2:]))
 
     order = []
