@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
                                                              float* __restrict__ feat,   // packed B operand (fp32 blend) or null
                                                              unsigned short* __restrict__ feat3,  // bf16x3 planes or null
                                                              f32x4* __restrict__ A4,     // [bt][55][3][32]
-                                                             float* __restrict__ out_joints, int joints_ld) {
+                                                             float* __restrict__ out_joints, int joints_ld,
+                                                             float template_lo_feat /* 1 in the two-plane blend mode */) {
   __shared__ float sR[4][NJ][9];
   __shared__ float sJ[4][NJ][3];
   __shared__ float sG[4][NJ][12];
@@ -182,8 +183,10 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
         const int k0 = 10 + egx_compact_joint(j) * 9;
         for (int e = 0; e < 9; ++e) feat_store(k0 + e, R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f));
       }
-      // column 469 multiplies the template column of the bases (acc = v_template + offsets); 470, 471 are padding
-      if (j >= 22 && j <= 24) feat_store(KACT + (j - 22), j == 22 ? 1.f : 0.f);
+      // column 469 multiplies the template column of the bases (acc = v_template + offsets); column 470 multiplies the
+      // third bf16 term of the template (bf16x3 bases only): switched on in the two-plane blend mode, where the product keeps
+      // 16 bits per operand - enough for the centimetre-scale offsets, not for the metre-scale template; 471 is padding
+      if (j >= 22 && j <= 24) feat_store(KACT + (j - 22), j == 22 ? 1.f : (j == 23 ? template_lo_feat : 0.f));
       if (feat3b && j >= 22 && j <= 24) {  // bf16x3 pads K to 480: columns 472..479
         for (int k = KDIM + (j - 22); k < KS3 * 16; k += 3) feat_store(k, 0.f);
       }
@@ -338,6 +341,16 @@ __device__ __forceinline__ int lbs_load_meta(const LbsParams& p, LbsWave& w, int
   return JT;
 }
 
+#ifdef EGX_LBS_TIMING
+// development build only (make CXXFLAGS+=-DEGX_LBS_TIMING): cycle totals of the phases of the bf16x3 stage loop
+__device__ unsigned long long g_lbs_t[16];
+#define LBS_T(i, v) do { tacc[i] += (unsigned long long)(v); } while (0)
+#define LBS_NOW() __builtin_readcyclecounter()
+#else
+#define LBS_T(i, v) do { } while (0)
+#define LBS_NOW() 0ull
+#endif
+
 // Epilogue of one work item: each lane owns 16 vertices (rows) x 2 bodies (column n of tiles bt0, bt0+1).
 template <bool WRITE_VERTS, bool DO_SDF, int RB, int QCAP>
 __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int JT) {
@@ -375,8 +388,12 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
   };
   const unsigned pick_mask = p.picked ? s_masks[0] : 0u;
   const unsigned sdf_mask = s_masks[1];
+#ifdef EGX_LBS_TIMING
+  unsigned long long et[4] = {0, 0, 0, 0};
+#endif
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
+    const unsigned long long q0 = LBS_NOW();
     const f32x4* Aq = p.A4 + (size_t)min(bt0 + q, num_bt - 1) * NJ * 3 * 32 + n;
     // rows are handled in adjacent pairs (r, r+1): the accumulator registers, weights and outputs of a pair are
     // neighbours, so the nine transform FMAs and three weight FMAs map onto packed fp32 instructions
@@ -421,17 +438,36 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
       o[r][1] = o2[r >> 1][1][r & 1] + tr[q][1];
       o[r][2] = o2[r >> 1][2][r & 1] + tr[q][2];
     }
+#ifdef EGX_LBS_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long q1 = LBS_NOW();
+    et[0] += q1 - q0;
+#endif
     if (DO_SDF) {
       // Bracket table first (eight independent 8-byte loads per batch).  A vertex the brackets cannot decide needs the
       // eight-corner interpolation; executed in place that would run for the whole wave whenever ONE lane needs it, and
       // with 64 different bodies across the lanes that is almost every row.  Undecided points are therefore appended
       // to a wave-private LDS queue and evaluated densely (64 queued points per pass) by sdf_flush().
       const int ag = (bvalid[q] ? body[q] : p.B - 1) / p.fpa;
-      float Rw[9], Tw[3];
+      // canonical frame -> world (R0, T0) -> unclamped voxel coordinates ((w - c) scale + 1) d / 2 - 1 / 2 folded into one
+      // affine map per body (align_corners=False, utils.py:58-68); the clamp (padding "border") happens in the lookup /
+      // before the exact evaluation.  The folded rounding differs from the reference's chain by ~1e-7 relative - far
+      // inside the level-set band the counts are compared in.
+      float Mw[9], tw[3];
+      {
+        const float kx = p.sdf.scale * (float)p.sdf.d0 * 0.5f, ky = p.sdf.scale * (float)p.sdf.d1 * 0.5f,
+                    kz = p.sdf.scale * (float)p.sdf.d2 * 0.5f;
+        const float kk[3] = {kx, ky, kz};
+        const float cc[3] = {p.sdf.cx, p.sdf.cy, p.sdf.cz};
+        const float dd[3] = {(float)p.sdf.d0, (float)p.sdf.d1, (float)p.sdf.d2};
 #pragma unroll
-      for (int e = 0; e < 9; ++e) Rw[e] = p.R0 ? p.R0[(size_t)ag * 9 + e] : ((e % 4 == 0) ? 1.f : 0.f);
+        for (int a = 0; a < 3; ++a) {
 #pragma unroll
-      for (int e = 0; e < 3; ++e) Tw[e] = p.T0 ? p.T0[(size_t)ag * 3 + e] : 0.f;
+          for (int e = 0; e < 3; ++e) Mw[a * 3 + e] = kk[a] * (p.R0 ? p.R0[(size_t)ag * 9 + a * 3 + e] : ((a == e) ? 1.f : 0.f));
+          tw[a] = kk[a] * ((p.T0 ? p.T0[(size_t)ag * 3 + a] : 0.f) - cc[a]) + (dd[a] - 1.f) * 0.5f;
+        }
+      }
+      const float hx = (float)(p.sdf.d0 - 1), hy = (float)(p.sdf.d1 - 1), hz = (float)(p.sdf.d2 - 1);
       const unsigned mine = bvalid[q] ? (sdf_mask >> (4 * half)) : 0u;  // bit (r&3)+8(r>>2) = this lane's row r
       int cnt = 0;
 #pragma unroll
@@ -441,22 +477,23 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
         if (qn + RB * 64 > QCAP) { sdf_flush(qn); qn = 0; }  // room for one batch: RB rows x 64 lanes
 #pragma unroll
         for (int r = r0; r < r0 + RB; ++r) {
-          const float wx = Rw[0] * o[r][0] + Rw[1] * o[r][1] + Rw[2] * o[r][2] + Tw[0];
-          const float wy = Rw[3] * o[r][0] + Rw[4] * o[r][1] + Rw[5] * o[r][2] + Tw[1];
-          const float wz = Rw[6] * o[r][0] + Rw[7] * o[r][1] + Rw[8] * o[r][2] + Tw[2];
-          egx_sdf_voxel_coords(p.sdf, wx, wy, wz, wp[r - r0][0], wp[r - r0][1], wp[r - r0][2]);  // clamped voxel coordinates
-          mm[r - r0] = (p.dbg & 32) ? float2{wx, wy} : egx_sdf_coarse_at(p.sdf, wp[r - r0][0], wp[r - r0][1], wp[r - r0][2]);
+          wp[r - r0][0] = fmaf(Mw[0], o[r][0], fmaf(Mw[1], o[r][1], fmaf(Mw[2], o[r][2], tw[0])));
+          wp[r - r0][1] = fmaf(Mw[3], o[r][0], fmaf(Mw[4], o[r][1], fmaf(Mw[5], o[r][2], tw[1])));
+          wp[r - r0][2] = fmaf(Mw[6], o[r][0], fmaf(Mw[7], o[r][1], fmaf(Mw[8], o[r][2], tw[2])));
+          mm[r - r0] = egx_sdf_coarse_at_raw(p.sdf, wp[r - r0][0], wp[r - r0][1], wp[r - r0][2]);
         }
 #pragma unroll
         for (int r = r0; r < r0 + RB; ++r) {
           const bool on = (mine >> ((r & 3) + 8 * (r >> 2))) & 1u;
           const bool inside = mm[r - r0].x > 0.f;
           cnt += (on && inside) ? 1 : 0;
-          const bool und = on && !inside && !(mm[r - r0].y < 0.f) && !(p.dbg & 16);
+          const bool und = on && !inside && !(mm[r - r0].y < 0.f);
           const unsigned long long bm = __ballot(und);
           if (bm != 0) {
             const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
-            if (und) s_queue[pos] = f32x4{wp[r - r0][0], wp[r - r0][1], wp[r - r0][2], __int_as_float(q * 32 + n)};
+            if (und)
+              s_queue[pos] = f32x4{__builtin_amdgcn_fmed3f(wp[r - r0][0], 0.f, hx), __builtin_amdgcn_fmed3f(wp[r - r0][1], 0.f, hy),
+                                   __builtin_amdgcn_fmed3f(wp[r - r0][2], 0.f, hz), __int_as_float(q * 32 + n)};
             qn += __popcll(bm);
           }
         }
@@ -464,6 +501,11 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
       if (cnt != 0) atomicAdd(&s_cnt[q * 32 + n], cnt);
       if (WRITE_VERTS) { sdf_flush(qn); qn = 0; }  // the queue shares its LDS with the vertex transpose buffer
     }
+#ifdef EGX_LBS_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long q2 = LBS_NOW();
+    et[1] += q2 - q1;
+#endif
     if (pick_mask != 0 && bvalid[q]) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -504,6 +546,9 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
       }
     }
   }
+#ifdef EGX_LBS_TIMING
+  const unsigned long long f0 = LBS_NOW();
+#endif
   if (DO_SDF) {
     if (!WRITE_VERTS) { sdf_flush(qn); qn = 0; }
     __builtin_amdgcn_wave_barrier();
@@ -513,6 +558,11 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
     if (c != 0 && bd < p.B) atomicAdd(p.pene + bd, c);
     __builtin_amdgcn_wave_barrier();
   }
+#ifdef EGX_LBS_TIMING
+  __builtin_amdgcn_sched_barrier(0);
+  et[2] += LBS_NOW() - f0;
+  if (lane == 0) { atomicAdd(&g_lbs_t[9], et[0]); atomicAdd(&g_lbs_t[10], et[1]); atomicAdd(&g_lbs_t[11], et[2]); atomicAdd(&g_lbs_t[12], 1ull); }
+#endif
   w.qn = qn;
 }
 
@@ -638,74 +688,77 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
 // second workgroup of the CU covers the gap, and - unlike the fp32 MFMA, which shares the fp32 VALU lanes - the bf16
 // matrix pipe runs concurrently with the other workgroup's VALU epilogue.
 // ------------------------------------------------------------------------------------------------
-constexpr int LBS3_STAGE_KS = 2;
-constexpr int LBS3_STAGE_PIECES = LBS3_STAGE_KS * 9;
-constexpr int LBS3_STAGES = KS3 / LBS3_STAGE_KS;
-constexpr int LBS3_SHARED_BYTES = 2 * LBS3_STAGE_PIECES * 1024 + 7424;  // stage ring + tile metadata
+template <int NPL>
+struct Wg4Cfg {
+  static constexpr int STAGE_KS = NPL == 3 ? 2 : 3;          // k-steps per stage: 72 / 54 MFMAs per wave and stage
+  static constexpr int STAGE_PIECES = STAGE_KS * NPL * 3;    // 1 KiB base pieces per stage
+  static constexpr int STAGES = KS3 / STAGE_KS;
+  static_assert(KS3 % STAGE_KS == 0, "stages cover K exactly");
+};
+constexpr int LBS3_SHARED_BYTES = 2 * 18 * 1024 + 7424;                // stage ring (18 pieces in either mode) + tile metadata
+static_assert(Wg4Cfg<3>::STAGE_PIECES <= 18 && Wg4Cfg<2>::STAGE_PIECES <= 18, "stage ring");
 constexpr int LBS3_RB = 4;                                             // SDF rows per bracket batch
 constexpr int LBS3_QCAP = LBS3_RB * 64 + 64;
 constexpr int LBS3_WAVE_BYTES = 256 + LBS3_QCAP * 16;                  // s_cnt + queue
-static_assert(KS3 % LBS3_STAGE_KS == 0, "stages cover K exactly");
 
-#ifdef EGX_LBS_TIMING
-// development build only (make CXXFLAGS+=-DEGX_LBS_TIMING): cycle totals of the phases of the bf16x3 stage loop
-__device__ unsigned long long g_lbs_t[8];
-#define LBS_T(i, v) do { tacc[i] += (unsigned long long)(v); } while (0)
-#define LBS_NOW() __builtin_readcyclecounter()
-#else
-#define LBS_T(i, v) do { } while (0)
-#define LBS_NOW() 0ull
-#endif
-
-__device__ __forceinline__ void lbs_blend_bf16x3(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave,
-                                                 bf16x8* sA, unsigned long long* tacc) {
-  constexpr int NB = LBS_NB;
+template <int NPL>
+__device__ __forceinline__ void lbs_blend_split(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave,
+                                                bf16x8* sA, unsigned long long* tacc) {
+  using Cfg = Wg4Cfg<NPL>;
+  constexpr int NB = LBS_NB, SKS = Cfg::STAGE_KS, SP = Cfg::STAGE_PIECES;
   const int num_bt = (p.B + 31) >> 5;
   const bf16x8* dpv = p.dirs3 + (size_t)vt * KS3 * 9 * 64 + lane;  // piece (s, plane, coord) at ((s*3 + plane)*3 + coord)*64
   const bf16x8* fq[NB];
 #pragma unroll
   for (int q = 0; q < NB; ++q) fq[q] = p.feat3 + (size_t)min(bt0 + q, num_bt - 1) * KS3 * 3 * 64 + lane;
-  for (int st = 0; st < LBS3_STAGES; ++st) {
+  for (int st = 0; st < Cfg::STAGES; ++st) {
     // burst: this wave's share of the stage's base pieces + its own feature pieces
-    constexpr int NGA = (LBS3_STAGE_PIECES + 3) / 4;
-    bf16x8 ga[NGA], b[LBS3_STAGE_KS][3][NB];
+    constexpr int NGA = (SP + 3) / 4;
+    bf16x8 ga[NGA], b[SKS][NPL][NB];
     const unsigned long long t0 = LBS_NOW();
 #pragma unroll
     for (int i = 0; i < NGA; ++i) {
-      const int piece = wave + 4 * i;
-      if (piece < LBS3_STAGE_PIECES) ga[i] = dpv[(size_t)(st * LBS3_STAGE_PIECES + piece) * 64];
+      const int piece = wave + 4 * i;                 // (ks, plane, coord) of the stage, planes 0..NPL-1 only
+      if (piece < SP) ga[i] = dpv[(size_t)((st * SKS + piece / (NPL * 3)) * 9 + piece % (NPL * 3)) * 64];
     }
 #pragma unroll
-    for (int ks = 0; ks < LBS3_STAGE_KS; ++ks)
+    for (int ks = 0; ks < SKS; ++ks)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-        for (int q = 0; q < NB; ++q) b[ks][pl][q] = fq[q][((st * LBS3_STAGE_KS + ks) * 3 + pl) * 64];
+        for (int q = 0; q < NB; ++q) b[ks][pl][q] = fq[q][((st * SKS + ks) * 3 + pl) * 64];
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long t1 = LBS_NOW();
-    bf16x8* buf = sA + (st & 1) * LBS3_STAGE_PIECES * 64;
+    bf16x8* buf = sA + (st & 1) * 18 * 64;
 #pragma unroll
     for (int i = 0; i < NGA; ++i) {
       const int piece = wave + 4 * i;
-      if (piece < LBS3_STAGE_PIECES) buf[piece * 64 + lane] = ga[i];
+      if (piece < SP) buf[piece * 64 + lane] = ga[i];
     }
     __syncthreads();  // stage visible; also: everyone is done reading the other buffer's previous contents
     const unsigned long long t2 = LBS_NOW();
 #pragma unroll
-    for (int ks = 0; ks < LBS3_STAGE_KS; ++ks) {
-      bf16x8 a[3][3];  // [plane][coord]
+    for (int ks = 0; ks < SKS; ++ks) {
+      bf16x8 a[NPL][3];  // [plane][coord]
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a[pl][c] = buf[(ks * 9 + pl * 3 + c) * 64 + lane];
-      // product-major order: consecutive MFMAs go to the six different accumulator tuples, so no MFMA waits for the
-      // previous one's result (small partial products first)
+        for (int c = 0; c < 3; ++c) a[pl][c] = buf[((ks * NPL + pl) * 3 + c) * 64 + lane];
+      // product-major order: consecutive MFMAs go to different accumulator tuples, so no MFMA waits for the previous
+      // one's result (small partial products first)
+      constexpr int NPROD = NPL == 3 ? 6 : 3;
 #pragma unroll
-      for (int pr = 0; pr < 6; ++pr) {
-        const int pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
-        const int pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
+      for (int pr = 0; pr < NPROD; ++pr) {
+        int pa, pb;
+        if (NPL == 3) {
+          pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
+          pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
+        } else {
+          pa = (pr == 0) ? 0 : (pr == 1) ? 1 : 0;
+          pb = (pr == 0) ? 1 : (pr == 1) ? 0 : 0;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -723,13 +776,13 @@ __device__ __forceinline__ void lbs_blend_bf16x3(const LbsParams& p, f32x16 (&ac
   }
 }
 
-template <bool DO_SDF>
+template <int NPL, bool DO_SDF>
 __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
   constexpr int NB = LBS_NB;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   bf16x8* sA = reinterpret_cast<bf16x8*>(smem_raw);
-  char* meta = smem_raw + 2 * LBS3_STAGE_PIECES * 1024;
+  char* meta = smem_raw + 2 * 18 * 1024;
   char* my = smem_raw + LBS3_SHARED_BYTES + wave * LBS3_WAVE_BYTES;
   LbsWave w;
   w.lane = lane; w.n = lane & 31; w.half = lane >> 5;
@@ -786,7 +839,7 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
       for (int q = 0; q < NB; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
-    if (!(p.dbg & 2)) lbs_blend_bf16x3(p, acc, vt, bt0, lane, wave, sA, tacc);
+    if (!(p.dbg & 2)) lbs_blend_split<NPL>(p, acc, vt, bt0, lane, wave, sA, tacc);
     else __syncthreads();  // the blend's barriers also publish the metadata
     if (p.dbg & 1) {
       float sum = 0.f;
@@ -928,6 +981,11 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
               val = d->posedirs_host[(size_t)((j - 1) * 9 + e9) * 3 * V + (size_t)v * 3 + c];
             } else if (k == KACT) {
               val = d->v_template_host[(size_t)v * 3 + c];
+            } else if (k == KACT + 1) {  // what two bf16 terms of the template leave over (feature 470 selects it)
+              const float t = d->v_template_host[(size_t)v * 3 + c];
+              unsigned short ht[3];
+              egx_bf16_split3(t, ht);
+              val = (t - egx_bf16_to_f32(ht[0])) - egx_bf16_to_f32(ht[1]);
             }
             unsigned short h[3];
             egx_bf16_split3(val, h);
@@ -1055,13 +1113,21 @@ extern "C" int egx_body_model_num_verts(const egx_body_model* m) { return m ? m-
 extern "C" int egx_body_model_nnz(const egx_body_model* m) { return m ? m->NW : 0; }
 
 namespace {
-// blend mode of the fused kernel: 0 = fp32 MFMA, 1 = 3-term bf16 split (default); vertex-writing calls always use 0
+constexpr int kMaxDevices = 64;
+struct LbsDeviceInfo {
+  std::mutex mu;
+  int num_cu = 0;
+};
+LbsDeviceInfo g_lbs_dev[kMaxDevices];
+// blend mode of the fused kernel: 0 = fp32 MFMA, 1 = 3-term bf16 split, 2 = 2-term bf16 split (default); vertex-writing
+// calls always use 0
 std::atomic<int> g_blend_mode{-1};
 int blend_mode() {
   int m = g_blend_mode.load();
   if (m < 0) {
     const char* e = getenv("EGX_LBS_BLEND");
-    m = (e && (std::string(e) == "f32" || std::string(e) == "0")) ? 0 : 1;
+    const std::string v = e ? e : "";
+    m = (v == "f32" || v == "0") ? 0 : ((v == "bf16x3" || v == "1") ? 1 : 2);
     g_blend_mode.store(m);
   }
   return m;
@@ -1081,10 +1147,10 @@ WsLayout ws_layout(const egx_body_model* m, int B) {
 }  // namespace
 
 #ifdef EGX_LBS_TIMING
-extern "C" int egx_lbs_timing_read(unsigned long long* out8, int reset) {
-  EGX_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lbs_t), 8 * sizeof(unsigned long long)));
+extern "C" int egx_lbs_timing_read(unsigned long long* out16, int reset) {
+  EGX_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lbs_t), 16 * sizeof(unsigned long long)));
   if (reset) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[16] = {0};
     EGX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lbs_t), z, sizeof(z)));
   }
   return EGX_OK;
@@ -1092,7 +1158,7 @@ extern "C" int egx_lbs_timing_read(unsigned long long* out8, int reset) {
 #endif
 
 extern "C" int egx_lbs_set_blend_mode(int mode) {
-  EGX_REQUIRE(mode == 0 || mode == 1, "blend mode must be 0 (fp32 MFMA) or 1 (bf16x3 split)");
+  EGX_REQUIRE(mode >= 0 && mode <= 2, "blend mode must be 0 (fp32 MFMA), 1 (bf16x3 split) or 2 (bf16x2 split)");
   g_blend_mode.store(mode);
   return EGX_OK;
 }
@@ -1115,7 +1181,7 @@ extern "C" int egx_lbs_joints(const egx_body_model* m, const float* xb, const fl
   char* ws = static_cast<char*>(workspace);
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream_), m->pc, xb,
                      betas, B, fpa, static_cast<float*>(nullptr), static_cast<unsigned short*>(nullptr),
-                     reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ);
+                     reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ, 0.f);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
@@ -1141,10 +1207,10 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   const bool need_picks = out_joints || out_markers;
   float* picked = need_picks ? reinterpret_cast<float*>(ws + wl.picked) : nullptr;
 
-  const bool split3 = blend_mode() == 1 && !out_verts;
+  const bool split3 = blend_mode() >= 1 && !out_verts;
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, stream, m->pc, xb, betas, B, fpa,
                      split3 ? nullptr : feat, split3 ? reinterpret_cast<unsigned short*>(feat) : nullptr, A4, out_joints,
-                     EGX_NUM_JOINTS_OUT);
+                     EGX_NUM_JOINTS_OUT, (split3 && blend_mode() == 2) ? 1.f : 0.f);
   if (out_verts || need_picks || sdf) {
     LbsParams p;
     p.dirs = m->dirs; p.tj_off = m->tj_off; p.tj_idx = m->tj_idx; p.tj_w = m->tj_w; p.pick_slot = m->pick_slot;
@@ -1170,25 +1236,32 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
       p.sdf.c0 = egx_ceil_div(sdf->d0, 4); p.sdf.c1 = egx_ceil_div(sdf->d1, 4); p.sdf.c2 = egx_ceil_div(sdf->d2, 4);
       EGX_HIP_CHECK(hipMemsetAsync(out_pene_count, 0, (size_t)B * sizeof(int32_t), stream));
     }
-    // one persistent workgroup per CU (8 waves = 2 per SIMD); the attribute raises the dynamic-LDS cap once
-    static int num_cu = 0;
+    // one persistent workgroup per CU; per-device launch facts (CU count, raised dynamic-LDS caps) are set up once per device
     constexpr size_t lds_meta = (size_t)8 * LBS_META_BYTES, lds_verts = (size_t)8 * (LBS_META_BYTES + LBS_VERT_BYTES),
                      lds_sdf = (size_t)8 * (LBS_META_BYTES + LBS_QCAP * 16);
-    if (num_cu == 0) {
-      hipDeviceProp_t prop;
-      int dev = 0;
-      EGX_HIP_CHECK(hipGetDevice(&dev));
-      EGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_verts));
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<true, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_verts));
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sdf));
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<false, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_meta));
-      num_cu = prop.multiProcessorCount;
+    int dev = 0;
+    EGX_HIP_CHECK(hipGetDevice(&dev));
+    EGX_REQUIRE(dev >= 0 && dev < kMaxDevices, "device ordinal out of range");
+    LbsDeviceInfo& di = g_lbs_dev[dev];
+    {
+      std::lock_guard<std::mutex> lk(di.mu);
+      if (di.num_cu == 0) {
+        hipDeviceProp_t prop;
+        EGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        auto raise = [](const void* fn, size_t bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<true, true>), lds_verts));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<true, false>), lds_verts));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<false, true>), lds_sdf));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<false, false>), lds_meta));
+        constexpr size_t lds3a = (size_t)LBS3_SHARED_BYTES + 4 * LBS3_WAVE_BYTES;
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<3, true>), lds3a));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<3, false>), lds3a));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<2, true>), lds3a));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<2, false>), lds3a));
+        di.num_cu = prop.multiProcessorCount;
+      }
     }
+    const int num_cu = di.num_cu;
     p.bg_block = 2;
 #ifdef EGX_LBS_DEVELOPMENT
     if (const char* e = getenv("EGX_LBS_BG_BLOCK")) p.bg_block = atoi(e);
@@ -1200,20 +1273,17 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) EGX_HIP_CHECK(hipEventRecord(ev0, stream));
     if (split3) {
-      static bool attr3 = false;
+      // two persistent 4-wave workgroups per CU: one's VALU epilogue runs under the other's MFMA stages
+      const int mode = blend_mode();
       constexpr size_t lds3 = (size_t)LBS3_SHARED_BYTES + 4 * LBS3_WAVE_BYTES;
-      if (!attr3) {
-        EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-        EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-        attr3 = true;
+      const int grid3 = std::max(1, std::min(2 * num_cu, n_items));
+      if (mode == 2) {
+        if (sdf) hipLaunchKernelGGL((egx_lbs_fused3_kernel<2, true>), dim3(grid3), dim3(256), lds3, stream, p);
+        else hipLaunchKernelGGL((egx_lbs_fused3_kernel<2, false>), dim3(grid3), dim3(256), lds3, stream, p);
+      } else {
+        if (sdf) hipLaunchKernelGGL((egx_lbs_fused3_kernel<3, true>), dim3(grid3), dim3(256), lds3, stream, p);
+        else hipLaunchKernelGGL((egx_lbs_fused3_kernel<3, false>), dim3(grid3), dim3(256), lds3, stream, p);
       }
-      const int grid3 = std::max(1, std::min(((p.dbg & 64) ? 1 : 2) * num_cu, n_items));  // two persistent 4-wave workgroups per CU
-      if (sdf)
-        hipLaunchKernelGGL((egx_lbs_fused3_kernel<true>), dim3(grid3), dim3(256), lds3, stream, p);
-      else
-        hipLaunchKernelGGL((egx_lbs_fused3_kernel<false>), dim3(grid3), dim3(256), lds3, stream, p);
     } else if (out_verts && sdf)
       hipLaunchKernelGGL((egx_lbs_fused_kernel<true, true>), dim3(grid), dim3(LBS_THREADS), lds, stream, p);
     else if (out_verts)

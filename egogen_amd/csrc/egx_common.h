@@ -52,7 +52,7 @@ struct SdfDev {
   const float* grid;
   int d0, d1, d2;
   float cx, cy, cz, scale;
-  const float2* coarse;  // optional [c0][c1][c2] {min,max} of the fine values each 4^3 block's samples can touch
+  const float2* coarse;  // optional padded bracket table [(c0+2)][(c1+2)][(c2+2)] {min,max} (egx_sdf_build_coarse)
   int c0, c1, c2;
 };
 
@@ -73,21 +73,15 @@ __device__ __forceinline__ void egx_sdf_voxel_coords(const SdfDev& s, float x, f
   pz = fminf(fmaxf(pz, 0.f), (float)(s.d2 - 1));
 }
 
-// {min,max} bracket of the samples the interpolation at clamped voxel coordinates (px,py,pz) can touch: the 4^3 block's
-// footprint, or - for a point clamped onto the first / last sample plane of an axis (outside the cube or exactly on that
-// plane: the neighbouring layer has weight exactly 0 or is dropped) - the footprint inside that single layer (face tables
-// behind the block table, sdf.hip).  See egx_sdf_coarse_sign.
-__device__ __forceinline__ float2 egx_sdf_coarse_at(const SdfDev& s, float px, float py, float pz) {
-  // clamped to [0, d-1]: truncation is floor; 32-bit index keeps the address arithmetic off the 64-bit VALU paths
-  const unsigned ix = (unsigned)px >> 2, iy = (unsigned)py >> 2, iz = (unsigned)pz >> 2;
-  const unsigned c0 = (unsigned)s.c0, c1 = (unsigned)s.c1, c2 = (unsigned)s.c2;
-  const unsigned n_blk = c0 * c1 * c2, n_x = c1 * c2, n_y = c0 * c2, n_z = c0 * c1;
-  const bool xl = px == 0.f, xh = px == (float)(s.d0 - 1), yl = py == 0.f, yh = py == (float)(s.d1 - 1),
-             zl = pz == 0.f, zh = pz == (float)(s.d2 - 1);
-  unsigned idx = (ix * c1 + iy) * c2 + iz;
-  if (xl | xh) idx = n_blk + (xh ? n_x : 0u) + iy * c2 + iz;
-  if (yl | yh) idx = n_blk + 2u * n_x + (yh ? n_y : 0u) + ix * c2 + iz;
-  if (zl | zh) idx = n_blk + 2u * n_x + 2u * n_y + (zh ? n_z : 0u) + ix * c1 + iy;
+// {min,max} bracket of the samples the interpolation can touch for a point with UNCLAMPED voxel coordinates (rx,ry,rz):
+// entry (jx,jy,jz) of the padded table built by egx_sdf_build_coarse (sdf.hip), j = clamp(floor(r / 4) + 1, 0, c + 1).
+// A coordinate within round-off of a cell border may land in the neighbouring cell; both cells' footprints contain the
+// samples such a point touches (block footprints include their border planes), so the bracket stays valid.
+__device__ __forceinline__ float2 egx_sdf_coarse_at_raw(const SdfDev& s, float rx, float ry, float rz) {
+  const float jx = __builtin_amdgcn_fmed3f(floorf(fmaf(rx, 0.25f, 1.f)), 0.f, (float)(s.c0 + 1));
+  const float jy = __builtin_amdgcn_fmed3f(floorf(fmaf(ry, 0.25f, 1.f)), 0.f, (float)(s.c1 + 1));
+  const float jz = __builtin_amdgcn_fmed3f(floorf(fmaf(rz, 0.25f, 1.f)), 0.f, (float)(s.c2 + 1));
+  const unsigned idx = ((unsigned)jx * (unsigned)(s.c1 + 2) + (unsigned)jy) * (unsigned)(s.c2 + 2) + (unsigned)jz;
   return s.coarse[idx];
 }
 
@@ -128,21 +122,6 @@ __device__ __forceinline__ float egx_sdf_neg_trilinear(const SdfDev& s, float x,
   float px, py, pz;
   egx_sdf_voxel_coords(s, x, y, z, px, py, pz);
   return egx_sdf_neg_trilinear_at(s, px, py, pz);
-}
-
-__device__ __forceinline__ float2 egx_sdf_coarse_fetch(const SdfDev& s, float x, float y, float z) {
-  float px, py, pz;
-  egx_sdf_voxel_coords(s, x, y, z, px, py, pz);
-  return egx_sdf_coarse_at(s, px, py, pz);
-}
-
-// Sign of calc_sdf at a point without touching the fine grid when the coarse {min,max} brackets decide it:
-// trilinear interpolation is a convex combination of the 8 corners, so if every value the footprint can touch is
-// negative (free space) the result is negative and -result > 0: not penetrating; if all are positive: penetrating.
-// Returns -1 (not penetrating), +1 (penetrating) or 0 (mixed: evaluate the fine grid).  Exact, not an approximation.
-__device__ __forceinline__ int egx_sdf_coarse_sign(const SdfDev& s, float x, float y, float z) {
-  const float2 mm = egx_sdf_coarse_fetch(s, x, y, z);
-  return (mm.y < 0.f) ? -1 : ((mm.x > 0.f) ? 1 : 0);
 }
 
 // ---- rotation helpers shared with the env kernels (torchgeometry 0.1.2 semantics) ----

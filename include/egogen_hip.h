@@ -90,11 +90,15 @@ int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream
 
 /* Bytes of scratch egx_lbs_forward needs for `num_bodies` bodies. */
 /* Blend-GEMM arithmetic of egx_lbs_forward calls that do not write full vertices (process-wide switch; the environment
- * variable EGX_LBS_BLEND=f32 selects mode 0 at first use):
- *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ * variable EGX_LBS_BLEND=f32|bf16x3|bf16x2 selects it at first use):
+ *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32); always used when vertices are written
  *   1  3-term bf16 split of both operands, six partial products per fp32 product on v_mfma_f32_32x32x16_bf16 with fp32
- *      accumulation: same 2^-24-level accuracy as mode 0 (tests/test_lbs_gpu.py holds both to the same tolerances) at a
- *      third of the matrix-pipe time.  Default.
+ *      accumulation: 2^-24-level accuracy (indistinguishable from mode 0) at a third of the matrix-pipe time
+ *   2  2-term bf16 split, three partial products (hi.hi + hi.mid + mid.hi: 16 significant bits per operand) - and a third
+ *      term for the template column, carried by a padding column of K - at a sixth of the matrix-pipe time.  Default: the
+ *      offsets it rounds are centimetres, so vertices move by <= 1.1e-6 m against the float64 oracle (mode 0: 3.7e-7) and
+ *      the fused penetration counts do not change (tests/test_lbs_gpu.py::test_lbs_blend_mode_accuracy_report); all three
+ *      modes are held to the same parity tolerances (north_star: 1e-4 relative).
  * (No reference counterpart: smplx evaluates the blend shapes as fp32 einsum/matmul, lbs.py [upstream smplx 0.1.28].) */
 int egx_lbs_set_blend_mode(int mode);
 int egx_lbs_get_blend_mode(void);

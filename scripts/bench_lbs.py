@@ -10,7 +10,10 @@ from egogen_amd.body_model import BodyModelHandle, SdfScene
 bm = synth.make_body_model(0)
 h = BodyModelHandle(bm, synth.marker_ids(), synth.feet_vids())
 scene = SdfScene(synth.make_sdf_scene(256))
-for A in (64, 512):
+lib0 = _lib.load()
+modes = [int(m) for m in os.environ.get("EGX_BENCH_MODES", "1,2,0").split(",")]
+for mode, A in [(m, a) for m in modes for a in (64, 512)]:
+    lib0.egx_lbs_set_blend_mode(mode)
     T = 20
     B = A * T
     g = torch.Generator().manual_seed(0)
@@ -43,5 +46,5 @@ for A in (64, 512):
             lib.egx_event_destroy(k0); lib.egx_event_destroy(k1)
         kms = min(kms)
         flops = B * 31425 * 469 * 2
-        print(f"A={A} B={B} {name:10s} {ms:8.3f} ms (fused kernel {kms:6.3f} ms = {flops/kms/1e9:6.1f} TF)  blend {flops/ms/1e9:7.1f} TFLOP/s  "
+        print(f"mode={mode} A={A} B={B} {name:10s} {ms:8.3f} ms (fused kernel {kms:6.3f} ms = {flops/kms/1e9:6.1f} TF)  blend {flops/ms/1e9:7.1f} TFLOP/s  "
               f"{'verts %.1f GB/s' % (B*10475*12/ms/1e6) if 'verts' in name else ''}", flush=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Development aid: per-stage cycle breakdown of the bf16x3 blend loop (needs a library built with -DEGX_LBS_TIMING,
-path in EGX_LIB)."""
+"""Development aid: per-slot cycle breakdown of the team-pipelined blend kernel (needs a library built with
+-DEGX_LBS_TIMING: `make -C egogen_amd/csrc -B CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -DEGX_LBS_TIMING"`)."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -15,15 +15,23 @@ g = torch.Generator().manual_seed(0)
 xb = (torch.randn(A * T, 93, generator=g) * 0.2).cuda(); xb[:, 2] += 1
 betas = torch.randn(A, 10, generator=g).cuda()
 R0 = torch.eye(3).repeat(A, 1, 1).cuda(); T0 = (torch.rand(A, 3, generator=g) * 2 - 1).cuda(); T0[:, 2] = 0
-out = {}
-for _ in range(3):
-    h.forward(xb, betas, T, out=out, sdf=scene, R0=R0, T0=T0)
-torch.cuda.synchronize()
-buf = (C.c_ulonglong * 8)()
-raw = C.CDLL(os.environ["EGX_LIB"])
-raw.egx_lbs_timing_read(buf, 1)
-h.forward(xb, betas, T, out=out, sdf=scene, R0=R0, T0=T0)
-torch.cuda.synchronize()
-raw.egx_lbs_timing_read(buf, 0)
-n = buf[3]
-print(f"wave-stages {n}: load burst -> data {buf[0]/n:.0f} cyc, LDS write + barrier {buf[1]/n:.0f} cyc, LDS reads + 72 MFMAs {buf[2]/n:.0f} cyc (pure MFMA issue = 2304)")
+raw = C.CDLL(_lib.LIB_PATH)
+for mode in (1, 2):
+    lib.egx_lbs_set_blend_mode(mode)
+    for name, kw in (("picks", {}), ("picks+sdf", dict(sdf=scene, R0=R0, T0=T0))):
+        out = {}
+        for _ in range(3):
+            h.forward(xb, betas, T, out=out, **kw)
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * 16)()
+        raw.egx_lbs_timing_read(buf, 1)
+        h.forward(xb, betas, T, out=out, **kw)
+        torch.cuda.synchronize()
+        raw.egx_lbs_timing_read(buf, 0)
+        nf, nm = max(buf[6], 1), max(buf[3], 1)
+        nslots = nf + nm  # wave-slots with work (fetch or mfma)
+        print(f"mode {mode} {name}: mfma-slot vmcnt wait {buf[0]/nm:.0f}, fetch-slot work {buf[1]/nf:.0f} | mfma phase (incl. wait) {buf[2]/nm:.0f} | "
+              f"barrier wait: mfma team {buf[4]/nm:.0f}, fetch team {buf[5]/nm:.0f} | slot total {buf[7]/(2*nm):.0f} | "
+              f"epilogue per wave-item {buf[8]/(nm/ (15 if mode==1 else 10)):.0f}  (wave-slots: {nm} mfma, {nf} fetch)")
+        ne = max(buf[12], 1)
+        print(f"      epilogue parts per wave-item: skinning {buf[9]/ne:.0f}, sdf brackets+queue {buf[10]/ne:.0f}, flush+counters {buf[11]/ne:.0f}")
