@@ -206,3 +206,28 @@ class GRUSeqFn(torch.autograd.Function):
             g_w_hh.addmm_(dgh2[nb:].t(), hs[1:T].reshape((T - 1) * nb, H))
         g_w_ih.addmm_(dgi.t(), x2)
         return (None,) * 10
+
+
+class FlatGrads:
+    """One flat fp32 gradient buffer aliased by the `.grad` of every parameter of `module` (256-byte aligned slices): what
+    LinearFn / GRUSeqFn accumulate into.  `zero()` before every backward, `attach()` after anything that may have replaced
+    a `.grad` (zero_grad(set_to_none=True), load_state_dict into new tensors)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters()]
+        off, self.layout = 0, []
+        for p in self.params:
+            self.layout.append((p, off, p.numel()))
+            off += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(off, dtype=torch.float32, device=self.params[0].device)
+        self.attach()
+
+    def attach(self):
+        base = self.flat.data_ptr()
+        for p, off, n in self.layout:
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                p.grad = self.flat[off:off + n].view_as(p)
+
+    def zero(self):
+        self.attach()
+        self.flat.zero_()

@@ -94,6 +94,48 @@ class GAMMAPrimitiveVAE(nn.Module):
         self.d_mlp = MLP(h, hd, "tanh")
         self.d_out = nn.Linear(self.d_mlp.out_dim, in_dim)
 
+    def forward_train(self, x: torch.Tensor, y: torch.Tensor, eps: Optional[torch.Tensor] = None):
+        """GAMMAPrimitiveVAE.forward (models_GAMMA_primitive.py:103-110: encode, VAE._sample, decode) for TRAINING, as an
+        autograd graph of HIP-backed nodes (fused_ops.LinearFn / GRUSeqFn / GRUPointwiseFn: weight gradients accumulate into
+        the flat buffer of `fused_ops.FlatGrads`, so the 18 uses of the decoder cell's weights cost no AccumulateGrad
+        kernels).  x[t_his,b,201], y[t_pred,b,201], eps[b,z] (drawn here when None) -> y_pred[t_pred,b,201], mu, logvar."""
+        from .fused_ops import GRUPointwiseFn, linear_act, linear_fn
+        if not x.is_cuda:
+            raise _lib.EgxError("the training forward runs on the HIP device only (no CPU fallback)")
+        t_his, nb, _ = x.shape
+        t_pred = y.shape[0]
+        x = x.to(torch.float32).contiguous()
+        y = y.to(torch.float32).contiguous()
+        # encode (:75-80).  decode (:85) evaluates x_enc on the same x again: the same tensor, used twice.
+        hx = _gru_last_fused_tm(self.x_enc, x.reshape(t_his * nb, -1), t_his)
+        hy = _gru_last_fused_tm(self.e_rnn, y.reshape(t_pred * nb, -1), t_pred)
+        h = torch.cat([hx, hy], dim=-1)
+        for fc in self.e_mlp.layers:
+            h = linear_act(h, fc, "tanh")
+        mu, logvar = linear_act(h, self.e_mu), linear_act(h, self.e_logvar)
+        if eps is None:
+            eps = torch.randn_like(mu)
+        z = mu + eps * torch.exp(0.5 * logvar)                     # VAE._sample, baseops.py:650-653
+        # decode (:83-101)
+        h_rnn = hx
+        for fc in self.drnn_mlp.layers:
+            h_rnn = linear_act(h_rnn, fc, "tanh")
+        ys = []
+        y_i = x[-1][:, :self.in_dim]
+        cell = self.d_rnn
+        for _ in range(t_pred):
+            y_p = y_i
+            rnn_in = torch.cat([hx, z, y_p], dim=-1)
+            gi = linear_fn(rnn_in, cell.weight_ih, cell.bias_ih)
+            gh = linear_fn(h_rnn, cell.weight_hh, cell.bias_hh)
+            h_rnn = GRUPointwiseFn.apply(gi, gh, h_rnn)
+            hfc = h_rnn
+            for fc in self.d_mlp.layers:
+                hfc = linear_act(hfc, fc, "tanh")
+            y_i = linear_act(hfc, self.d_out) + y_p                # residual
+            ys.append(y_i)
+        return torch.stack(ys), mu, logvar
+
 
 class ResNetBlock(nn.Module):
     def __init__(self, in_dim, h_dim, out_dim, n_blocks, actfun="relu"):
@@ -328,6 +370,15 @@ def _gru_last_fused(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
     if any(t.grad is None for t in (w_ih, b_ih, w_hh, b_hh)):
         raise _lib.EgxError("GRUSeqFn needs pre-allocated gradient views (GAMMAPPOPolicy._ensure_flat_grads)")
     return GRUSeqFn.apply(X, w_ih, b_ih, w_hh, b_hh, w_ih.grad, b_ih.grad, w_hh.grad, b_hh.grad, T)
+
+
+def _gru_last_fused_tm(gru: nn.GRU, x_tm: torch.Tensor, T: int) -> torch.Tensor:
+    """As _gru_last_fused for an input that is already time-major and flattened: x_tm[T*b, in]."""
+    from .fused_ops import GRUSeqFn
+    w_ih, b_ih, w_hh, b_hh = gru.weight_ih_l0, gru.bias_ih_l0, gru.weight_hh_l0, gru.bias_hh_l0
+    if any(t.grad is None for t in (w_ih, b_ih, w_hh, b_hh)):
+        raise _lib.EgxError("GRUSeqFn needs pre-allocated gradient views (fused_ops.FlatGrads)")
+    return GRUSeqFn.apply(x_tm, w_ih, b_ih, w_hh, b_hh, w_ih.grad, b_ih.grad, w_hh.grad, b_hh.grad, T)
 
 
 def _mlpblock_fused(block: MLPBlock, x: torch.Tensor) -> torch.Tensor:

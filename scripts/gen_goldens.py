@@ -300,6 +300,59 @@ def main():
                 flat[f"mp{i}_{j}"] = v.numpy()
     np.savez_compressed(os.path.join(OUT, "rollout_ref.npz"), n_mp=np.int64(n_mp), **flat)
     print("rollout_ref", list(ref_obj.keys()), list(ref_obj["motion"][0].keys()))
+    # ---- marker-predictor training loss (models_GAMMA_primitive.py:389-505) ------------------------------------------
+    # GAMMAPrimitiveVAETrainOP.calc_loss / calc_loss_rollout of the reference, on the CPU (TrainOP falls back to it when no
+    # CUDA device is visible), seeded weights, the reparameterisation noise captured from VAE._sample's torch.randn_like.
+    import tempfile as _tf
+    from models import models_GAMMA_primitive as mgp
+    mcfg = {"body_repr": "ssm2_67", "h_dim": 256, "z_dim": 128, "t_his": 2, "t_pred": 18, "use_drnn_mlp": True,
+            "hdims_mlp": [512, 256], "residual": True}
+    lcfg = {"weight_rec": 1.0, "weight_td": 3.0, "weight_kld": 1.0, "annealing_kld": False, "robust_kld": True}
+    with _tf.TemporaryDirectory() as td:
+        tcfg = {"log_dir": td, "save_dir": td, "max_rollout": 8, "num_epochs": 400, "learning_rate": 0.0005, "batch_size": 4}
+        op = mgp.GAMMAPrimitiveVAETrainOP(mcfg, lcfg, tcfg)
+        op.build_model()
+        shapes = fill_module(op.model, seed=300, gain=0.8)
+        gt = torch.Generator().manual_seed(301)
+        eps_log = []
+        real_randn_like = torch.randn_like
+
+        def fake_randn_like(t, *a, **k):
+            e = torch.randn(t.shape, generator=gt)
+            eps_log.append(e.clone())
+            return e
+        torch.randn_like = fake_randn_like
+        try:
+            nb1 = 4
+            data = torch.randn(20, nb1, 201, generator=gt) * 0.4
+            data = data.cumsum(0) * 0.1 + torch.randn(1, nb1, 201, generator=gt) * 0.5     # smooth-ish trajectories
+            op.model.zero_grad()
+            loss1, info1 = op.calc_loss(data.clone(), 0)
+            loss1.backward()
+            g1 = {k: p.grad.detach().clone() for k, p in op.model.named_parameters()}
+            eps1 = eps_log[-1]
+            nt2, nb2 = 41, 3
+            mk2 = (torch.randn(nt2, nb2, 201, generator=gt) * 0.3).cumsum(0) * 0.1 + torch.randn(1, nb2, 201, generator=gt) * 0.5
+            jt2 = (torch.randn(nt2, nb2, 22 * 3, generator=gt) * 0.2).cumsum(0) * 0.05 + torch.randn(1, nb2, 22 * 3, generator=gt)
+            n0 = len(eps_log)
+            op.model.zero_grad()
+            loss2, info2 = op.calc_loss_rollout((mk2.clone(), jt2.clone()), 0)
+            loss2.backward()
+            g2 = {k: p.grad.detach().clone() for k, p in op.model.named_parameters()}
+            eps2 = torch.stack(eps_log[n0:])
+        finally:
+            torch.randn_like = real_randn_like
+    out = {"fill_seed": np.int64(300), "fill_gain": np.float64(0.8), "state_dict_keys": np.array(list(shapes.keys())),
+           "state_dict_shapes": np.array([str(v) for v in shapes.values()]),
+           "data": data.numpy(), "eps": eps1.numpy(), "loss_info": np.asarray(info1, np.float64),
+           "roll_markers": mk2.numpy(), "roll_jts": jt2.numpy(), "roll_eps": eps2.numpy(), "roll_loss_info": np.asarray(info2, np.float64),
+           "grad_keys": np.array(list(g1.keys())),
+           "grad_norm": np.array([float(v.norm()) for v in g1.values()]),
+           "grad_head": np.stack([np.resize(v.flatten()[:8].numpy(), 8) for v in g1.values()]),
+           "roll_grad_norm": np.array([float(v.norm()) for v in g2.values()]),
+           "roll_grad_head": np.stack([np.resize(v.flatten()[:8].numpy(), 8) for v in g2.values()])}
+    np.savez_compressed(os.path.join(OUT, "predictor_train_ref.npz"), **out)
+    print("predictor_train_ref", info1, info2, "primitives in the rollout:", eps2.shape[0])
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

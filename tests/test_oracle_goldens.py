@@ -147,3 +147,27 @@ def test_save_rollout_results_matches_reference(tmp_path):
     # the time-stamped name of the default call (utils.py:43-46)
     p2 = save_rollout_results(scene, mps[:1], str(tmp_path / "out"))
     assert os.path.basename(p2).startswith("motion_") and p2.endswith(".pkl") and p2 != path
+
+
+def test_predictor_training_loss_and_gradients_match_reference():
+    """oracle.train (C-VAE forward with encoder, reconstruction + temporal-difference + robust KL loss, the multi-primitive
+    roll-out loss with on-the-fly re-canonicalisation) against GAMMAPrimitiveVAETrainOP.calc_loss / calc_loss_rollout of the
+    reference run on the CPU with the same seeded weights, data and reparameterisation noise: loss terms and the gradient
+    of every parameter (norm + first entries)."""
+    from oracle import train as otrain
+    g = load_golden("predictor_train_ref.npz")
+    sd = rebuild_state_dict(g, [int(g["fill_seed"])], [""], gains=[float(g["fill_gain"])])
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    keys = [str(k) for k in g["grad_keys"]]
+    loss, info = otrain.predictor_loss(sd, torch.from_numpy(g["data"]), torch.from_numpy(g["eps"]))
+    np.testing.assert_allclose([float(v) for v in info], g["loss_info"], rtol=2e-6, atol=1e-7)
+    grads = torch.autograd.grad(loss, [sd[k] for k in keys])
+    for k, gr, n, hd in zip(keys, grads, g["grad_norm"], g["grad_head"]):
+        assert abs(float(gr.norm()) - n) <= 2e-5 * max(n, 1e-6) + 1e-9, k
+        assert max_abs(np.resize(gr.flatten()[:8].numpy(), 8), hd) <= 2e-5 * max(float(np.abs(hd).max()), 1e-4), k
+    loss2, info2 = otrain.predictor_loss_rollout(sd, torch.from_numpy(g["roll_markers"]), torch.from_numpy(g["roll_jts"]),
+                                                 [torch.from_numpy(e) for e in g["roll_eps"]])
+    np.testing.assert_allclose(info2.numpy(), g["roll_loss_info"], rtol=2e-6, atol=1e-7)
+    grads2 = torch.autograd.grad(loss2, [sd[k] for k in keys])
+    for k, gr, n in zip(keys, grads2, g["roll_grad_norm"]):
+        assert abs(float(gr.norm()) - n) <= 5e-5 * max(n, 1e-6) + 1e-9, k
