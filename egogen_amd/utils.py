@@ -71,3 +71,35 @@ def save_rollout_results(scene, outmps, outfolder, man_id=None):
     with open(path, "wb") as f:
         pickle.dump(node, f)
     return path
+
+
+def rollout_primitives(motion_primitives, body_model, to_numpy: bool = True):
+    """motion/vis.py:44-78 (also experiments/gen_egobody_depth.py:27-61): the `motion` list of a motion_*.pkl ->
+    one continuous world-frame SMPL-X parameter sequence [t, 93].  Every primitive's 20 canonical-frame parameter rows
+    are carried into the world frame of its (transf_rotmat, transf_transl) - transl' = R (transl + pelvis) - pelvis + T,
+    glorot' = log(R exp(glorot)) - and the motion-seed frames a primitive shares with its predecessor (2 for '2-frame',
+    1 for '1-frame') are dropped.  `body_model`: BodyModelHandle of the primitive's gender (the reference builds a smplx
+    module for `pelvis_original`).  The frame change is egx_update_transl_glorot with the inverse frame
+    (R^T, -R^T T): x' = R'^T (x + d - T') - d."""
+    lib = _lib.load()
+    if not motion_primitives:
+        raise ValueError("empty motion list")
+    dev = torch.device("cuda")
+    chunks = []
+    for idx, mp in enumerate(motion_primitives):
+        xb = torch.as_tensor(np.asarray(mp["smplx_params"], np.float32)).reshape(-1, 93).to(dev).contiguous()
+        n = xb.shape[0]
+        betas = torch.as_tensor(np.asarray(mp["betas"], np.float32)).reshape(1, -1)[:, :10].to(dev).contiguous()
+        R = torch.as_tensor(np.asarray(mp["transf_rotmat"], np.float32)).reshape(3, 3).to(dev)
+        T = torch.as_tensor(np.asarray(mp["transf_transl"], np.float32)).reshape(3).to(dev)
+        Rinv = R.t().contiguous().reshape(1, 3, 3)
+        Tinv = (-(R.t() @ T)).reshape(1, 3).contiguous()
+        zero = torch.zeros(1, 93, dtype=torch.float32, device=dev)
+        delta = body_model.joints55(zero, betas, 1)[:, 0].repeat(n, 1).contiguous()      # pelvis of the rest pose
+        out = torch.empty_like(xb)
+        _lib.check(lib.egx_update_transl_glorot(_lib.ptr(Rinv), _lib.ptr(Tinv), 1, _lib.ptr(delta), _lib.ptr(xb), n, _lib.ptr(out),
+                                                _lib.current_stream_ptr()), "egx_update_transl_glorot")
+        start = 0 if idx == 0 else (2 if mp.get("mp_type") == "2-frame" else 1)
+        chunks.append(out[start:])
+    seq = torch.cat(chunks, dim=0)
+    return seq.cpu().numpy() if to_numpy else seq

@@ -282,6 +282,43 @@ def test_single_agent_crowd_env_view_rollout_matches_oracle(tmp_path):
     print("un-synchronised marker drift per primitive:", ["%.2e" % d for d in drift])
 
 
+def test_rollout_primitives_matches_reference_restatement():
+    """egogen_amd.utils.rollout_primitives (vis.py:44-78, the consumer of motion_*.pkl) against the oracle's
+    line-by-line restatement (scipy rotations like the reference), and the defining property: the body posed with the
+    rolled-out parameters IS the canonical body carried into the world frame."""
+    from egogen_amd.utils import rollout_primitives
+    from oracle.rollout import rollout_primitives as oracle_rollout
+    from oracle.smplx_lbs import smplx_forward
+    from scipy.spatial.transform import Rotation
+    p, h, ob, mk = _parser()
+    g = torch.Generator().manual_seed(8)
+    betas = torch.randn(10, generator=g)
+    mps = []
+    for i in range(3):
+        xb = torch.zeros(20, 93)
+        xb[:, :3] = torch.randn(20, 3, generator=g) * 0.5
+        xb[:, 3:6] = torch.randn(20, 3, generator=g) * 0.7
+        xb[:, 6:69] = torch.randn(20, 63, generator=g) * 0.2
+        R = torch.from_numpy(Rotation.from_euler("z", float(torch.rand(1, generator=g)) * 6.28).as_matrix()).float()
+        mps.append({"smplx_params": xb[None].numpy(), "betas": betas.numpy(), "gender": "male", "transf_rotmat": R.numpy(),
+                    "transf_transl": (torch.randn(1, 3, generator=g) * 2).numpy(), "mp_type": "2-frame",
+                    "blended_marker": np.zeros((20, 67, 3), np.float32), "pelvis_loc": np.zeros((20, 3), np.float32)})
+
+    def pelvis_of(b):
+        _, j = smplx_forward(ob, torch.zeros(1, 93), torch.as_tensor(b).reshape(1, 10).float())
+        return j[0, 0].numpy()
+    got = rollout_primitives(mps, h)
+    ref = oracle_rollout(mps, pelvis_of)
+    assert got.shape == ref.shape == (20 + 18 + 18, 93)
+    assert max_abs(got[:, :3], ref[:, :3]) < 2e-5 and max_abs(got[:, 6:], ref[:, 6:]) == 0.0
+    assert max_abs(Rotation.from_rotvec(got[:, 3:6]).as_matrix(), Rotation.from_rotvec(ref[:, 3:6]).as_matrix()) < 2e-5
+    # property: joints(rolled-out params) == R joints(canonical params) + T for the first primitive
+    j_w = p.get_jts(betas.cuda(), "male", torch.from_numpy(got[:20]).cuda(), to_numpy=False).cpu()
+    j_c = p.get_jts(betas.cuda(), "male", torch.from_numpy(mps[0]["smplx_params"][0]).cuda(), to_numpy=False).cpu()
+    want = torch.einsum("ij,bpj->bpi", torch.from_numpy(mps[0]["transf_rotmat"]), j_c) + torch.from_numpy(mps[0]["transf_transl"])
+    assert max_abs(j_w, want) < 5e-5
+
+
 def test_main_ppo_watch_room0_one_agent(tmp_path):
     """configs[0] command line: main_ppo.py --watch --test-num 1 on room0 writes motion_*.pkl and config.yaml."""
     env = dict(os.environ, PYTHONPATH=ROOT)
