@@ -132,39 +132,52 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
   // No software prefetch: on gfx950 a wave that issues v_mfma_f32_32x32x2_f32 while its own global loads are in flight
   // runs the matrix pipe at about half rate (scripts/ubench/mfma_loads.hip); the load latency of one wave is covered
   // by the other waves of the SIMD (4 workgroups per CU) instead.
-  for (int b = b0; b < b1; ++b) {
-    f32x4 gx[4], gw[4];
+  // Two k-blocks per round trip: the loads of both are issued together and waited for once, then the blocks go through
+  // the wave's staging strip one after the other.  These layers are latency-bound (a wave walks 2..9 blocks, each a
+  // dependent round trip to L2 / Infinity Cache of ~2 us against 0.4 us of MFMAs), so halving the trips is what counts.
+  for (int b = b0; b < b1; b += 2) {
+    f32x4 gx[2][4], gw[2][4];
+    const bool two = b + 1 < b1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      gx[q] = load_x4(a, min(m0 + q * 8 + lr, a.M - 1), b * 32 + lc);
-      gw[q] = load_w4(a, min(n0 + q * 8 + lr, a.N - 1), b * 32 + lc);
-    }
+    for (int u = 0; u < 2; ++u) {
+      if (u == 0 || two) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<f32x4*>(xs + (q * 8 + lr) * 36 + lc) = gx[q];
-      *reinterpret_cast<f32x4*>(ws + (q * 8 + lr) * 36 + lc) = gw[q];
-    }
-    if (a.bf16) {
-      // two 16-wide k sub-blocks: lane (i, h) holds k = 16 s + 8 h + 0..7 of row i as 8 bf16 (A and B alike)
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h), x1 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h + 4);
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h), w1 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h + 4);
-        bf16x8 xa, wb;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xa[e] = (short)egx_bf16_rne(x0[e]); xa[4 + e] = (short)egx_bf16_rne(x1[e]);
-          wb[e] = (short)egx_bf16_rne(w0[e]); wb[4 + e] = (short)egx_bf16_rne(w1[e]);
+        for (int q = 0; q < 4; ++q) {
+          gx[u][q] = load_x4(a, min(m0 + q * 8 + lr, a.M - 1), (b + u) * 32 + lc);
+          gw[u][q] = load_w4(a, min(n0 + q * 8 + lr, a.N - 1), (b + u) * 32 + lc);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wb, acc, 0, 0, 0);
       }
-    } else {
+    }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
-        const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<f32x4*>(xs + (q * 8 + lr) * 36 + lc) = gx[u][q];
+        *reinterpret_cast<f32x4*>(ws + (q * 8 + lr) * 36 + lc) = gw[u][q];
+      }
+      if (a.bf16) {
+        // two 16-wide k sub-blocks: lane (i, h) holds k = 16 s + 8 h + 0..7 of row i as 8 bf16 (A and B alike)
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h), x1 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h + 4);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h), w1 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h + 4);
+          bf16x8 xa, wb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xa[e] = (short)egx_bf16_rne(x0[e]); xa[4 + e] = (short)egx_bf16_rne(x1[e]);
+            wb[e] = (short)egx_bf16_rne(w0[e]); wb[4 + e] = (short)egx_bf16_rne(w1[e]);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wb, acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
+          const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
+        }
       }
     }
   }
