@@ -434,7 +434,7 @@ def main():
     # applies only to the configuration that pass was taken on
     traffic = None
     try:
-        for name in (f"r02_lbs_pmc_mode{blend}.json", "r01_lbs_pmc_bf16x3.json" if blend == 1 else "r01_lbs_pmc.json"):
+        for name in (f"r02_lbs_pmc_mode{blend}.json",):
             f = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(f):
                 continue
@@ -458,9 +458,21 @@ def main():
     else:
         kernel_name, peak, peak_note, executed = "egx_lbs_fused_kernel", PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA peak", None
     in_scene = _lbs_in_scene_ms(m["env"], lib)
+    other_mode = None
     if in_scene is not None:
         in_scene["achieved"] = FLOP_PER_BODY * bodies / (in_scene["avg_launch_ms"] * 1e-3) / 1e12
         in_scene["frac"] = in_scene["achieved"] / peak
+        if blend in (1, 2):  # the same launch in the other split mode (three planes <-> two planes), for the record
+            alt = 3 - blend
+            _lib.check(lib.egx_lbs_set_blend_mode(alt), "egx_lbs_set_blend_mode")
+            try:
+                o = _lbs_in_scene_ms(m["env"], lib)
+            finally:
+                _lib.check(lib.egx_lbs_set_blend_mode(blend), "egx_lbs_set_blend_mode")
+            o_peak = PEAK_BF16_MFMA_TFLOPS / BLEND_PRODUCTS[alt]
+            o["achieved"] = FLOP_PER_BODY * bodies / (o["avg_launch_ms"] * 1e-3) / 1e12
+            other_mode = {"blend": f"bf16x{3 if alt == 1 else 2}", "in_scene_avg_launch_ms": o["avg_launch_ms"], "achieved": o["achieved"],
+                          "peak": o_peak, "frac": o["achieved"] / o_peak}
 
     total_agents = A * world
     result = {
@@ -488,7 +500,10 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
                      "flop_per_body": FLOP_PER_BODY, "peak_note": peak_note, "executed_bf16_tflops": executed,
-                     "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene},
+                     "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene, "other_blend_mode": other_mode,
+                     "sustained_matrix_rate_note": "72 back-to-back v_mfma_f32_32x32x16_bf16 take 46, not 32, cycles each on this part "
+                                                   "(clock-limited: 1720 of 2500 TFLOP/s in a load-free micro-benchmark, profiles/r01_ubench.md "
+                                                   "section 4, profiles/r02_lbs_experiments.md); `peak` is the data-sheet figure"},
     }
     if world > 1:
         result["allreduce"] = m["allreduce"]
@@ -501,17 +516,20 @@ def main():
         del mw
         torch.cuda.empty_cache()
     if world == 1 and args.extra_configs and args.scene == "single_box" and args.agents == 512:
+        # each extra configuration in a fresh process (a second environment + policy inside this one measurably disturbs the
+        # timing: allocator state, captured graphs of the first policy)
         others = []
-        for label, sc_name, a_tot in (("BASELINE configs[2]: 512 agents, random-box scene set (walkability-map penetration term)", "box", 512),
-                                      ("reference default shape: 256 agents, 1024 transitions per collect, single-box SDF scene", "single_box", 256)):
+        for label, flags in (("BASELINE configs[2]: 512 agents, random-box scene set (walkability-map penetration term)", ["--scene", "box"]),
+                             ("reference default shape: 256 agents, 1024 transitions per collect, single-box SDF scene", ["--agents", "256"])):
+            cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--extra-configs", "0", "--steps", str(args.steps),
+                   "--warmup", str(args.warmup), "--num-verts", str(args.num_verts), "--sdf-res", str(args.sdf_res),
+                   "--vec-steps", str(args.vec_steps), "--batch-size", str(args.batch_size)] + flags
             try:
-                sc = scene if sc_name == args.scene else sw.build_scene(sc_name, sdf_res=args.sdf_res, seed=0)
-                mo = _measure(args, 1, 0, a_tot, args.batch_size, sc, ops, args.steps, max(1, args.warmup), with_lbs_events=True)
-                others.append({"workload": label, "value": mo["transitions"] / mo["elapsed"], "unit": "env-steps/s",
-                               "ms_per_step": mo["elapsed"] / args.steps * 1e3, "lbs_avg_launch_ms": float(np.mean(mo["lbs_ms"])),
-                               "steps": args.steps})
-                del mo
-                torch.cuda.empty_cache()
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, stdin=subprocess.DEVNULL)
+                line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+                r2 = json.loads(line)
+                others.append({"workload": label, "value": r2["value"], "unit": r2["unit"], "ms_per_step": r2["ms_per_step"],
+                               "lbs_avg_launch_ms": r2["roofline"]["avg_launch_ms"], "steps": r2["steps"], "command": " ".join(cmd[1:])})
             except Exception as e:
                 others.append({"workload": label, "value": None, "error": f"{type(e).__name__}: {e}"})
         result["other_configs"] = others

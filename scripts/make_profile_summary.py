@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""profiles/r01_final_summary.md from the committed rocprofv3 kernel stats + bench JSON lines."""
-import csv, collections, json, os
+"""profiles/<round>_final_summary.md from the committed rocprofv3 kernel stats + bench JSON lines.
+usage: make_profile_summary.py r02 <cycles under rocprofv3>"""
+import csv, collections, json, os, sys
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
-rows = list(csv.DictReader(open(os.path.join(R, "r01_final_bench_kernel_stats.csv"))))
+RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rows = list(csv.DictReader(open(os.path.join(R, f"{RND}_final_bench_kernel_stats.csv"))))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 cat, calls = collections.Counter(), collections.Counter()
 for r in rows:
@@ -12,13 +14,13 @@ for r in rows:
     elif "at::native" in n: k = "torch " + n.split("at::native::")[1].split("<")[0][:40]
     else: k = n[:48]
     cat[k] += float(r["TotalDurationNs"]); calls[k] += int(r["Calls"])
-ncyc = 8
-b = json.load(open(os.path.join(R, "r01_final_bench.json")))
-u = json.loads(open(os.path.join(R, "r01_final_bench_under_rocprof.json")).read())
-lbs = [r for r in rows if "egx_lbs_fused3" in r["Name"]][0]
-L = ["# Round 1 final profile (1x MI355X)", "",
-     "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline` (2 warm-up + 6 timed cycles;",
-     "per-cycle figures below divide by 8).  Un-profiled run of `python bench.py`: `r01_final_bench.json`.", "",
+ncyc = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+b = json.load(open(os.path.join(R, f"{RND}_final_bench.json")))
+u = json.loads(open(os.path.join(R, f"{RND}_final_bench_under_rocprof.json")).read())
+lbs = max((r for r in rows if "egx_lbs_fused3" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+L = [f"# Round {int(RND[1:])} final profile (1x MI355X)", "",
+     f"Command: `bash scripts/run_profile.sh` = `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --extra-configs 0 --steps 10`",
+     f"(per-cycle figures below divide by {ncyc}).  Un-profiled run of `python bench.py`: `{RND}_final_bench.json`.", "",
      f"* un-profiled: **{b['value']:.0f} env-steps/s**, {b['ms_per_step']:.2f} ms per 2048-transition cycle; fused LBS kernel {b['roofline']['avg_launch_ms']:.3f} ms per launch (HIP events) = {b['roofline']['achieved']:.1f} TFLOP/s fp32-equivalent, frac {b['roofline']['frac']:.3f} of {b['roofline']['peak']:.1f} ({b['roofline']['peak_note']}); traffic {b['roofline']['traffic']/1e9:.2f} GB per launch (PMC)",
      f"* under rocprofv3: {u['value']:.0f} env-steps/s; LBS kernel: rocprofv3 average {float(lbs['AverageNs'])/1e6:.3f} ms over {lbs['Calls']} launches, HIP-event average in the same run {u['roofline']['avg_launch_ms']:.3f} ms",
      f"* cpu_baseline: {b['cpu_baseline']['value']:.2f} env-steps/s on {b['cpu_baseline']['cores']} threads ({b['cpu_baseline']['sample']})", "",
@@ -38,6 +40,6 @@ extra = ["", "| kernel | work per launch | avg us | rate | bound |", "|---|---|-
 egx = sum(v for k, v in cat.items() if "egx_" in k)
 L += extra
 L += ["", f"hand-written kernels (`egx_*`): {egx/tot*100:.1f} % of GPU time; summed kernel time {tot/ncyc/1e6:.2f} ms per cycle (the update's actor / critic and encoder branches run concurrently, so the sum exceeds the wall time).",
-      "PMC passes of the LBS kernel: `r01_lbs_pmc_bf16x3.json` (default blend mode), `r01_lbs_pmc.json` (fp32-MFMA kernel of the first half of the round); micro-benchmarks: `r01_ubench.md`."]
-open(os.path.join(R, "r01_final_summary.md"), "w").write("\n".join(L) + "\n")
+      f"PMC passes of the LBS kernel: `{RND}_lbs_pmc_mode*.json`; experiments of the round: `{RND}_lbs_experiments.md`; micro-benchmarks: `r01_ubench.md`."]
+open(os.path.join(R, f"{RND}_final_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L[5:9]))

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $R/bench.py --no-cpu-baseline --extra-configs 0 --steps 10 > "$OUT/bench_under_rocprof.log" 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $R/bench.py --no-cpu-baseline --extra-configs 0 --steps 10 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.log" < /dev/null
 echo "rocprofv3 rc=$?"
 f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$f" ] && [ -f "$f" ]; then
