@@ -28,7 +28,8 @@ SCENE_DEFAULT = "room0"
 CFG_NAME = "MPVAEPolicy_samp_collision"
 
 
-def get_args(argv=None):
+def get_args(argv=None, extra=()):
+    """`extra`: [(flag, add_argument kwargs)] of a sibling driver (main_egobody_eval.py)."""
     p = argparse.ArgumentParser()
     p.add_argument("--task", type=str, default="collision-avoidance")
     p.add_argument("--seed", type=int, default=0)
@@ -75,6 +76,8 @@ def get_args(argv=None):
     p.add_argument("--policy-dtype", type=str, default=None, choices=["fp32", "bf16"],
                    help="arithmetic of the rollout policy's dense layers (default: fp32; main_crowd_eval.py: bf16, BASELINE config 5)")
     p.add_argument("--num-scenes", type=int, default=None, help="main_crowd_eval.py: independent 4-human scenes per GPU")
+    for flag, kw in extra:
+        p.add_argument(flag, **kw)
     return p.parse_args(argv)
 
 

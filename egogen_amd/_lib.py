@@ -70,14 +70,14 @@ class EnvConfig(C.Structure):
                                          "weight_face_target", "weight_look_target", "weight_success", "weight_target_dist",
                                          "weight_pene", "weight_vp")] + \
                [(n, C.c_int) for n in ("max_depth", "scene_kind", "terminate_on_penetration", "pene_type_body")] + \
-               [("ray_len", C.c_float)]
+               [("ray_len", C.c_float), ("vp_thresh", C.c_float), ("no_goal_termination", C.c_int)]
 
 
 class EnvScenes(C.Structure):
     _fields_ = [("edges", C.c_void_p), ("edge_off", C.c_void_p), ("tris", C.c_void_p), ("tri_off", C.c_void_p),
                 ("floor_height", C.c_void_p), ("map_lin", C.c_void_p), ("map_res", C.c_int),
                 ("crowd_bbox", C.c_void_p), ("crowd_group", C.c_int), ("crowd_scenes", C.c_int), ("crowd_member", C.c_int),
-                ("crowd_floor_half", C.c_float)]
+                ("crowd_floor_half", C.c_float), ("crowd_polygon", C.c_int), ("crowd_static", C.c_int)]
 
 
 class EnvState(C.Structure):
@@ -87,7 +87,7 @@ class EnvState(C.Structure):
 class EnvStepIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("Y_gen", "pred_params", "joints", "markers_proj", "pene_count", "vp_emb",
                                           "feet_marker_idx", "reward", "terminated", "reward_terms", "obs_ego", "obs_dist",
-                                          "obs_time", "out_marker_b", "out_prev_frame", "nonfinite_count")]
+                                          "obs_time", "out_marker_b", "out_prev_frame", "nonfinite_count", "invalid_flags")]
 
 
 class EnvResetIO(C.Structure):

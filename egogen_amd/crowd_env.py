@@ -49,7 +49,12 @@ class VecCrowdEnv:
                  motion_seed: Optional[dict] = None, cfg: Optional[dict] = None, finetuning: bool = False,
                  seed: int = 0, num_candidates: Optional[int] = None, use_graph: bool = False,
                  keep_rollout: bool = False, device: str = "cuda", crowd_bbox: Optional[torch.Tensor] = None,
-                 crowd_member: int = 0, crowd_pairs=None, crowd_floor_half: float = 4.0):
+                 crowd_member: int = 0, crowd_pairs=None, crowd_floor_half: float = 4.0,
+                 crowd_rings: Optional[List[np.ndarray]] = None, crowd_static: bool = False, agent_seeds: Optional[List[dict]] = None,
+                 vp_thresh: float = 11.0, goal_terminates: bool = True):
+        """`crowd_rings` / `crowd_static` / `agent_seeds` / `vp_thresh` / `goal_terminates` are the EgoBody-evaluation variant of
+        the crowd scenes (crowd_env_egobody_eval.py, see CrowdGroupEnv): the scene's walkable polygon as exterior, one motion
+        seed (two frames + betas) per agent instead of one table for all, the looser pose filter, no goal termination."""
         if not torch.cuda.is_available():
             raise _lib.EgxError("VecCrowdEnv needs a HIP device (no CPU fallback)")
         self.lib = _lib.load()
@@ -94,7 +99,13 @@ class VecCrowdEnv:
         ms = motion_seed or {k: synth.load_assets()[f"seed_{k}"] for k in ("poses", "trans", "betas")}
         self.motion_seed = {k: np.asarray(v, np.float64) for k, v in ms.items() if k in ("poses", "trans", "betas")}
         self.betas = torch.tensor(self.motion_seed["betas"], **f32).reshape(1, 10).repeat(A, 1).contiguous()
-        if scene_kind == "sdf":
+        self.agent_seeds = agent_seeds
+        if agent_seeds is not None:
+            if scene_kind != "crowd" or len(agent_seeds) != A:
+                raise ValueError("agent_seeds: one {poses[2,66], trans[2,3], betas[10]} per agent, crowd scenes only")
+            self.betas = torch.tensor(np.stack([np.asarray(d["betas"], np.float32).reshape(10) for d in agent_seeds]), **f32).contiguous()
+            starts = list(range(A))                                # table row a = agent a's own two frames
+        elif scene_kind == "sdf":
             starts = [5]                                           # environments.py:193 fixed start frame
         elif scene_kind == "crowd" and motion_seed is not None and motion_seed.get("fixed_start") is not None:
             starts = [int(motion_seed["fixed_start"])]
@@ -102,6 +113,7 @@ class VecCrowdEnv:
             starts = list(range(len(self.motion_seed["poses"]) - 1))  # environments.py:483 random start frame
         self.variant_starts = starts
         self._build_seed_tables(starts)
+        self.invalid = torch.zeros(A, **i32)   # EgoBody filters (egx_env_step_io.invalid_flags)
 
         # ---- scenes ----
         self.sdf = None
@@ -129,6 +141,8 @@ class VecCrowdEnv:
             if crowd_bbox is None or crowd_pairs is None or crowd_bbox.shape[1] != A or crowd_bbox.shape[2] != 4:
                 raise ValueError("crowd scene kind needs crowd_bbox[G,A,4] and crowd_pairs[A,2,3]")
             edges, tris, floor = [np.zeros((1, 4), np.float32)], [np.zeros((0, 6), np.float32)], [0.0]
+            if crowd_rings is not None:
+                edges = [synth.rings_to_edges(crowd_rings).astype(np.float32)]
             self.crowd_pairs = torch.tensor(np.asarray(crowd_pairs, np.float32), **f32).reshape(A, 1, 2, 3)
             self.K = 1
         else:
@@ -170,6 +184,8 @@ class VecCrowdEnv:
         ec.scene_kind = {"sdf": 0, "box": 1, "crowd": 2}[scene_kind]
         ec.pene_type_body = 1 if c["pene_type"] == "body" else 0
         ec.ray_len = float(c["ray_len"])
+        ec.vp_thresh = float(vp_thresh)
+        ec.no_goal_termination = 0 if goal_terminates else 1
         self._ec = ec
         sc = _lib.EnvScenes()
         sc.edges, sc.edge_off, sc.tris, sc.tri_off = self.edges.data_ptr(), self.edge_off.data_ptr(), self.tris.data_ptr(), self.tri_off.data_ptr()
@@ -177,6 +193,7 @@ class VecCrowdEnv:
         if scene_kind == "crowd":
             sc.crowd_bbox, sc.crowd_group, sc.crowd_scenes = crowd_bbox.data_ptr(), int(crowd_bbox.shape[0]), A
             sc.crowd_member, sc.crowd_floor_half = self.crowd_member, float(crowd_floor_half)
+            sc.crowd_polygon, sc.crowd_static = int(crowd_rings is not None), int(bool(crowd_static))
         self._sc = sc
         self._st = self._make_state_struct(self.state, self.seed, self.R0, self.T0, self.dist, self.steps, self.wpath, self.scene_idx)
         io = _lib.EnvStepIO()
@@ -186,6 +203,7 @@ class VecCrowdEnv:
         io.reward, io.terminated, io.reward_terms = self.reward.data_ptr(), self.terminated.data_ptr(), self.rterms.data_ptr()
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=self.dev)
         io.nonfinite_count = self.nonfinite.data_ptr()
+        io.invalid_flags = self.invalid.data_ptr()
         io.obs_ego, io.obs_dist, io.obs_time = self.obs_ego.data_ptr(), self.obs_dist.data_ptr(), self.obs_time.data_ptr()
         io.out_marker_b = self.marker_b.data_ptr() if keep_rollout else None
         io.out_prev_frame = self.prev_frame.data_ptr() if keep_rollout else None
@@ -224,12 +242,20 @@ class VecCrowdEnv:
         pose = np.zeros((NV, 2, 63))
         for v, s in enumerate(starts):
             for f in range(2):
-                pose[v, f] = ms["poses"][s + f, 3:66]
-                glorot[v, f] = _rodrigues_np(ms["poses"][s + f, :3])
-                transl[v, f] = ms["trans"][s + f]
+                if self.agent_seeds is not None:
+                    d = self.agent_seeds[v]
+                    po, tr = np.asarray(d["poses"], np.float64)[f], np.asarray(d["trans"], np.float64)[f]
+                else:
+                    po, tr = ms["poses"][s + f], ms["trans"][s + f]
+                pose[v, f] = po[3:66]
+                glorot[v, f] = _rodrigues_np(po[:3])
+                transl[v, f] = tr
         xb[:, 6:69] = torch.tensor(pose.reshape(NV * 2, 63), dtype=torch.float32)
-        betas = torch.tensor(ms["betas"], dtype=torch.float32).reshape(1, 10).to(self.dev)
-        out = self.bm.forward(xb.to(self.dev), betas.repeat(NV * 2, 1).contiguous(), 1, want_verts=False)
+        if self.agent_seeds is not None:
+            betas_rows = self.betas.repeat_interleave(2, 0).contiguous()
+        else:
+            betas_rows = torch.tensor(ms["betas"], dtype=torch.float32).reshape(1, 10).to(self.dev).repeat(NV * 2, 1).contiguous()
+        out = self.bm.forward(xb.to(self.dev), betas_rows, 1, want_verts=False)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.tab_joints = out["joints"].reshape(NV, 2, -1, 3).clone().contiguous()
         self.tab_markers = out["markers"].reshape(NV, 2, -1, 3).clone().contiguous()
@@ -290,7 +316,10 @@ class VecCrowdEnv:
             self.cand_pairs.copy_(self.valid_pairs[idx].reshape(A, K, 2, 3))
         elif self.scene_kind == "crowd":
             self.cand_pairs.copy_(self.crowd_pairs)
-            self.cand_variant.copy_(torch.randint(0, len(self.variant_starts), (A, K), generator=g, device=self.dev).to(torch.int32))
+            if self.agent_seeds is not None:
+                self.cand_variant.copy_(torch.arange(A, dtype=torch.int32, device=self.dev).reshape(A, K))
+            else:
+                self.cand_variant.copy_(torch.randint(0, len(self.variant_starts), (A, K), generator=g, device=self.dev).to(torch.int32))
             u = torch.rand(A, K, generator=g, device=self.dev) * 2 - 1
             self.cand_yaw.copy_(u * (2 * np.pi * 0.2))           # environments.py:1100-1101 (CrowdMotion.gen_init_body)
         else:
@@ -424,14 +453,29 @@ class CrowdGroupEnv:
     and those of k+1.. from the previous round - the ordering of dummy_vector_env.py:81-84."""
 
     def __init__(self, num_scenes: int, start_target, body_model, prior, vposer, cfg=None, seed=0, keep_rollout=False,
-                 motion_seed=None, floor_half: float = 4.0, device="cuda"):
+                 motion_seed=None, floor_half: float = 4.0, device="cuda", scene_rings=None, static_scene: bool = False,
+                 agent_seeds=None, vp_thresh: float = 11.0, goal_terminates: bool = True):
+        """`scene_rings` ... `goal_terminates`: the EgoBody evaluation (main_egobody_eval.py / crowd_env_egobody_eval.py, G = 2):
+        the walkable polygon of the scene's navmesh as exterior (:402), `agent_seeds[k][s]` = the two seed frames + betas of
+        member k in scene s (Egobody.gen_init_body, environments.py:679-765), pose filter at 14 (:229), only max_depth
+        terminates (:378).  `static_scene=True` reproduces what `Polygon(self.scene_poly, holes)` (:824) evaluates to when
+        the shell is already a Polygon - shapely returns that polygon, the other person never becomes a hole."""
         st = np.asarray(start_target, np.float32)          # [G,S,2,3]
         self.G, self.S = int(st.shape[0]), int(num_scenes)
         assert st.shape[1] == self.S
         self.bbox = torch.zeros(self.G, self.S, 4, dtype=torch.float32, device=device)
         self.members = [VecCrowdEnv(self.S, body_model, prior, vposer, scene_kind="crowd", cfg=cfg, seed=seed + 17 * k,
                                     keep_rollout=keep_rollout, motion_seed=motion_seed, crowd_bbox=self.bbox, crowd_member=k,
-                                    crowd_pairs=st[k], crowd_floor_half=floor_half, device=device) for k in range(self.G)]
+                                    crowd_pairs=st[k], crowd_floor_half=floor_half, device=device, crowd_rings=scene_rings,
+                                    crowd_static=static_scene, agent_seeds=None if agent_seeds is None else agent_seeds[k],
+                                    vp_thresh=vp_thresh, goal_terminates=goal_terminates) for k in range(self.G)]
+
+    def invalid(self) -> torch.Tensor:
+        """[S] OR of the members' filter flags (1: pelvis left the scene polygon early, 2: unrealistic pose)."""
+        out = self.members[0].invalid.clone()
+        for m in self.members[1:]:
+            out |= m.invalid
+        return out
 
     def reset(self):
         """Every member publishes its initial box (constructor of crowd_env_crowd_eval.CrowdEnv, :54-75) before anyone

@@ -82,11 +82,30 @@ struct SceneDev {
   float* crowd_bbox;    // [G][S][4] (minx,miny,maxx,maxy) or null
   int crowd_G, crowd_S, crowd_k;
   float crowd_half;     // floor is [-half, half]^2 (crowd_env_crowd_eval.py:391)
+  int crowd_polygon;    // 1: the exterior is the ring set edges[edge_off[0] .. edge_off[1]) instead of the square floor
+                        //    (crowd_env_egobody_eval.py:402 scene_poly = walkable region of the scene's navmesh)
+  int crowd_static;     // 1: the other members' boxes are NOT holes (what shapely's Polygon(polygon, holes) evaluates to in
+                        //    crowd_env_egobody_eval.py:824)
 };
+
+// even-odd containment of (x, y) in the ring set edges[e0, e1), float64 like shapely's predicates on these inputs
+__device__ __forceinline__ bool point_in_rings(const float* edges, int e0, int e1, double x, double y) {
+  int crossings = 0;
+  for (int e = e0; e < e1; ++e) {
+    const float* q = edges + (size_t)e * 4;
+    const double x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3];
+    if ((y0 > y) != (y1 > y)) {
+      const double xint = x0 + (y - y0) * (x1 - x0) / (y1 - y0);
+      if (x < xint) ++crossings;
+    }
+  }
+  return (crossings & 1) == 1;
+}
 
 // number of boundary edges of scene `sc_i` and the e-th edge (x0,y0,x1,y1) in float64
 __device__ __forceinline__ int scene_num_edges(const SceneDev& sc, int sc_i) {
-  if (sc.crowd_bbox) return 4 + 4 * (sc.crowd_G - 1);
+  if (sc.crowd_bbox)
+    return (sc.crowd_polygon ? sc.edge_off[1] - sc.edge_off[0] : 4) + (sc.crowd_static ? 0 : 4 * (sc.crowd_G - 1));
   return sc.edge_off[sc_i + 1] - sc.edge_off[sc_i];
 }
 __device__ __forceinline__ void scene_edge(const SceneDev& sc, int sc_i, int e, double& x0, double& y0, double& x1, double& y1) {
@@ -95,12 +114,19 @@ __device__ __forceinline__ void scene_edge(const SceneDev& sc, int sc_i, int e, 
     x0 = p[0]; y0 = p[1]; x1 = p[2]; y1 = p[3];
     return;
   }
+  const int n_ext = sc.crowd_polygon ? sc.edge_off[1] - sc.edge_off[0] : 4;
+  if (sc.crowd_polygon && e < n_ext) {
+    const float* p = sc.edges + (size_t)(sc.edge_off[0] + e) * 4;
+    x0 = p[0]; y0 = p[1]; x1 = p[2]; y1 = p[3];
+    return;
+  }
   float lo[2], hi[2];
   int q;
-  if (e < 4) {
+  if (e < n_ext) {
     lo[0] = lo[1] = -sc.crowd_half; hi[0] = hi[1] = sc.crowd_half;
     q = e;
   } else {
+    e -= n_ext - 4;
     int other = (e - 4) >> 2;
     if (other >= sc.crowd_k) ++other;  // skip this member's own box
     const float* b = sc.crowd_bbox + ((size_t)other * sc.crowd_S + sc_i) * 4;
@@ -187,8 +213,9 @@ __device__ __forceinline__ bool walk_cell(const SceneDev& sc, int scene, const f
   if (world_xy) { world_xy[0] = px; world_xy[1] = py; }
   bool walk = false;
   if (sc.crowd_bbox) {  // crowd_env_crowd_eval.py:742-764: polygon(floor, holes).contains(point), z forced to 0
-    walk = (fabsf(px) < sc.crowd_half) && (fabsf(py) < sc.crowd_half);
-    for (int o = 0; o < sc.crowd_G && walk; ++o) {
+    walk = sc.crowd_polygon ? point_in_rings(sc.edges, sc.edge_off[0], sc.edge_off[1], (double)px, (double)py)
+                            : (fabsf(px) < sc.crowd_half) && (fabsf(py) < sc.crowd_half);
+    for (int o = 0; o < sc.crowd_G && walk && !sc.crowd_static; ++o) {
       if (o == sc.crowd_k) continue;
       const float* b = sc.crowd_bbox + ((size_t)o * sc.crowd_S + scene) * 4;
       if (px >= b[0] && px <= b[2] && py >= b[1] && py <= b[3]) walk = false;
@@ -229,6 +256,8 @@ struct EnvCfg {
   float w_skate, w_floor, w_face, w_look, w_success, w_target_dist, w_pene, w_vp;
   int max_depth, scene_kind /*0 sdf, 1 box*/, terminate_on_pene, pene_body;
   float ray_len;
+  float vp_thresh;      // mean VPoser-embedding norm above which a pose counts as unrealistic (11; EgoBody eval: 14)
+  int no_goal_term;     // 1: reaching the goal does not end the episode (crowd_env_egobody_eval.py:378)
 };
 
 struct StepArgs {
@@ -257,6 +286,7 @@ struct StepArgs {
   int* terminated;     // [A]
   float* rterms;       // [A,8] or null: skate, floor, face, look, goal, target_dist, pene, vp
   int* nonfinite;      // device counter or null
+  int* invalid;        // [A] or null: |= 1 pelvis left the scene polygon in the first steps, |= 2 unrealistic pose
   float* obs_ego;      // [A,2,32]
   float* obs_dist;     // [A]
   float* obs_time;     // [A]
@@ -355,7 +385,7 @@ __global__ __launch_bounds__(BLK) void egx_env_step_post_kernel(StepArgs p) {
     part = sqrtf(s);
   }
   const float vp_norm = block_reduce(part, s_red, 0) / (float)NT;
-  const float r_vp = (vp_norm > 11.f) ? 0.f : 0.05f;
+  const float r_vp = (vp_norm > c.vp_thresh) ? 0.f : 0.05f;
 
   // ---- 4. SDF penetration (room env) -----------------------------------------------------------------------
   float r_pene = 0.f;
@@ -496,8 +526,21 @@ __global__ __launch_bounds__(BLK) void egx_env_step_post_kernel(StepArgs p) {
                          r_goal * c.w_success + r_td * c.w_target_dist + r_pene * c.w_pene + r_vp * c.w_vp;
     const int steps = p.steps[a] + 1;
     p.steps[a] = steps;
-    bool term = (r_goal > 0.f) || (steps == c.max_depth);
+    bool term = (steps == c.max_depth) || (r_goal > 0.f && !c.no_goal_term);
     if (c.terminate_on_pene) term = term || penetration;
+    if (p.invalid) {
+      // the filters of crowd_env_egobody_eval.py:208-216,229-234 (the reference process exits; here the sequence is flagged)
+      int bad = (vp_norm > c.vp_thresh) ? 2 : 0;
+      if (steps < 6 && p.sc.crowd_bbox && p.sc.crowd_polygon) {
+        for (int t = 0; t < NT && !(bad & 1); ++t) {
+          const float* j0 = J + (size_t)t * NJO * 3;  // pelvis, canonical frame of this step
+          const float wx = (R0o[0] * j0[0] + R0o[1] * j0[1] + R0o[2] * j0[2]) + T0o[0];
+          const float wy = (R0o[3] * j0[0] + R0o[4] * j0[1] + R0o[5] * j0[2]) + T0o[1];
+          if (!point_in_rings(p.sc.edges, p.sc.edge_off[0], p.sc.edge_off[1], (double)wx, (double)wy)) bad |= 1;
+        }
+      }
+      if (bad) p.invalid[a] |= bad;
+    }
     p.reward[a] = reward;
     if (p.nonfinite && !(isfinite(reward) && isfinite(d2t))) atomicAdd(p.nonfinite, 1);
     p.terminated[a] = term ? 1 : 0;
@@ -768,6 +811,8 @@ static EnvCfg to_cfg(const egx_env_config* c) {
   o.w_success = c->weight_success; o.w_target_dist = c->weight_target_dist; o.w_pene = c->weight_pene; o.w_vp = c->weight_vp;
   o.max_depth = c->max_depth; o.scene_kind = c->scene_kind; o.terminate_on_pene = c->terminate_on_penetration;
   o.pene_body = c->pene_type_body; o.ray_len = c->ray_len;
+  o.vp_thresh = c->vp_thresh > 0.f ? c->vp_thresh : 11.f;
+  o.no_goal_term = c->no_goal_termination;
   return o;
 }
 static SceneDev to_scene(const egx_env_scenes* s) {
@@ -776,6 +821,7 @@ static SceneDev to_scene(const egx_env_scenes* s) {
   o.map_lin = s->map_lin; o.map_res = s->map_res;
   o.crowd_bbox = s->crowd_bbox; o.crowd_G = s->crowd_group; o.crowd_S = s->crowd_scenes; o.crowd_k = s->crowd_member;
   o.crowd_half = s->crowd_floor_half;
+  o.crowd_polygon = s->crowd_polygon; o.crowd_static = s->crowd_static;
   return o;
 }
 
@@ -794,7 +840,8 @@ extern "C" int egx_env_step_post(const egx_env_config* cfg, const egx_env_scenes
   EGX_REQUIRE(io->Y_gen && io->pred_params && io->joints && io->markers_proj && io->vp_emb && io->feet_marker_idx &&
                   io->reward && io->terminated && io->obs_ego && io->obs_dist && io->obs_time, "null io array");
   EGX_REQUIRE(cfg->scene_kind == 2 ? (scenes->crowd_bbox && scenes->crowd_group >= 2 && scenes->crowd_scenes == A &&
-                                      scenes->crowd_member >= 0 && scenes->crowd_member < scenes->crowd_group && scenes->map_lin)
+                                      scenes->crowd_member >= 0 && scenes->crowd_member < scenes->crowd_group && scenes->map_lin &&
+                                      (!scenes->crowd_polygon || (scenes->edges && scenes->edge_off)))
                                    : (scenes->edges && scenes->edge_off),
               "scene tables missing");
   EGX_REQUIRE(cfg->scene_kind == 0 ? (io->pene_count != nullptr)
@@ -806,7 +853,7 @@ extern "C" int egx_env_step_post(const egx_env_config* cfg, const egx_env_scenes
   p.wpath = st->wpath; p.scene_idx = st->scene_idx;
   p.Y_gen = io->Y_gen; p.pred_params = io->pred_params; p.joints = io->joints; p.markers_proj = io->markers_proj;
   p.pene_count = io->pene_count; p.vp_emb = io->vp_emb; p.feet_marker_idx = io->feet_marker_idx;
-  p.reward = io->reward; p.terminated = io->terminated; p.rterms = io->reward_terms; p.nonfinite = io->nonfinite_count; p.obs_ego = io->obs_ego;
+  p.reward = io->reward; p.terminated = io->terminated; p.rterms = io->reward_terms; p.nonfinite = io->nonfinite_count; p.invalid = io->invalid_flags; p.obs_ego = io->obs_ego;
   p.obs_dist = io->obs_dist; p.obs_time = io->obs_time; p.out_marker_b = io->out_marker_b; p.out_prev_frame = io->out_prev_frame;
   hipLaunchKernelGGL(egx_env_step_post_kernel, dim3(A), dim3(BLK), 0, static_cast<hipStream_t>(stream_), p);
   EGX_HIP_CHECK(hipGetLastError());
@@ -818,7 +865,9 @@ extern "C" int egx_env_reset(const egx_env_config* cfg, const egx_env_scenes* sc
   EGX_REQUIRE(cfg && scenes && st && io && A > 0, "bad arguments");
   EGX_REQUIRE(io->num_candidates >= 1 && io->cand_pairs && io->tab_joints && io->tab_markers && io->tab_glorot &&
                   io->tab_transl && io->tab_pose && io->obs_ego && io->obs_dist && io->obs_time, "null reset io array");
-  EGX_REQUIRE(cfg->scene_kind == 2 ? (scenes->crowd_bbox != nullptr && scenes->crowd_scenes == A) : (scenes->edges && scenes->edge_off),
+  EGX_REQUIRE(cfg->scene_kind == 2 ? (scenes->crowd_bbox != nullptr && scenes->crowd_scenes == A &&
+                                      (!scenes->crowd_polygon || (scenes->edges && scenes->edge_off)))
+                                   : (scenes->edges && scenes->edge_off),
               "scene tables missing");
   ResetArgs p;
   p.cfg = to_cfg(cfg); p.sc = to_scene(scenes); p.A = A; p.K = io->num_candidates; p.mask = io->mask;

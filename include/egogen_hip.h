@@ -294,6 +294,9 @@ typedef struct egx_env_config {   /* cfg_samp20/MPVAEPolicy_samp_collision(_2).y
   int terminate_on_penetration; /* finetuning (crowd_env_2f.py:299-300) or box env (crowd_env_2f_box.py:325)       */
   int pene_type_body;           /* lossconfig.pene_type == 'body'                                                 */
   float ray_len;                /* 7 (2 when rendering), crowd_env_2f.py:556-558                                   */
+  float vp_thresh;              /* mean VPoser norm of an "unrealistic pose": 11 (crowd_env_2f.py:201); 14 in
+                                   crowd_env_egobody_eval.py:229.  <= 0 selects 11                                 */
+  int no_goal_termination;      /* 1: only max_depth ends an episode (crowd_env_egobody_eval.py:378)               */
 } egx_env_config;
 
 typedef struct egx_env_scenes { /* static scene tables, device pointers */
@@ -311,6 +314,10 @@ typedef struct egx_env_scenes { /* static scene tables, device pointers */
   int crowd_scenes;        /* S = num_agents of the call                                                    */
   int crowd_member;        /* k: which member the agents of this call are                                   */
   float crowd_floor_half;  /* 4.0 (crowd_env_crowd_eval.py:391)                                             */
+  int crowd_polygon;       /* 1: exterior = ring set edges[edge_off[0]..edge_off[1]) (the walkable region of the scene's
+                            * navmesh, crowd_env_egobody_eval.py:402,824) instead of the square floor               */
+  int crowd_static;        /* 1: the other members' boxes are not holes (effective behaviour of
+                            * crowd_env_egobody_eval.py:824 `Polygon(self.scene_poly, holes)`)            */
 } egx_env_scenes;
 
 typedef struct egx_env_state {  /* persistent per-agent state, device pointers, updated in place */
@@ -343,6 +350,9 @@ typedef struct egx_env_step_io {
   int32_t* nonfinite_count;  /* device counter or NULL: +1 per agent whose reward / target distance is not finite
                               * (the reference drops into pdb on NaN/Inf, crowd_env_2f.py:287-297; here the host polls
                               * the counter once per collect and raises) */
+  int32_t* invalid_flags;    /* [A] or NULL: |= 1 when a pelvis of the 20 frames leaves the scene polygon during the first
+                              * 5 steps (scene_kind 2 with crowd_polygon), |= 2 on an unrealistic pose - the two filters
+                              * on which crowd_env_egobody_eval.py:208-216,229-234 abandons the sequence               */
 } egx_env_step_io;
 
 typedef struct egx_env_reset_io {

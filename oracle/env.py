@@ -111,6 +111,17 @@ def _point_in_rings(px, py, edges: np.ndarray) -> bool:
     return bool(np.count_nonzero(cond & (px < xint)) % 2 == 1)
 
 
+def points_in_rings(edges: np.ndarray, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """Even-odd containment of points in a ring set given as edges[E,4] (float64) - shapely Polygon.contains up to
+    boundary measure-zero cases."""
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    x0, y0, x1, y1 = (edges[:, k][None, :] for k in range(4))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        straddle = (y0 > y[:, None]) != (y1 > y[:, None])
+        xint = x0 + (y[:, None] - y0) * (x1 - x0) / (y1 - y0)
+    return (np.sum(straddle & (x[:, None] < xint), axis=1) & 1) == 1
+
+
 def calc_egosensing(joints_w: torch.Tensor, edges: np.ndarray, ray_len: float = 7.0) -> torch.Tensor:
     """crowd_env_2f.py:524-613 for one agent.  joints_w[2,127,3] float32 (world), edges[E,4] float64.
     Returns float32[2,32] = -1 + 2*d/ray_len, d = distance from the eye mid-point to the first exit
@@ -229,6 +240,16 @@ class OracleCrowdEnv:
         self.crowd_boxes = np.asarray(boxes, np.float64)
         self.floor_half = float(floor_half)
 
+    def set_egobody(self, scene_edges, static=True, vp_thresh=14.0):
+        """crowd_env_egobody_eval.py: the exterior is the scene's walkable region (`scene_poly`, :402) instead of the square
+        floor; only max_depth terminates (:378); vp_norm > 14 (:229) and a pelvis outside the scene polygon during the first
+        5 steps (:208-216) abandon the sequence (flagged in last['invalid']).  `static`: `Polygon(self.scene_poly, holes)`
+        (:824) is called with a Polygon as shell, for which shapely returns the shell itself - the other person's box never
+        becomes a hole [PARITY UNPINNED: shapely absent here]; static=False gives the evidently intended polygon."""
+        self.ego_edges = np.asarray(scene_edges, np.float64)
+        self.ego_static = bool(static)
+        self.vp_thresh = float(vp_thresh)
+
     def own_bbox(self):
         """world-space xy box of the two seed frames' markers (crowd_env_crowd_eval.py:345-352)."""
         A = self.state.shape[0]
@@ -239,8 +260,10 @@ class OracleCrowdEnv:
 
     def _crowd_edges(self, a):
         h = self.floor_half
-        rects = [(-h, -h, h, h)] + [tuple(b) for b in self.crowd_boxes[a]]
-        es = []
+        ego = getattr(self, "ego_edges", None)
+        rects = ([] if ego is not None else [(-h, -h, h, h)]) + \
+                ([] if ego is not None and self.ego_static else [tuple(b) for b in self.crowd_boxes[a]])
+        es = [] if ego is None else [list(e) for e in ego]
         for (x0, y0, x1, y1) in rects:
             c = [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
             for q in range(4):
@@ -256,9 +279,13 @@ class OracleCrowdEnv:
         pts = torch.stack([xv, yv, torch.zeros_like(xv)], dim=2).reshape(1, -1, 3).repeat(A, 1, 1).to(R0.dtype)
         ps = torch.einsum("bij,bpj->bpi", R0, pts) + T0
         px, py = ps[:, :, 0], ps[:, :, 1]
-        walk = (px.abs() < self.floor_half) & (py.abs() < self.floor_half)
+        ego = getattr(self, "ego_edges", None)
+        if ego is None:
+            walk = (px.abs() < self.floor_half) & (py.abs() < self.floor_half)
+        else:
+            walk = torch.as_tensor(points_in_rings(ego, px.double().numpy().ravel(), py.double().numpy().ravel())).reshape(px.shape)
         for a in range(A):
-            for b in self.crowd_boxes[a]:
+            for b in ([] if ego is not None and self.ego_static else self.crowd_boxes[a]):
                 inside = (px[a] >= b[0]) & (px[a] <= b[2]) & (py[a] >= b[1]) & (py[a] <= b[3])
                 walk[a] &= ~inside
         local_map = walk.to(R0.dtype)
@@ -326,7 +353,8 @@ class OracleCrowdEnv:
         # ---- vposer (:196-204) ----
         emb = nets.vposer_encode(self.vposer_sd, pred_params[:, :, 6:69].reshape(A * T_ALL, -1))
         vp_norm = torch.norm(emb.reshape(A, T_ALL, -1), dim=-1).mean(dim=1)
-        r_vp = torch.where(vp_norm > 11, torch.zeros_like(vp_norm), torch.full_like(vp_norm, 0.05))
+        vp_thresh = getattr(self, "vp_thresh", 11.0)
+        r_vp = torch.where(vp_norm > vp_thresh, torch.zeros_like(vp_norm), torch.full_like(vp_norm, 0.05))
         # ---- facing (:206-219) ----
         je = pred_joints[:, -1]
         x_axis = (je[:, 2, :] - je[:, 1, :]).clone()
@@ -394,7 +422,15 @@ class OracleCrowdEnv:
         ego = torch.stack([calc_egosensing(jw[a], self._edges_for(a)) for a in range(A)]).to(dt)
 
         at_depth = self.steps == cfg["max_depth"]
-        if self.scene_kind == "crowd":
+        if self.scene_kind == "crowd" and getattr(self, "ego_edges", None) is not None:
+            terminated = at_depth                                          # crowd_env_egobody_eval.py:378
+            invalid = (vp_norm > vp_thresh).long() * 2
+            pel_w = (torch.einsum("bij,btj->bti", R0, joints_all[:, :, 0]) + T0).double().numpy()
+            for a in range(A):
+                if int(self.steps[a]) < 6 and not points_in_rings(self.ego_edges, pel_w[a, :, 0], pel_w[a, :, 1]).all():
+                    invalid[a] |= 1
+            self.last["invalid"] = invalid
+        elif self.scene_kind == "crowd":
             terminated = (r_goal > 0) | at_depth                           # crowd_env_crowd_eval.py:367
         elif self.scene_kind == "box" or self.finetuning:
             terminated = (r_goal > 0) | penetration | at_depth

@@ -362,3 +362,81 @@ def test_episode_without_resync_reports_drift():
     print("\nstep  |dY| gpu-o32  o32-o64   |dJ| gpu-o32  o32-o64   |dreward|  max|dcount|  near-zero")
     for r in rows:
         print("%4d  %.2e     %.2e  %.2e     %.2e  %.2e  %6d  %6d" % r)
+
+
+@pytest.mark.parametrize("static_scene", [True, False])
+def test_egobody_pair_matches_oracle(static_scene):
+    """crowd_env_egobody_eval.py (main_egobody_eval.py): two members per scene inside the walkable polygon of a navmesh
+    (the in-tree Replica room_0 navmesh, 6 rings), per-member motion seed and random shape, only max_depth terminates, the
+    pose filter sits at 14, a pelvis outside the polygon during the first steps flags the sequence.  static_scene=True is
+    what the reference's `Polygon(self.scene_poly, holes)` evaluates to (the other person is not a hole); False adds the
+    other member's marker box as a hole."""
+    from egogen_amd.crowd_env import CrowdGroupEnv
+    from egogen_amd.egobody import EgobodySampler
+    from oracle.env import OracleCrowdEnv
+    from oracle.smplx_lbs import BodyModel
+    S, G = 3, 2
+    w = build_world(V=1536, A=2, scene_kind="sdf", n_pairs=4)   # only for the shared assets / operators
+    env0 = w["env"]
+    a = synth.load_assets()
+    sampler = EgobodySampler(a["room0_nav_v"], a["room0_nav_f"], [{"poses": a["seed_poses"], "trans": a["seed_trans"]}], seed=11)
+    pairs = [sampler.next_body() for _ in range(S)]
+    st = np.stack([np.stack([pairs[s][k]["wpath"] for s in range(S)]) for k in range(G)])
+    if not static_scene:   # bring the two people close enough for the boxes to matter
+        st[1, :, 0] = st[0, :, 0] + (st[0, :, 1] - st[0, :, 0]) * (0.9 / np.linalg.norm(st[0, :, 1] - st[0, :, 0], axis=-1, keepdims=True))
+        st[1, :, 1] = st[0, :, 0]
+        st[0, :, 1] = st[1, :, 0]
+    seeds = [[pairs[s][k]["seed"] for s in range(S)] for k in range(G)]
+    grp = CrowdGroupEnv(S, st, w["handle"], env0.prior, env0.vposer, seed=5, scene_rings=sampler.rings, static_scene=static_scene,
+                        agent_seeds=seeds, vp_thresh=14.0, goal_terminates=False)
+    rng = np.random.default_rng(4)
+    yaw = (rng.uniform(-1, 1, (G, S)) * 2 * np.pi * 0.2).astype(np.float32)
+    for k, m in enumerate(grp.members):
+        m.set_candidates(st[k].reshape(S, 1, 2, 3), yaw[k], np.arange(S))
+        m._launch_reset(None)
+    for k, m in enumerate(grp.members):
+        m._launch_reset(None)
+    torch.cuda.synchronize()
+    if static_scene:   # sampled starts have 0.3 m of clearance: every eye is inside the scene polygon and sees its walls
+        for m in grp.members:
+            assert float(m.obs_ego.amax(dim=(1, 2)).min()) > -1.0 and float(m.obs_ego.min()) < 1.0
+    edges = synth.rings_to_edges(sampler.rings).astype(np.float32).astype(np.float64)   # the kernel's float32 table
+    oracles, boxes = [], np.zeros((G, S, 4))
+    for k in range(G):
+        o = OracleCrowdEnv(BodyModel(w["bm"]), w["prior_sd"], {kk: v.float() for kk, v in w["vposer_sd"].items()}, w["mk"], w["feet"],
+                           synth.feet_marker_idx(), scene_kind="crowd")
+        o.set_egobody(edges, static=static_scene, vp_thresh=14.0)
+        poses = torch.tensor(np.stack([d["poses"] for d in seeds[k]]), dtype=torch.float32)
+        trans = torch.tensor(np.stack([d["trans"] for d in seeds[k]]), dtype=torch.float32)
+        betas = torch.tensor(np.stack([d["betas"] for d in seeds[k]]), dtype=torch.float32)
+        tr, go, bp, wp = o.next_body(torch.as_tensor(st[k, :, 0]), torch.as_tensor(st[k, :, 1]), poses, trans, betas,
+                                     yaw_jitter=torch.as_tensor(yaw[k]))
+        o.set_crowd_boxes(np.zeros((S, G - 1, 4)))
+        o.reset_from(tr, go, bp, betas, wp)
+        boxes[k] = o.own_bbox().numpy()
+        _close(grp.members[k].betas, betas, 0, "per-member betas")
+        oracles.append(o)
+    _close(grp.bbox, boxes, 1e-4, "initial boxes")
+    g = torch.Generator().manual_seed(9)
+    saw_goal = False
+    flags = [torch.zeros(S, dtype=torch.long) for _ in range(G)]
+    for it in range(2):
+        for k in range(G):
+            m, o = grp.members[k], oracles[k]
+            o.set_state(m.state.cpu(), m.seed.cpu(), m.R0.cpu(), m.T0.cpu().reshape(-1, 1, 3), m.betas.cpu(), m.dist.cpu(),
+                        m.steps.cpu(), m.wpath.cpu(), None)
+            boxes = grp.bbox.cpu().numpy().astype(np.float64)
+            o.set_crowd_boxes(np.stack([boxes[j] for j in range(G) if j != k], axis=1))
+            z = torch.randn(S, 128, generator=g) * (3.0 if it == 1 else 1.0)
+            obs, rew, term = m.step(z.cuda(), auto_reset=False)
+            oobs, orew, oterm = o.step(z)
+            _close(m.rterms[:, 6], o.last["r_pene"], 1e-6, f"r_pene member {k}")
+            _close(m.rterms[:, 7], o.last["r_vp"], 1e-6, f"r_vp member {k}")
+            _close(rew, orew, 3e-4, f"reward member {k}")
+            assert term.cpu().bool().tolist() == oterm.tolist() and not term.any()       # two steps < max_depth
+            saw_goal |= bool((o.last["r_goal"] > 0).any())
+            _close(obs["egosensing"], oobs["egosensing"], 2e-4, f"egosensing member {k}")
+            flags[k] |= o.last["invalid"]                                                # the kernel ORs over the steps
+            assert m.invalid.cpu().tolist() == flags[k].tolist()
+    if not static_scene:   # the other member's box must shorten some ray / block some cell in this layout
+        assert float(grp.members[0].obs_ego.min()) < 0.5

@@ -233,6 +233,31 @@ def test_main_crowd_eval_entry_point(tmp_path):
     assert d["motion"][0]["blended_marker"].shape == (20, 67, 3) and d["wpath"].shape == (2, 3)
 
 
+def test_main_egobody_eval_entry_point(tmp_path):
+    """crowd_ppo/main_egobody_eval.py drop-in: two people per scene, male and female pairs, ./egobody_tmp_res/<member>.pkl in
+    the reference's layout with exactly max_depth primitives each (only max_depth terminates); flagged sequences are dropped
+    unless --keep-invalid (random weights leave the walkable polygon at once)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "crowd_ppo", "main_egobody_eval.py"), "--num-scenes", "5", "--num-verts", "1024",
+           "--seed", "2", "--keep-invalid"]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "Final reward:" in r.stdout and "5 scene(s) written" in r.stdout
+    pk = sorted((tmp_path / "egobody_tmp_res").glob("motion_s*_*.pkl"))
+    assert len(pk) == 10
+    genders = set()
+    for f in pk:
+        d = pickle.load(open(f, "rb"))
+        assert len(d["motion"]) == 11 and d["wpath"].shape == (2, 3) and d["navmesh_path"].endswith("navmesh_tight.ply")
+        mp = d["motion"][0]
+        assert mp["blended_marker"].shape == (20, 67, 3) and mp["smplx_params"].shape == (1, 20, 93) and mp["betas"].shape == (10,)
+        genders.add(mp["gender"])
+    assert genders == {"male", "female"}
+    a, b = (pickle.load(open(tmp_path / "egobody_tmp_res" / f"motion_s0_{k}.pkl", "rb")) for k in (0, 1))
+    assert np.allclose(a["wpath"][0, :2], b["wpath"][1, :2], atol=1e-5) and a["motion"][0]["gender"] == b["motion"][0]["gender"]
+    assert not np.array_equal(a["motion"][0]["betas"], b["motion"][0]["betas"])
+
+
 def test_crowd_eval_bf16_policy_is_statistically_equivalent(tmp_path):
     """Config 5 (bf16 policy): episode statistics over 64 four-human scenes (256 humans) against the fp32 policy, same
     seeds - statistical parity, not 1e-4."""
