@@ -113,6 +113,7 @@ SIGNATURES = {
     "egx_canonical_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egx_update_transl_glorot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "egx_sdf_sample": (C.c_int, [C.POINTER(SdfGrid), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "egx_mesh_sdf": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "egx_sdf_coarse_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "egx_sdf_build_coarse": (C.c_int, [C.POINTER(SdfGrid), C.c_void_p, C.c_void_p]),
     "egx_linear": (C.c_int, [C.POINTER(LinearDesc), C.c_void_p]),

@@ -67,3 +67,114 @@ extern "C" int egx_sdf_sample(const egx_sdf_grid* sdf, const float* pts, int64_t
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Scene preparation: signed-distance grid of a closed triangle mesh in the storage convention of
+// `sdf_dict` (crowd_ppo/utils.py:54-84): grid[d0][d1][d2] indexed by (x, y, z), sample (i, j, k) at the cell centre
+// center + ((2 i + 1) / d - 1) / scale (grid_sample, align_corners=False).  The reference ships room0_sdf.pkl ready-made
+// and has no generator in its tree (README.md:97); this is the tool for new scenes.
+// One sample per lane; the triangles stream through LDS in chunks every lane reads in lock step (broadcast reads).
+// Distance: exact closest point on each triangle (Voronoi-region walk).  Sign: crossing parity of the +z ray, each
+// edge's crossing evaluated from its endpoints in canonical order, so the two triangles sharing an edge always agree on
+// which of them a ray through that edge hits (watertight rule) - no epsilon, no jitter.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int MESH_CHUNK = 512;
+
+__device__ __forceinline__ float tri_dist2(const float* t, float px, float py, float pz) {
+  const float ax = t[0], ay = t[1], az = t[2];
+  const float abx = t[3] - ax, aby = t[4] - ay, abz = t[5] - az;
+  const float acx = t[6] - ax, acy = t[7] - ay, acz = t[8] - az;
+  const float apx = px - ax, apy = py - ay, apz = pz - az;
+  const float d1 = abx * apx + aby * apy + abz * apz, d2 = acx * apx + acy * apy + acz * apz;
+  float cx, cy, cz;  // closest point - a
+  if (d1 <= 0.f && d2 <= 0.f) {
+    cx = cy = cz = 0.f;
+  } else {
+    const float bpx = apx - abx, bpy = apy - aby, bpz = apz - abz;
+    const float d3 = abx * bpx + aby * bpy + abz * bpz, d4 = acx * bpx + acy * bpy + acz * bpz;
+    const float cpx = apx - acx, cpy = apy - acy, cpz = apz - acz;
+    const float d5 = abx * cpx + aby * cpy + abz * cpz, d6 = acx * cpx + acy * cpy + acz * cpz;
+    const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d3 >= 0.f && d4 <= d3) {
+      cx = abx; cy = aby; cz = abz;
+    } else if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
+      const float v = d1 / (d1 - d3);
+      cx = v * abx; cy = v * aby; cz = v * abz;
+    } else if (d6 >= 0.f && d5 <= d6) {
+      cx = acx; cy = acy; cz = acz;
+    } else if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
+      const float w = d2 / (d2 - d6);
+      cx = w * acx; cy = w * acy; cz = w * acz;
+    } else if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+      const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+      cx = abx + w * (acx - abx); cy = aby + w * (acy - aby); cz = abz + w * (acz - abz);
+    } else {
+      const float den = 1.f / (va + vb + vc);
+      const float v = vb * den, w = vc * den;
+      cx = abx * v + acx * w; cy = aby * v + acy * w; cz = abz * v + acz * w;
+    }
+  }
+  const float dx = apx - cx, dy = apy - cy, dz = apz - cz;
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// does the projection of edge (p, q) onto the xy plane cross the +x half line from (x, y)?  canonical endpoint order
+__device__ __forceinline__ bool edge_cross(float px, float py, float qx, float qy, float x, float y) {
+  if (py > qy || (py == qy && px > qx)) { float t = px; px = qx; qx = t; t = py; py = qy; qy = t; }
+  if ((py > y) == (qy > y)) return false;
+  return x < px + (y - py) * (qx - px) / (qy - py);
+}
+
+__global__ __launch_bounds__(256) void egx_mesh_sdf_kernel(const float* __restrict__ tris, int F, float cx, float cy, float cz, float inv_scale,
+                                                          int d0, int d1, int d2, int inside_positive, float* __restrict__ out) {
+  __shared__ float s_t[MESH_CHUNK * 9];
+  const size_t n = (size_t)d0 * d1 * d2;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t id = idx < n ? idx : n - 1;
+  const int k = (int)(id % d2), j = (int)((id / d2) % d1), i = (int)(id / ((size_t)d1 * d2));
+  const float px = cx + ((2 * i + 1) / (float)d0 - 1.f) * inv_scale;
+  const float py = cy + ((2 * j + 1) / (float)d1 - 1.f) * inv_scale;
+  const float pz = cz + ((2 * k + 1) / (float)d2 - 1.f) * inv_scale;
+  float best = 3.4e38f;
+  int parity = 0;
+  for (int f0 = 0; f0 < F; f0 += MESH_CHUNK) {
+    const int nf = min(MESH_CHUNK, F - f0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nf * 9; e += 256) s_t[e] = tris[(size_t)f0 * 9 + e];
+    __syncthreads();
+    for (int f = 0; f < nf; ++f) {
+      const float* t = s_t + f * 9;
+      best = fminf(best, tri_dist2(t, px, py, pz));
+      // the vertical line through (px, py) meets the triangle iff (px, py) is inside its projection (odd crossings)
+      const bool in = edge_cross(t[0], t[1], t[3], t[4], px, py) ^ edge_cross(t[3], t[4], t[6], t[7], px, py) ^
+                      edge_cross(t[6], t[7], t[0], t[1], px, py);
+      if (in) {
+        const float ux = t[3] - t[0], uy = t[4] - t[1], uz = t[5] - t[2];
+        const float vx = t[6] - t[0], vy = t[7] - t[1], vz = t[8] - t[2];
+        const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+        if (nz != 0.f) {
+          const float zt = t[2] - (nx * (px - t[0]) + ny * (py - t[1])) / nz;
+          parity ^= (zt > pz) ? 1 : 0;
+        }
+      }
+    }
+  }
+  if (idx < n) {
+    const float d = sqrtf(best);
+    out[idx] = ((parity != 0) == (inside_positive != 0)) ? d : -d;
+  }
+}
+}  // namespace
+
+extern "C" int egx_mesh_sdf(const float* triangles, int num_triangles, const float* center_host, float scale, int d0, int d1, int d2,
+                            int inside_positive, float* out_grid, void* stream_) {
+  EGX_REQUIRE(triangles && center_host && out_grid && num_triangles > 0, "null mesh / centre / grid");
+  EGX_REQUIRE(scale > 0.f && egx_sdf_dims_ok(d0, d1, d2), "scale must be positive, the grid needs d2 >= 2 and fewer than 2^32 samples");
+  const size_t n = (size_t)d0 * d1 * d2;
+  hipLaunchKernelGGL(egx_mesh_sdf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     triangles, num_triangles, center_host[0], center_host[1], center_host[2], 1.f / scale, d0, d1, d2, inside_positive,
+                     out_grid);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}

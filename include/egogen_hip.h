@@ -160,6 +160,17 @@ int egx_update_transl_glorot(const float* R, const float* T, int num_frames, con
  */
 int egx_sdf_sample(const egx_sdf_grid* sdf, const float* pts, int64_t n, float* out, void* stream);
 
+/*
+ * egx_mesh_sdf - scene preparation (the reference ships data/room0_sdf.pkl ready-made and refers to an
+ * external tool for new scenes, README.md:97): fills grid[d0][d1][d2] (indexed by x, y, z; sample (i,j,k) at
+ * center + ((2i+1)/d - 1) / scale, the cell centres `calc_sdf`'s grid_sample(align_corners=False) assumes,
+ * crowd_ppo/utils.py:54-84) with the signed distance to a closed triangle mesh.
+ *   triangles [F,9] device (ax,ay,az,bx,by,bz,cx,cy,cz); center_host [3] host; inside_positive 1: > 0 inside the mesh
+ *   (obstacle solids, the stored convention: calc_sdf negates), 0: < 0 inside (a room shell whose interior is free space).
+ */
+int egx_mesh_sdf(const float* triangles, int num_triangles, const float* center_host, float scale, int d0, int d1, int d2,
+                 int inside_positive, float* out_grid, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense layers of the rollout networks.  One fused call replaces nn.Linear + torch.cat + activation
  * (+ residual) as composed in models/baseops.py:615-641 (MLP), models_GAMMA_primitive.py:160-175
