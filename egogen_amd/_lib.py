@@ -146,6 +146,7 @@ SIGNATURES = {
     "egx_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egx_adv_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "egx_track_episode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egx_rollout_store": (C.c_int, [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 10),
     "egx_adamw_workspace_floats": (C.c_size_t, []),
     "egx_adamw_clip_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float] + [C.c_double] * 5 +
                             [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -221,6 +221,52 @@ __global__ __launch_bounds__(256) void egx_track_episode_kernel(const float* __r
   if (threadIdx.x < 3) done_sums[threadIdx.x] += s[threadIdx.x][0];
 }
 
+// One launch per vector step of the collector instead of seven copies + the bookkeeping kernel: the observation the
+// environment just produced goes into rollout slot t+1, reward / termination flag into slot t, and the extra workgroup
+// (blockIdx == A) runs the episode bookkeeping above.
+__global__ __launch_bounds__(256) void egx_rollout_store_kernel(const float* __restrict__ state, const float* __restrict__ ego,
+                                                                const float* __restrict__ dist, const float* __restrict__ time,
+                                                                const float* __restrict__ rew, const int* __restrict__ term, int A,
+                                                                float* __restrict__ state_dst, float* __restrict__ ego_dst,
+                                                                float* __restrict__ dist_dst, float* __restrict__ time_dst,
+                                                                float* __restrict__ rew_dst, int* __restrict__ term_dst,
+                                                                float* __restrict__ ep_ret, float* __restrict__ ep_len,
+                                                                float* __restrict__ done_sums) {
+  const int a = blockIdx.x;
+  if (a < A) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(state + (size_t)a * 804);   // 804 = 201 float4
+    f32x4* d4 = reinterpret_cast<f32x4*>(state_dst + (size_t)a * 804);
+    if (threadIdx.x < 201) d4[threadIdx.x] = s4[threadIdx.x];
+    else if (threadIdx.x < 217) {
+      const int e = threadIdx.x - 201;
+      reinterpret_cast<f32x4*>(ego_dst + (size_t)a * 64)[e] = reinterpret_cast<const f32x4*>(ego + (size_t)a * 64)[e];
+    } else if (threadIdx.x == 217) {
+      dist_dst[a] = dist[a];
+      time_dst[a] = time[a];
+      if (rew_dst) { rew_dst[a] = rew[a]; term_dst[a] = term[a]; }
+    }
+    return;
+  }
+  if (!ep_ret) return;
+  __shared__ float s[3][256];
+  float x = 0.f, y = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < A; i += 256) {
+    const float r = ep_ret[i] + rew[i], l = ep_len[i] + 1.f;
+    const bool d = term[i] != 0;
+    if (d) { x += r; y += l; c += 1.f; }
+    ep_ret[i] = d ? 0.f : r;
+    ep_len[i] = d ? 0.f : l;
+  }
+  s[0][threadIdx.x] = x; s[1][threadIdx.x] = y; s[2][threadIdx.x] = c;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int k = 0; k < 3; ++k) s[k][threadIdx.x] += s[k][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) done_sums[threadIdx.x] += s[threadIdx.x][0];
+}
+
 // ---- optimiser step over flat buffers: gradient-norm clip of a prefix + AdamW (torch.optim.AdamW semantics) ----------
 // pass 1: per-block partial sums of squares of g[0..n_clip) (double accumulation, fixed order -> deterministic); block 0
 // also advances the step counter, so that pass 2 (a later kernel on the same stream) reads the new value everywhere.
@@ -393,6 +439,19 @@ extern "C" int egx_track_episode(const float* rew, const int32_t* term, int num_
   EGX_REQUIRE(rew && term && ep_ret && ep_len && done_sums && num_agents > 0, "bad arguments");
   hipLaunchKernelGGL(egx_track_episode_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), rew, term, num_agents,
                      ep_ret, ep_len, done_sums);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_rollout_store(const float* state, const float* egosensing, const float* dist, const float* time, const float* rew,
+                                 const int32_t* term, int num_agents, float* state_dst, float* ego_dst, float* dist_dst, float* time_dst,
+                                 float* rew_dst, int32_t* term_dst, float* ep_ret, float* ep_len, float* done_sums, void* stream_) {
+  EGX_REQUIRE(state && egosensing && dist && time && state_dst && ego_dst && dist_dst && time_dst && num_agents > 0, "bad arguments");
+  EGX_REQUIRE((!rew_dst && !term_dst && !ep_ret) || (rew && term && rew_dst && term_dst), "reward / termination source or slot missing");
+  EGX_REQUIRE(!ep_ret || (ep_len && done_sums && rew && term), "episode bookkeeping needs ep_len, done_sums, rew, term");
+  hipLaunchKernelGGL(egx_rollout_store_kernel, dim3(num_agents + (ep_ret ? 1 : 0)), dim3(256), 0, static_cast<hipStream_t>(stream_), state,
+                     egosensing, dist, time, rew, term, num_agents, state_dst, ego_dst, dist_dst, time_dst, rew_dst, term_dst, ep_ret, ep_len,
+                     done_sums);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

@@ -92,8 +92,20 @@ class Collector:
         if b is None:
             b = RolloutBatch(n_vec_steps, self.A, self.env.dev)
             self._batches[n_vec_steps] = b
+        fused = self._episodes is None and self.obs["state"].is_cuda
+        if fused:
+            from . import _lib
+            lib, ptr = _lib.load(), _lib.ptr
+            store = lambda o, t1, rew, term, t0: _lib.check(lib.egx_rollout_store(
+                ptr(o["state"]), ptr(o["egosensing"]), ptr(o["dist"]), ptr(o["time"]), ptr(rew) if rew is not None else None,
+                ptr(term) if term is not None else None, self.A, ptr(b.state[t1]), ptr(b.ego[t1]), ptr(b.dist[t1]), ptr(b.time[t1]),
+                ptr(b.rew[t0]) if rew is not None else None, ptr(b.term[t0]) if rew is not None else None,
+                ptr(self.ep_ret) if rew is not None else None, ptr(self.ep_len), ptr(self._done), _lib.current_stream_ptr()),
+                "egx_rollout_store")
+            store(self.obs, 0, None, None, 0)
         for t in range(n_vec_steps):
-            b.store_obs(t, self.obs)
+            if not fused:
+                b.store_obs(t, self.obs)
             # the policy writes straight into the rollout slot of this step
             out = self.policy(self.obs, out={"act": b.act[t], "mu": b.mu[t], "logvar": b.logvar[t], "logp": b.logp_old[t],
                                              "value": b.values[t]})
@@ -105,11 +117,16 @@ class Collector:
                 self.env.reset(mask=term)
             else:
                 obs, rew, term = self.env.step(out["act"])
-            b.rew[t].copy_(rew)
-            b.term[t].copy_(term)
-            self._track(rew, term)
+            if fused:
+                # one launch: next observation -> slot t+1, reward / termination -> slot t, episode bookkeeping
+                store(obs, t + 1, rew, term, t)
+            else:
+                b.rew[t].copy_(rew)
+                b.term[t].copy_(term)
+                self._track(rew, term)
             self.obs = obs
-        b.store_obs(n_vec_steps, self.obs)
+        if not fused:
+            b.store_obs(n_vec_steps, self.obs)
         b.rollout_values_valid = True
         return b
 

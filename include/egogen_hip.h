@@ -472,6 +472,12 @@ int egx_adv_stats(const float* adv, int n, float* out_mean_std, void* stream);
  * episode count} and the running values reset. */
 int egx_track_episode(const float* rew, const int32_t* term, int num_agents, float* ep_ret, float* ep_len, float* done_sums,
                       void* stream);
+/* The same bookkeeping fused with the collector's per-step stores (tianshou Collector.collect [upstream] -> ReplayBuffer.add,
+ * main_ppo.py:177-183): obs (state [A,2,402], egosensing [A,2,32], dist [A], time [A]) -> rollout slot t+1, reward / terminated
+ * -> slot t.  rew_dst / term_dst / ep_ret may be NULL (the first observation of a collect has no reward yet). */
+int egx_rollout_store(const float* state, const float* egosensing, const float* dist, const float* time, const float* rew,
+                      const int32_t* term, int num_agents, float* state_dst, float* ego_dst, float* dist_dst, float* time_dst,
+                      float* rew_dst, int32_t* term_dst, float* ep_ret, float* ep_len, float* done_sums, void* stream);
 
 /* One optimiser step of GAMMAPPOPolicy.learn (ppo_policy.py:243-247: clip_grad_norm_ over the actor+critic parameters,
  * optim.step() with the AdamW of main_ppo.py:134) over FLAT fp32 buffers of n elements: the gradient norm of the first
