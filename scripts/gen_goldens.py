@@ -14,6 +14,10 @@ imported, never called, on these code paths - SURVEY.md section 8(c)):
   crowd_ppo/crowd_env_2f_box.py::CrowdEnv._get_feature (with the walkability map) and
   exp_GAMMAPrimitive/utils/batch_gen_amass.py::get_map                   -> getmap_ref.npz
   crowd_ppo/utils.py::save_rollout_results                               -> rollout_ref.npz + rollout_ref.pkl
+  exp_GAMMAPrimitive/utils/utils_canonicalize_samp.py::canonicalize_subsequence (`python scripts/gen_goldens.py canonicalize`)
+      -> canonicalize_ref.npz.  The script builds smplx body models at import; `smplx.create` is replaced by an adapter around
+      oracle/smplx_lbs.py on the synthetic full-size model (smplx itself is absent), so the fixture pins the SCRIPT's arithmetic
+      (frame of the first body, pelvis-offset correction, scipy rotations, which joints / vertices are saved), not smplx.
 get_map hard-codes device='cuda' / torch.cuda.FloatTensor; `cuda_to_cpu()` below redirects exactly those two spellings to the
 CPU for the duration of the call (placement only - the arithmetic executed is the reference's).
 """
@@ -357,5 +361,75 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def gen_canonicalize():
+    import pickle
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from egogen_amd import synth
+    from oracle.smplx_lbs import BodyModel, smplx_forward
+    install_stubs()
+    install_env_stubs()
+    bm = BodyModel(synth.make_body_model(0))
+
+    class _Out:
+        pass
+
+    class _FakeSMPLX:
+        """smplx.SMPLX call signature as the script uses it (keyword tensors, batch inferred) on the oracle LBS."""
+
+        def cuda(self):
+            return self
+
+        def __call__(self, return_verts=True, transl=None, global_orient=None, body_pose=None, betas=None, **kw):
+            n = max(t.shape[0] for t in (transl, global_orient, body_pose, betas) if t is not None)
+            xb = torch.zeros(n, 93)
+            if transl is not None:
+                xb[:, :3] = transl
+            if global_orient is not None:
+                xb[:, 3:6] = global_orient
+            if body_pose is not None:
+                xb[:, 6:69] = body_pose
+            b = torch.zeros(n, 10) if betas is None else betas.reshape(-1, 10).expand(n, 10)
+            v, j = smplx_forward(bm, xb.to(bm.dtype), b.to(bm.dtype))
+            o = _Out()
+            o.vertices, o.joints = v.float(), j.float()
+            return o
+    sys.modules["smplx"].create = lambda *a, **k: _FakeSMPLX()
+    g = np.random.default_rng(17)
+    n = 3 * 40 + 7                                   # two 20-frame primitives after the x3 down-sampling, plus a tail
+    pose = np.zeros((n, 165))
+    pose[:, :66] = np.cumsum(g.normal(0, 0.02, (n, 66)), 0) + g.normal(0, 0.25, (1, 66))
+    pose[:, :3] += np.array([1.3, 0.2, -0.4])       # a global orientation away from identity
+    trans = np.cumsum(g.normal(0, 0.01, (n, 3)), 0) + np.array([0.7, -1.1, 0.95])
+    betas = g.normal(0, 0.6, 16)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda t, *a, **k: t
+    cwd = os.getcwd()
+    try:
+        os.chdir(REF)                               # the script opens data/CMU.json and data/SSM2.json relative to motion/
+        sys.path.insert(0, REF)
+        with tempfile.TemporaryDirectory() as td:
+            seq = os.path.join(td, "locomotion_test_stageII.pkl")
+            with open(seq, "wb") as f:
+                pickle.dump({"mocap_framerate": 120.0, "pose_est_trans": trans, "pose_est_fullposes": pose, "shape_est_betas": betas}, f)
+            from exp_GAMMAPrimitive.utils import utils_canonicalize_samp as ucs
+            with cuda_to_cpu():
+                outs = [ucs.canonicalize_subsequence(seq, s, s + 60) for s in (0, 60)]
+                tail = ucs.canonicalize_subsequence(seq, 120, 180)
+    finally:
+        os.chdir(cwd)
+        torch.Tensor.cuda = real_cuda
+    assert tail is None
+    flat = {"in_trans": trans, "in_poses": pose, "in_betas": betas, "body_model_seed": np.int64(0), "cmu_ids": np.asarray(ucs.marker_cmu_41),
+            "ssm_ids": np.asarray(ucs.marker_ssm_67)}
+    for i, d in enumerate(outs):
+        for k, v in d.items():
+            flat[f"out{i}_{k}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "canonicalize_ref.npz"), **flat)
+    print("canonicalize_ref", {k: (np.asarray(v).shape, np.asarray(v).dtype) for k, v in outs[0].items()})
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["canonicalize"]:
+        sys.exit(gen_canonicalize())
     main()

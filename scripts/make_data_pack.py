@@ -7,6 +7,7 @@ walkable polygon / navmesh / start-target pairs), no reference source text.
 
 Sources (reference file -> key):
   data/SSM2.json                         -> marker_names, marker_ids   (main_ppo.py:296-300)
+  data/CMU.json                          -> cmu_marker_ids             (exp_GAMMAPrimitive/utils/utils_canonicalize_samp.py:117-118)
   data/smplx_vert_segmentation.json      -> feet_vids, part_names, vert_part (crowd_env_2f.py:53-59)
   data/locomotion/subseq_00343.npz       -> seed_*                     (environments.py:61-62,188-194)
   data/replica_room0_shapely.pkl         -> room0_ring_xy, room0_ring_off (environments.py:59-60)
@@ -78,6 +79,7 @@ def main():
     ssm = json.load(open(f"{REF}/SSM2.json"))["markersets"][0]["indices"]
     out["marker_names"] = np.array(list(ssm.keys()))
     out["marker_ids"] = np.array(list(ssm.values()), np.int32)
+    out["cmu_marker_ids"] = np.array(list(json.load(open(f"{REF}/CMU.json"))["markersets"][0]["indices"].values()), np.int32)
     seg = json.load(open(f"{REF}/smplx_vert_segmentation.json"))
     feet = []
     for part in ["leftToeBase", "rightToeBase", "leftFoot", "rightFoot"]:

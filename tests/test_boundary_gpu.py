@@ -333,3 +333,53 @@ def test_main_ppo_watch_room0_one_agent(tmp_path):
     with open(pk[0], "rb") as f:
         node = pickle.load(f)
     assert node["wpath"].shape == (2, 3) and node["motion"][0]["blended_marker"].shape == (20, 67, 3)
+
+
+def test_canonicalize_samp_matches_reference_golden(tmp_path):
+    """exp_GAMMAPrimitive/utils/utils_canonicalize_samp.py on the GPU operators (get_new_coordinate, update_transl_glorot,
+    SMPL-X forward) against the outputs of the reference's own script on the same synthetic SAMP pickle
+    (tests/golden/canonicalize_ref.npz, body model = synthetic full size), then the file loop: names, keys, dtypes, and that the
+    marker-predictor's batch generator reads what was written."""
+    import pickle
+    from egogen_amd.body_model import BodyModelHandle, SMPLXParser
+    from egogen_amd.canonicalize import canonicalize_frames, canonicalize_samp
+    from egogen_amd.train_predictor import BatchGeneratorAMASSCanonicalized
+    from tests.helpers import load_golden
+    g = load_golden("canonicalize_ref.npz")
+    h = BodyModelHandle(synth.make_body_model(int(g["body_model_seed"])), synth.marker_ids(), synth.feet_vids())
+    parser = SMPLXParser({"n_batch": 20, "device": "cuda", "marker_placement": "ssm2_67", "body_models": {"male": h}})
+    for i, s in enumerate((0, 60)):
+        d = canonicalize_frames(parser, g["in_trans"][s:s + 60:3], g["in_poses"][s:s + 60:3], g["in_betas"])
+        for k, tol in (("transf_rotmat", 1e-5), ("transf_transl", 1e-5), ("trans", 1e-4), ("betas", 0), ("joints", 1e-4),
+                       ("marker_cmu_41", 1e-4), ("marker_ssm2_67", 1e-4)):
+            ref = g[f"out{i}_{k}"]
+            assert d[k].shape == ref.shape and d[k].dtype == ref.dtype, (k, d[k].dtype, ref.dtype)
+            assert np.abs(d[k].astype(np.float64) - ref).max() <= tol * max(1.0, np.abs(ref).max()), (i, k)
+        # axis-angle vectors are compared as rotations (the reference goes through scipy, the kernel through torchgeometry's formulas)
+        from oracle.rot import tgm_angle_axis_to_rotation_matrix as aa2R
+        Ra, Rb = aa2R(torch.tensor(d["poses"][:, :3], dtype=torch.float64)), aa2R(torch.tensor(g[f"out{i}_poses"][:, :3], dtype=torch.float64))
+        assert float((Ra - Rb).abs().max()) < 1e-5
+        assert np.array_equal(d["poses"][:, 3:], g[f"out{i}_poses"][:, 3:]) and d["poses"].shape == (20, 165)
+    # the file loop of the script's __main__ (:192-290)
+    root = tmp_path / "samp"
+    root.mkdir()
+    for name, n in (("locomotion_a_stageII.pkl", 127), ("locomotion_b_stageII.pkl", 50), ("run_c_stageII.pkl", 190)):
+        k = min(n, len(g["in_trans"]))
+        reps = -(-n // k)
+        with open(root / name, "wb") as f:
+            pickle.dump({"mocap_framerate": 120.0, "pose_est_trans": np.tile(g["in_trans"][:k], (reps, 1))[:n],
+                         "pose_est_fullposes": np.tile(g["in_poses"][:k], (reps, 1))[:n], "shape_est_betas": g["in_betas"]}, f)
+    counts = canonicalize_samp(parser, 1, str(root), verbose=False)
+    assert counts["locomotion"] == 2 and counts["run"] == 3 and counts["chair"] == 0      # 43 -> 2, 17 -> skipped, 64 -> 3
+    files = sorted((root / "Canonicalized-MP" / "data" / "run").glob("subseq_*.npz"))
+    assert [f.name for f in files] == ["subseq_00000.npz", "subseq_00001.npz", "subseq_00002.npz"]
+    with np.load(files[0]) as z:
+        assert set(z.files) == {"transf_rotmat", "transf_transl", "trans", "poses", "betas", "gender", "mocap_framerate", "joints",
+                                "marker_cmu_41", "marker_ssm2_67"}                      # the keys of data/locomotion/subseq_00343.npz
+        assert z["joints"].dtype == np.float32 and z["trans"].dtype == np.float64 and z["transf_transl"].shape == (1, 3)
+    loco = sorted((root / "Canonicalized-MP" / "data" / "locomotion").glob("*.npz"))
+    with np.load(loco[0]) as z:
+        assert np.abs(z["marker_ssm2_67"] - g["out0_marker_ssm2_67"]).max() < 1e-4       # first file = frames 0, 3, .., 57 of sequence a
+    gen = BatchGeneratorAMASSCanonicalized(str(root / "Canonicalized-MP" / "data"), amass_subset_name=["locomotion", "run"], sample_rate=1)
+    gen.get_rec_list(shuffle_seed=0)
+    assert gen.data_all.shape[0] == 5 and gen.data_all.shape[2] == 201

@@ -171,3 +171,24 @@ def test_predictor_training_loss_and_gradients_match_reference():
     grads2 = torch.autograd.grad(loss2, [sd[k] for k in keys])
     for k, gr, n in zip(keys, grads2, g["roll_grad_norm"]):
         assert abs(float(gr.norm()) - n) <= 5e-5 * max(n, 1e-6) + 1e-9, k
+
+
+def test_canonicalize_restatement_matches_the_reference_script():
+    """oracle/canonicalize.py against what the reference's own canonicalize_subsequence (utils_canonicalize_samp.py:123-189)
+    returned for two back-to-back 20-frame sub-sequences of a synthetic SAMP pickle (scripts/gen_goldens.py canonicalize)."""
+    from egogen_amd import synth
+    from oracle.canonicalize import canonicalize_frames
+    from oracle.smplx_lbs import BodyModel
+    g = load_golden("canonicalize_ref.npz")
+    bm = BodyModel(synth.make_body_model(int(g["body_model_seed"])))
+    assert np.array_equal(g["cmu_ids"], synth.load_assets()["cmu_marker_ids"]) and np.array_equal(g["ssm_ids"], synth.marker_ids())
+    for i, s in enumerate((0, 60)):
+        d = canonicalize_frames(bm, g["in_trans"][s:s + 60:3], g["in_poses"][s:s + 60:3], g["in_betas"], g["cmu_ids"], g["ssm_ids"])
+        for k in ("transf_rotmat", "transf_transl", "trans", "poses", "betas", "joints", "marker_cmu_41", "marker_ssm2_67"):
+            ref = g[f"out{i}_{k}"]
+            assert np.asarray(d[k]).shape == ref.shape, k
+            assert np.abs(np.asarray(d[k], np.float64) - ref).max() < 2e-6, (i, k)
+        assert str(g[f"out{i}_gender"]) == "male" and int(g[f"out{i}_mocap_framerate"]) == 120
+    # in its own frame the first body stands at the origin facing +y: pelvis xy = 0 up to the offset correction, hips along x
+    j = g["out0_joints"][0]
+    assert abs(j[0, 0]) < 1e-5 and abs(j[0, 1]) < 1e-5 and abs(j[2, 1] - j[1, 1]) < 1e-5 and j[2, 0] > j[1, 0]
