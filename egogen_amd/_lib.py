@@ -141,6 +141,7 @@ SIGNATURES = {
     "egx_ppo_loss": (C.c_int, [C.c_void_p] * 9 + [C.c_float] * 6 + [C.c_int] + [C.c_void_p] * 5),
     "egx_gru_pointwise_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
+    "egx_ppo_loss_packed": (C.c_int, [C.c_void_p] * 8 + [C.c_float] * 6 + [C.c_int] + [C.c_void_p] * 4),
     "egx_lbs_set_blend_mode": (C.c_int, [C.c_int]),
     "egx_lbs_get_blend_mode": (C.c_int, []),
     "egx_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -27,17 +27,18 @@ __global__ __launch_bounds__(128) void egx_ppo_loss_kernel(const float* __restri
                                                           const float* __restrict__ logp_old, const float* __restrict__ adv_stats,
                                                           const float* __restrict__ scale_ptr, float adv_eps, float min_lv,
                                                           float max_lv, float eps_clip, float vf_coef, float ent_coef, int n,
+                                                          int stride /* row pitch of mu, logvar, g_mu, g_logvar */,
                                                           float* __restrict__ g_mu, float* __restrict__ g_logvar,
                                                           float* __restrict__ g_value, float* __restrict__ out_terms) {
   __shared__ float sh[128];
   const int row = blockIdx.x, d = threadIdx.x;
-  const size_t i = (size_t)row * 128 + d;
+  const size_t i = (size_t)row * stride + d;
   const float scale = scale_ptr[0];
   const float lv_raw = logvar[i];
   const float lv = fminf(fmaxf(lv_raw, min_lv), max_lv);
   const bool pass = (lv_raw >= min_lv) && (lv_raw <= max_lv);  // clamp backward
   const float inv_var = expf(-lv);
-  const float diff = act[i] - mu[i];
+  const float diff = act[(size_t)row * 128 + d] - mu[i];
   const float lp_d = -0.5f * diff * diff * inv_var - 0.5f * lv - LOG_SQRT_2PI;
   const float ent_d = 0.5f + LOG_SQRT_2PI + 0.5f * lv;
   const float lp = block_sum128(lp_d, sh);
@@ -367,8 +368,22 @@ extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* v
   hipStream_t st = static_cast<hipStream_t>(stream_);
   EGX_HIP_CHECK(hipMemsetAsync(out_terms, 0, 6 * sizeof(float), st));
   hipLaunchKernelGGL(egx_ppo_loss_kernel, dim3(num_rows), dim3(128), 0, st, mu, logvar, value, act, adv, ret, logp_old,
-                     adv_stats, scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef, ent_coef, num_rows, g_mu, g_logvar,
+                     adv_stats, scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef, ent_coef, num_rows, 128, g_mu, g_logvar,
                      g_value, out_terms);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_ppo_loss_packed(const float* zp, const float* value, const float* act, const float* adv, const float* ret,
+                                   const float* logp_old, const float* adv_stats, const float* scale, float adv_eps, float min_logvar,
+                                   float max_logvar, float eps_clip, float vf_coef, float ent_coef, int num_rows, float* g_zp,
+                                   float* g_value, float* out_terms, void* stream_) {
+  EGX_REQUIRE(zp && value && act && adv && ret && logp_old && scale && g_zp && g_value && out_terms && num_rows > 0, "bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  EGX_HIP_CHECK(hipMemsetAsync(out_terms, 0, 6 * sizeof(float), st));
+  hipLaunchKernelGGL(egx_ppo_loss_kernel, dim3(num_rows), dim3(128), 0, st, zp, zp + 128, value, act, adv, ret, logp_old, adv_stats,
+                     scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef, ent_coef, num_rows, 256, g_zp, g_zp + 128, g_value,
+                     out_terms);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

@@ -63,6 +63,34 @@ class PPOLossFn(torch.autograd.Function):
         return (grad_loss * g_mu, grad_loss * g_lv, (grad_loss * g_v).reshape(ctx.value_shape)) + (None,) * 12
 
 
+class PPOLossPackedFn(torch.autograd.Function):
+    """PPOLossFn on the actor head's raw output zp[n,256] = [mu | logvar]: the kernel reads both halves in place and writes one
+    gradient tensor, so neither the split nor the re-join of the two halves costs a copy / fill / add."""
+
+    @staticmethod
+    def forward(ctx, zp, value, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_lv, max_lv, eps_clip, vf_coef, ent_coef):
+        lib = _lib.load()
+        zp, value = zp.contiguous(), value.contiguous().reshape(-1)
+        n = zp.shape[0]
+        g_zp, g_v = torch.empty_like(zp), torch.empty_like(value)
+        terms = torch.empty(6, dtype=torch.float32, device=zp.device)
+        rc = lib.egx_ppo_loss_packed(_lib.ptr(zp), _lib.ptr(value), _lib.ptr(act.contiguous()), _lib.ptr(adv.contiguous()),
+                                     _lib.ptr(ret.contiguous()), _lib.ptr(logp_old.contiguous()),
+                                     _lib.ptr(adv_stats) if adv_stats is not None else None, _lib.ptr(scale), float(adv_eps),
+                                     float(min_lv), float(max_lv), float(eps_clip), float(vf_coef), float(ent_coef), n,
+                                     _lib.ptr(g_zp), _lib.ptr(g_v), _lib.ptr(terms), _lib.current_stream_ptr())
+        _lib.check(rc, "egx_ppo_loss_packed")
+        ctx.save_for_backward(g_zp, g_v)
+        ctx.value_shape = value.shape
+        ctx.mark_non_differentiable(terms)
+        return terms[0].clone(), terms
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_terms):
+        g_zp, g_v = ctx.saved_tensors
+        return (grad_loss * g_zp, (grad_loss * g_v).reshape(ctx.value_shape)) + (None,) * 12
+
+
 def posenc_dist_time(dist: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
     """[n] , [n] -> [n,128] = [posenc(dist) | posenc(time)] (no gradient: both are observations)."""
     lib = _lib.load()
@@ -112,6 +140,57 @@ class LinearFn(torch.autograd.Function):
         ctx.wg.addmm_(g.t(), x)
         dx = torch.mm(g, W) if ctx.needs_input_grad[0] else None
         return dx, None, None, None, None, None, None, (dout if ctx.has_res else None)
+
+
+class ResMLPFn(torch.autograd.Function):
+    """out = act(act(x W1^T + b1) W2^T + b2) + x: one residual unit of MLPBlock (models_policy_ppo.py:233-274) as ONE node.
+    The same kernels and products as two LinearFn nodes, but the two gradient paths into x (through W1 and through the
+    skip connection) are summed by the last GEMM (`addmm` with the incoming gradient as its addend) instead of by an extra
+    element-wise kernel of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, wg1, bg1, W2, b2, wg2, bg2, act, slope):
+        lib, st = _lib.load(), _lib.current_stream_ptr()
+        x = x.contiguous()
+        a1 = torch.addmm(b1, x, W1.t())
+        M, N1 = a1.shape
+        _lib.check(lib.egx_act_fwd(_lib.ptr(a1), None, None, M, N1, int(act), float(slope), st), "egx_act_fwd")
+        a2 = torch.addmm(b2, a1, W2.t())
+        out = torch.empty_like(a2)
+        _lib.check(lib.egx_act_fwd(_lib.ptr(a2), _lib.ptr(x), _lib.ptr(out), M, a2.shape[1], int(act), float(slope), st), "egx_act_fwd")
+        ctx.save_for_backward(x, W1, a1, W2, a2)
+        ctx.g = (wg1, bg1, wg2, bg2)
+        ctx.act, ctx.slope = int(act), float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib, st = _lib.load(), _lib.current_stream_ptr()
+        x, W1, a1, W2, a2 = ctx.saved_tensors
+        wg1, bg1, wg2, bg2 = ctx.g
+        dout = dout.contiguous()
+        M = dout.shape[0]
+        g2 = torch.empty_like(dout)
+        _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(dout), _lib.ptr(a2), _lib.ptr(g2), _lib.ptr(bg2), M, g2.shape[1], ctx.act, ctx.slope, st),
+                   "egx_act_bwd_colsum")
+        wg2.addmm_(g2.t(), a1)
+        d1 = torch.mm(g2, W2)
+        g1 = torch.empty_like(d1)
+        _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(d1), _lib.ptr(a1), _lib.ptr(g1), _lib.ptr(bg1), M, g1.shape[1], ctx.act, ctx.slope, st),
+                   "egx_act_bwd_colsum")
+        wg1.addmm_(g1.t(), x)
+        dx = torch.addmm(dout, g1, W1) if ctx.needs_input_grad[0] else None
+        return (dx,) + (None,) * 10
+
+
+def res_mlp(x, fc1: torch.nn.Linear, fc2: torch.nn.Linear, act="relu", slope=0.01):
+    for fc in (fc1, fc2):
+        if fc.weight.grad is None or fc.bias.grad is None:
+            raise _lib.EgxError("ResMLPFn needs pre-allocated gradient views (GAMMAPPOPolicy._ensure_flat_grads)")
+    if ACT_CODE[act] == 0:
+        raise ValueError("res_mlp: the unit has an activation after both layers")
+    return ResMLPFn.apply(x, fc1.weight, fc1.bias, fc1.weight.grad, fc1.bias.grad, fc2.weight, fc2.bias, fc2.weight.grad, fc2.bias.grad,
+                          ACT_CODE[act], slope)
 
 
 def linear_fn(x, weight, bias, act="none", slope=0.01, res=None):

@@ -382,9 +382,12 @@ def _gru_last_fused_tm(gru: nn.GRU, x_tm: torch.Tensor, T: int) -> torch.Tensor:
 
 
 def _mlpblock_fused(block: MLPBlock, x: torch.Tensor) -> torch.Tensor:
-    from .fused_ops import linear_act
+    from .fused_ops import ACT_CODE, linear_act, res_mlp
     h = x
     for mlp in block.layers:
+        if block.residual and len(mlp.layers) == 2 and ACT_CODE[mlp.act_name] != 0 and mlp.layers[1].out_features == h.shape[1]:
+            h = res_mlp(h, mlp.layers[0], mlp.layers[1], mlp.act_name)
+            continue
         t = h
         last = len(mlp.layers) - 1
         for i, fc in enumerate(mlp.layers):
@@ -393,9 +396,10 @@ def _mlpblock_fused(block: MLPBlock, x: torch.Tensor) -> torch.Tensor:
     return linear_act(h, block.out_fc, "none")
 
 
-def fused_update_forward(shared_net: "GAMMAPolicyBase", actor: "GAMMAActor", critic: "GAMMACritic", obs):
+def fused_update_forward(shared_net: "GAMMAPolicyBase", actor: "GAMMAActor", critic: "GAMMACritic", obs, packed: bool = False):
     """Forward of (shared_net, actor, critic) for the PPO update with every dense layer a `fused_ops.LinearFn` node
-    (models_policy_ppo.py:287-350).  Returns mu[b,128], raw logvar[b,128], value[b]."""
+    (models_policy_ppo.py:287-350).  Returns mu[b,128], raw logvar[b,128], value[b] - or, with `packed`, the actor head's raw
+    output zp[b,256] = [mu | logvar] and value[b]."""
     from .fused_ops import posenc_dist_time
     nb = obs["state"].shape[0]
     if _TWO_STREAM_UPDATE:  # the two encoders are independent as well
@@ -425,6 +429,8 @@ def fused_update_forward(shared_net: "GAMMAPolicyBase", actor: "GAMMAActor", cri
     else:
         zp = _mlpblock_fused(actor.pnet, h)
         value = _mlpblock_fused(critic.vnet, h).flatten()
+    if packed:
+        return zp, value
     return zp[:, :actor.z_dim], zp[:, actor.z_dim:], value
 
 

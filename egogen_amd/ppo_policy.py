@@ -422,11 +422,15 @@ class GAMMAPPOPolicy(nn.Module):
     def _minibatch_loss_fused(self, obs, act, adv, returns, logp_old, global_stats):
         """Same function as the torch expression above, with the loss and its gradients w.r.t. (mu, logvar, value)
         computed by one HIP kernel (egx_ppo_loss)."""
-        from .fused_ops import PPOLossFn
+        from .fused_ops import PPOLossFn, PPOLossPackedFn
+        zp = None
         if self.use_fused_linear:
             from .models import fused_update_forward
             self._ensure_flat_grads()
-            mu, logvar, value = fused_update_forward(self.shared_net, self.actor, self.critic, obs)
+            if self.actor.z_dim == 128:   # the loss kernel reads the actor head's [mu | logvar] in place
+                zp, value = fused_update_forward(self.shared_net, self.actor, self.critic, obs, packed=True)
+            else:
+                mu, logvar, value = fused_update_forward(self.shared_net, self.actor, self.critic, obs)
         else:
             hx = self.shared_net(obs)
             (mu, logvar), _ = self.actor(hx)
@@ -447,8 +451,12 @@ class GAMMAPPOPolicy(nn.Module):
                 self._scale_cache[(n_local, dev)] = scale
         else:
             scale = (1.0 / global_stats[2]).reshape(1).float()
-        loss, terms = PPOLossFn.apply(mu, logvar, value, act, adv, returns, logp_old, stats, scale, _EPS, self.actor.min_logvar,
-                                      self.actor.max_logvar, self._eps_clip, self._weight_vf, self._weight_ent)
+        if zp is not None:
+            loss, terms = PPOLossPackedFn.apply(zp, value, act, adv, returns, logp_old, stats, scale, _EPS, self.actor.min_logvar,
+                                                self.actor.max_logvar, self._eps_clip, self._weight_vf, self._weight_ent)
+        else:
+            loss, terms = PPOLossFn.apply(mu, logvar, value, act, adv, returns, logp_old, stats, scale, _EPS, self.actor.min_logvar,
+                                          self.actor.max_logvar, self._eps_clip, self._weight_vf, self._weight_ent)
         return loss, {"loss": terms[0], "loss/clip": terms[1], "loss/vf": terms[2], "loss/ent": terms[3], "loss/kld": terms[4],
                       "approx_kl": terms[5], "_packed": terms}
 

@@ -442,6 +442,12 @@ int egx_ppo_loss(const float* mu, const float* logvar, const float* value, const
                  const float* ret, const float* logp_old, const float* adv_stats, const float* scale, float adv_eps,
                  float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef, int num_rows,
                  float* g_mu, float* g_logvar, float* g_value, float* out_terms, void* stream);
+/* The same on the actor head's raw output zp [n,256] = [mu | logvar] (models_policy_ppo.py:313-317 splits it after the fact):
+ * no split / re-join copies on the way in, one gradient tensor g_zp [n,256] on the way out. */
+int egx_ppo_loss_packed(const float* zp, const float* value, const float* act, const float* adv, const float* ret,
+                        const float* logp_old, const float* adv_stats, const float* scale, float adv_eps, float min_logvar,
+                        float max_logvar, float eps_clip, float vf_coef, float ent_coef, int num_rows, float* g_zp, float* g_value,
+                        float* out_terms, void* stream);
 
 /* Backward of egx_gru_pointwise: (gi, gh, h_prev, dh) -> d gi, d gh [M,3H], d h_prev [M,H] (NULL to skip).
  * Tensors are dense (row strides H / 3H). */

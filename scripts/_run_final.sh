@@ -1,0 +1,10 @@
+set -u
+mkdir -p gpurun_out/final
+timeout 2400 python -m pytest tests -x -q -m gpu < /dev/null > gpurun_out/final/gpu_tests.log 2>&1
+echo "gpu tests rc=$?"; tail -4 gpurun_out/final/gpu_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" < /dev/null > gpurun_out/final/smoke.log 2>&1
+echo "smoke rc=$?"; tail -2 gpurun_out/final/smoke.log
+timeout 900 python bench.py < /dev/null > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
+echo "bench rc=$?"; cut -c1-300 gpurun_out/final/bench.json
+bash scripts/run_profile.sh final > gpurun_out/final/profile.log 2>&1
+tail -3 gpurun_out/final/profile.log
