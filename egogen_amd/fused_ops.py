@@ -103,6 +103,7 @@ def posenc_dist_time(dist: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
 
 ACT_CODE = {None: 0, "none": 0, "tanh": 1, "relu": 2, "lrelu": 3, "leaky_relu": 3}
 
+
 class LinearFn(torch.autograd.Function):
     """out = act(x W^T + b) (+ res).  The gradients of W and b are ACCUMULATED into `wg` / `bg` (views of the flat
     gradient buffer, zeroed once per minibatch by the caller) inside backward, and None is returned for them, so autograd
