@@ -73,7 +73,7 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
             pel = m.joints.reshape(S, 20, -1, 3)[:, :, 0].cpu()
             tm = term.cpu().numpy()
             for s in range(S):
-                episodes[k][s].append([mb[s:s + 1], pp[s:s + 1], m.betas[s].cpu(), "male", fr[s, :9].reshape(3, 3),
+                episodes[k][s].append([mb[s:s + 1], pp[s:s + 1], m.betas[s].cpu(), m.gender, fr[s, :9].reshape(3, 3),
                                        fr[s, 9:].reshape(1, 3), pel[s:s + 1], "2-frame"])
                 if tm[s]:
                     save_rollout_results({"wpath": wpath_before[s], "navmesh_path": None, "scene_path": "data/floor.ply"},

@@ -76,7 +76,7 @@ def main(args, num_scenes=1, scene_name="cab_e", out_dir="./egobody_tmp_res/", s
         agent_seeds = [[pairs[s][k]["seed"] for s in idx] for k in range(2)]
         grp = CrowdGroupEnv(S, st, body, prior, vposer, cfg=sw.env_cfg_from_yaml(cfg), seed=args.seed + 100 * local_rank + gi,
                             keep_rollout=True, scene_rings=sampler.rings, static_scene=static_scene, agent_seeds=agent_seeds,
-                            vp_thresh=14.0, goal_terminates=False)
+                            vp_thresh=14.0, goal_terminates=False, gender=gender)
         obs = grp.reset()
         episodes = [[[] for _ in range(S)] for _ in range(2)]
         ep_ret = torch.zeros(2, S, device="cuda")

@@ -51,8 +51,10 @@ class VecCrowdEnv:
                  keep_rollout: bool = False, device: str = "cuda", crowd_bbox: Optional[torch.Tensor] = None,
                  crowd_member: int = 0, crowd_pairs=None, crowd_floor_half: float = 4.0,
                  crowd_rings: Optional[List[np.ndarray]] = None, crowd_static: bool = False, agent_seeds: Optional[List[dict]] = None,
-                 vp_thresh: float = 11.0, goal_terminates: bool = True):
-        """`crowd_rings` / `crowd_static` / `agent_seeds` / `vp_thresh` / `goal_terminates` are the EgoBody-evaluation variant of
+                 vp_thresh: float = 11.0, goal_terminates: bool = True, gender: str = "male"):
+        """`gender` names the body model / motion prior the caller passed in (`crowd_env_2f.py:393` picks
+        genop_2frame_male | female by it; every sampler but the EgoBody one draws from ['male'], environments.py:254,555,906);
+        it is recorded in the saved rollouts.  `crowd_rings` / `crowd_static` / `agent_seeds` / `vp_thresh` / `goal_terminates` are the EgoBody-evaluation variant of
         the crowd scenes (crowd_env_egobody_eval.py, see CrowdGroupEnv): the scene's walkable polygon as exterior, one motion
         seed (two frames + betas) per agent instead of one table for all, the looser pose filter, no goal termination."""
         if not torch.cuda.is_available():
@@ -61,6 +63,7 @@ class VecCrowdEnv:
         self.A = A = int(num_agents)
         self.dev = torch.device(device)
         self.bm, self.prior, self.vposer = body_model, prior, vposer
+        self.gender = gender
         self.scene_kind = scene_kind
         self.cfg = dict(cfg or (BOX_CFG if scene_kind in ("box", "crowd") else DEFAULT_CFG))  # main_crowd_eval.py:224 load_model(box=True)
         self.crowd_bbox, self.crowd_member = crowd_bbox, int(crowd_member)
@@ -454,7 +457,7 @@ class CrowdGroupEnv:
 
     def __init__(self, num_scenes: int, start_target, body_model, prior, vposer, cfg=None, seed=0, keep_rollout=False,
                  motion_seed=None, floor_half: float = 4.0, device="cuda", scene_rings=None, static_scene: bool = False,
-                 agent_seeds=None, vp_thresh: float = 11.0, goal_terminates: bool = True):
+                 agent_seeds=None, vp_thresh: float = 11.0, goal_terminates: bool = True, gender: str = "male"):
         """`scene_rings` ... `goal_terminates`: the EgoBody evaluation (main_egobody_eval.py / crowd_env_egobody_eval.py, G = 2):
         the walkable polygon of the scene's navmesh as exterior (:402), `agent_seeds[k][s]` = the two seed frames + betas of
         member k in scene s (Egobody.gen_init_body, environments.py:679-765), pose filter at 14 (:229), only max_depth
@@ -468,7 +471,8 @@ class CrowdGroupEnv:
                                     keep_rollout=keep_rollout, motion_seed=motion_seed, crowd_bbox=self.bbox, crowd_member=k,
                                     crowd_pairs=st[k], crowd_floor_half=floor_half, device=device, crowd_rings=scene_rings,
                                     crowd_static=static_scene, agent_seeds=None if agent_seeds is None else agent_seeds[k],
-                                    vp_thresh=vp_thresh, goal_terminates=goal_terminates) for k in range(self.G)]
+                                    vp_thresh=vp_thresh, goal_terminates=goal_terminates, gender=gender) for k in range(self.G)]
+        self.gender = gender
 
     def invalid(self) -> torch.Tensor:
         """[S] OR of the members' filter flags (1: pelvis left the scene polygon early, 2: unrealistic pose)."""

@@ -78,7 +78,7 @@ class Collector:
         pel = env.joints.reshape(self.A, 20, -1, 3)[:, :, 0].cpu()
         tm = term.cpu().numpy()
         for a in range(self.A):
-            mp = [mb[a:a + 1], pp[a:a + 1], env.betas[a].cpu(), "male", fr[a, :9].reshape(3, 3), fr[a, 9:].reshape(1, 3), pel[a:a + 1], "2-frame"]
+            mp = [mb[a:a + 1], pp[a:a + 1], env.betas[a].cpu(), getattr(env, "gender", "male"), fr[a, :9].reshape(3, 3), fr[a, 9:].reshape(1, 3), pel[a:a + 1], "2-frame"]
             self._episodes[a].append(mp)
             if tm[a]:
                 scene = {"wpath": self._wpath_before[a], "navmesh_path": "synthetic"}
