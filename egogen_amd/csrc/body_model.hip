@@ -99,6 +99,8 @@ struct egx_body_model {
   int* tj_idx = nullptr;       // [tj_off[NVT]] joints with a non-zero skinning weight on some vertex of the tile
   float* tj_w = nullptr;       // [tj_off[NVT]][32] dense weights of the tile's 32 vertices for that joint
   int* pick_slot = nullptr;    // [NVT*32], -1 = not picked
+  int* pick_tiles = nullptr;   // [n_pick_tiles] vertex tiles that hold a picked vertex (all a markers-and-joints-only call needs)
+  int n_pick_tiles = 0;
   uint8_t* vflags = nullptr;   // [NVT*32] bit0 feet, bit1 valid
   int* vorig = nullptr;        // [NVT*32] original vertex id of every (sorted) row, -1 = padding
   PoseConsts* pc = nullptr;
@@ -256,6 +258,8 @@ struct LbsParams {
   const int* tj_idx;
   const float* tj_w;
   const int* pick_slot;
+  const int* tiles;    // vertex tiles to compute (null = all NVT); n_tiles of them
+  int n_tiles;
   const uint8_t* vflags;
   const int* vorig;    // original vertex id per sorted row
   const bf16x8* dirs3; // bf16x3 bases (blend mode 1)
@@ -651,9 +655,10 @@ __global__ __launch_bounds__(LBS_THREADS, 1) void egx_lbs_fused_kernel(LbsParams
     n_streams = gridDim.x * 2;
     stream = blockIdx.x * 2 + set;
   }
-  const int n_items = p.NVT * nper;
+  const int n_items = p.n_tiles * nper;
   for (int item = stream; item < n_items; item += n_streams) {
-    const int vt = item / nper, bg = bg_lo + item % nper;
+    const int vti = item / nper, bg = bg_lo + item % nper;
+    const int vt = p.tiles ? p.tiles[vti] : vti;
     const int bt0 = bg * 8 + w4 * NB;  // first 32-body tile of this wave
     const int JT = lbs_load_meta(p, w, vt);
     f32x16 acc[3][NB];
@@ -807,17 +812,18 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
     n_streams = gridDim.x;
     stream = blockIdx.x;
   }
-  const int n_items = p.NVT * nper;
+  const int n_items = p.n_tiles * nper;
   // item order: blocks of bg_block body groups, vertex-tile-major inside a block - the features / joint transforms of
   // a block (1.4 MB per group) stay in the XCD's 4 MiB L2 while the bases stream through once per block
   const int PB = max(1, min(p.bg_block, max(nper, 1)));
   unsigned long long tacc[4] = {0, 0, 0, 0};
   (void)tacc;
   for (int item = stream; item < n_items; item += n_streams) {
-    const int blk = item / (p.NVT * PB);
+    const int blk = item / (p.n_tiles * PB);
     const int pb = min(PB, nper - blk * PB);
-    const int r = item - blk * p.NVT * PB;
-    const int vt = r / pb, bg = bg_lo + blk * PB + r % pb;
+    const int r = item - blk * p.n_tiles * PB;
+    const int vti = r / pb, bg = bg_lo + blk * PB + r % pb;
+    const int vt = p.tiles ? p.tiles[vti] : vti;
     const int bt0 = bg * 8 + wave * NB;
     __syncthreads();  // previous item: every wave is done with the metadata and with the stage ring
     const int j_lo = p.tj_off[vt];
@@ -1043,6 +1049,13 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
   for (int i = 0; i < NLMK * 3; ++i) ok &= (lmk_slot[i] = slot_of(d->lmk_vids_host[i])) >= 0;
   if (!ok) { delete m; egx_set_error("vertex id out of range in marker/extra/landmark tables"); return EGX_ERR_ARG; }
   m->NP = NP;
+  std::vector<int> pick_tiles;
+  for (int vt = 0; vt < NVT; ++vt) {
+    bool any = false;
+    for (int r = 0; r < 32; ++r) any |= pick_slot[vt * 32 + r] >= 0;
+    if (any) pick_tiles.push_back(vt);
+  }
+  m->n_pick_tiles = (int)pick_tiles.size();
   std::vector<uint8_t> vflags(VP, 0);
   for (int v = 0; v < V; ++v) vflags[v] = 2;
   for (int i = 0; i < d->num_feet; ++i) {
@@ -1089,7 +1102,7 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
     if ((rc = upload(&d3, dirs3))) { egx_body_model_destroy(m); return rc; }
     m->dirs3 = reinterpret_cast<bf16x8*>(d3);
   }
-  if ((rc = upload(&m->vorig, perm))) { egx_body_model_destroy(m); return rc; }
+  if ((rc = upload(&m->vorig, perm)) || (rc = upload(&m->pick_tiles, pick_tiles))) { egx_body_model_destroy(m); return rc; }
   if ((rc = upload(&m->dirs, dirs)) || (rc = upload(&m->tj_off, tj_off)) || (rc = upload(&m->tj_idx, tj_idx)) ||
       (rc = upload(&m->tj_w, tj_w)) || (rc = upload(&m->pick_slot, pick_slot)) || (rc = upload(&m->vflags, vflags)) ||
       (rc = upload(&m->pc, pcv)) || (rc = upload(&m->marker_slot, marker_slot)) || (rc = upload(&m->extra_slot, extra_slot)) ||
@@ -1104,7 +1117,7 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
 extern "C" void egx_body_model_destroy(egx_body_model* m) {
   if (!m) return;
   (void)hipFree(m->dirs); (void)hipFree(m->dirs3); (void)hipFree(m->tj_off); (void)hipFree(m->tj_idx); (void)hipFree(m->tj_w);
-  (void)hipFree(m->pick_slot); (void)hipFree(m->vflags); (void)hipFree(m->vorig); (void)hipFree(m->pc); (void)hipFree(m->marker_slot);
+  (void)hipFree(m->pick_slot); (void)hipFree(m->pick_tiles); (void)hipFree(m->vflags); (void)hipFree(m->vorig); (void)hipFree(m->pc); (void)hipFree(m->marker_slot);
   (void)hipFree(m->extra_slot); (void)hipFree(m->lmk_slot); (void)hipFree(m->lmk_bary);
   delete m;
 }
@@ -1228,6 +1241,10 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     p.dbg = 0;
 #endif
     p.verts = out_verts; p.picked = picked; p.R0 = R0; p.T0 = T0; p.pene = out_pene_count;
+    // markers and joints only: the vertex tiles without a picked vertex are never looked at
+    const bool picks_only = !out_verts && !sdf;
+    p.tiles = picks_only ? m->pick_tiles : nullptr;
+    p.n_tiles = picks_only ? m->n_pick_tiles : m->NVT;
     std::memset(&p.sdf, 0, sizeof(p.sdf));
     if (sdf) {
       p.sdf.grid = sdf->grid; p.sdf.d0 = sdf->d0; p.sdf.d1 = sdf->d1; p.sdf.d2 = sdf->d2;
@@ -1266,7 +1283,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
 #ifdef EGX_LBS_DEVELOPMENT
     if (const char* e = getenv("EGX_LBS_BG_BLOCK")) p.bg_block = atoi(e);
 #endif
-    const int n_items = p.nbg * m->NVT;
+    const int n_items = p.nbg * p.n_tiles;
     const int grid = std::max(1, std::min(num_cu, (n_items + 1) / 2));
     const size_t lds = out_verts ? lds_verts : (sdf ? lds_sdf : lds_meta);
     hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
