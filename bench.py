@@ -47,6 +47,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_BODY = 2.0 * 469 * 31425          # blend GEMM only: K = 10 betas + 9 x 51 movable joints (jaw/eye columns are exactly 0)
+# of which the kernel evaluates the vertex tiles that hold a picked vertex or a vertex of the penetration count (the count
+# excludes the feet, crowd_env_2f.py:163-175): `flop_per_body` of the roofline object is 2 * 469 * 3 * that vertex count
 PEAK_F32_MFMA_TFLOPS = 157.3               # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 MFMA peak (same guide)
 BLEND_PRODUCTS = {0: None, 1: 6, 2: 3}     # bf16 partial products per fp32 product of the split blend modes
@@ -446,6 +448,9 @@ def main():
     except Exception:
         pass
     bodies = A * 20
+    bm_handle = m["env"].bm
+    verts_eval = bm_handle.lbs_vertices["sdf" if m["env"].sdf is not None else "picks"]
+    FLOP_PER_BODY = 2.0 * 469 * 3 * verts_eval     # noqa: N806 - the work this call form needs (see the module constant)
     achieved = FLOP_PER_BODY * bodies / (lbs_ms * 1e-3) / 1e12
     if blend in (1, 2):
         # n-term bf16 split: BLEND_PRODUCTS bf16 MFMA products per fp32 product -> the matrix-pipe ceiling of the
@@ -499,7 +504,8 @@ def main():
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
-                     "flop_per_body": FLOP_PER_BODY, "peak_note": peak_note, "executed_bf16_tflops": executed,
+                     "flop_per_body": FLOP_PER_BODY, "vertices_evaluated": verts_eval, "vertices_total": bm_handle.V,
+                     "peak_note": peak_note, "executed_bf16_tflops": executed,
                      "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene, "other_blend_mode": other_mode,
                      "sustained_matrix_rate_note": "72 back-to-back v_mfma_f32_32x32x16_bf16 take 46, not 32, cycles each on this part "
                                                    "(clock-limited: 1720 of 2500 TFLOP/s in a load-free micro-benchmark, profiles/r01_ubench.md "

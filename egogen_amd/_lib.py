@@ -105,6 +105,7 @@ SIGNATURES = {
     "egx_body_model_destroy": (None, [C.c_void_p]),
     "egx_body_model_num_verts": (C.c_int, [C.c_void_p]),
     "egx_body_model_nnz": (C.c_int, [C.c_void_p]),
+    "egx_body_model_lbs_vertices": (C.c_int, [C.c_void_p, C.c_int]),
     "egx_lbs_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "egx_lbs_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(SdfGrid), C.c_void_p, C.c_void_p, C.c_void_p,

@@ -91,6 +91,8 @@ class BodyModelHandle:
         self.M = d.num_markers
         self.marker_vids = [int(v) for v in k["marker"]]
         self.nnz = lib.egx_body_model_nnz(h)
+        # vertices a call without vertex output evaluates (tiles without picks / counted vertices are skipped)
+        self.lbs_vertices = {"picks": lib.egx_body_model_lbs_vertices(h, 0), "sdf": lib.egx_body_model_lbs_vertices(h, 1)}
         self._ws: Dict[tuple, torch.Tensor] = {}
         del self._keep  # device copies are owned by the handle now
 

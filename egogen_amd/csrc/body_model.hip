@@ -101,6 +101,9 @@ struct egx_body_model {
   int* pick_slot = nullptr;    // [NVT*32], -1 = not picked
   int* pick_tiles = nullptr;   // [n_pick_tiles] vertex tiles that hold a picked vertex (all a markers-and-joints-only call needs)
   int n_pick_tiles = 0;
+  int* sdf_tiles = nullptr;    // [n_sdf_tiles] tiles that hold a picked vertex or a vertex of the penetration count (non-feet)
+  int n_sdf_tiles = 0;
+  int verts_pick_tiles = 0, verts_sdf_tiles = 0;   // real vertices inside the two tile lists (work accounting)
   uint8_t* vflags = nullptr;   // [NVT*32] bit0 feet, bit1 valid
   int* vorig = nullptr;        // [NVT*32] original vertex id of every (sorted) row, -1 = padding
   PoseConsts* pc = nullptr;
@@ -1063,6 +1066,17 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
     if (v < 0 || v >= V) { delete m; egx_set_error("feet vertex id out of range"); return EGX_ERR_ARG; }
     vflags[inv[v]] |= 1;
   }
+  std::vector<int> sdf_tiles;   // tiles of feet vertices only (and no pick) contribute nothing to a picks + SDF-count call
+  for (int vt = 0; vt < NVT; ++vt) {
+    bool any = false;
+    for (int r = 0; r < 32; ++r) any |= pick_slot[vt * 32 + r] >= 0 || (vflags[vt * 32 + r] & 3) == 2;
+    if (any) sdf_tiles.push_back(vt);
+  }
+  m->n_sdf_tiles = (int)sdf_tiles.size();
+  for (int vt : sdf_tiles)
+    for (int r = 0; r < 32; ++r) m->verts_sdf_tiles += (vflags[vt * 32 + r] & 2) ? 1 : 0;
+  for (int vt : pick_tiles)
+    for (int r = 0; r < 32; ++r) m->verts_pick_tiles += (vflags[vt * 32 + r] & 2) ? 1 : 0;
   std::vector<float> lmk_bary(d->lmk_bary_host, d->lmk_bary_host + NLMK * 3);
 
   // pose constants; joint regression folded through the shape space in double precision:
@@ -1102,7 +1116,8 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
     if ((rc = upload(&d3, dirs3))) { egx_body_model_destroy(m); return rc; }
     m->dirs3 = reinterpret_cast<bf16x8*>(d3);
   }
-  if ((rc = upload(&m->vorig, perm)) || (rc = upload(&m->pick_tiles, pick_tiles))) { egx_body_model_destroy(m); return rc; }
+  if ((rc = upload(&m->vorig, perm)) || (rc = upload(&m->pick_tiles, pick_tiles)) ||
+      (rc = upload(&m->sdf_tiles, sdf_tiles))) { egx_body_model_destroy(m); return rc; }
   if ((rc = upload(&m->dirs, dirs)) || (rc = upload(&m->tj_off, tj_off)) || (rc = upload(&m->tj_idx, tj_idx)) ||
       (rc = upload(&m->tj_w, tj_w)) || (rc = upload(&m->pick_slot, pick_slot)) || (rc = upload(&m->vflags, vflags)) ||
       (rc = upload(&m->pc, pcv)) || (rc = upload(&m->marker_slot, marker_slot)) || (rc = upload(&m->extra_slot, extra_slot)) ||
@@ -1117,13 +1132,16 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
 extern "C" void egx_body_model_destroy(egx_body_model* m) {
   if (!m) return;
   (void)hipFree(m->dirs); (void)hipFree(m->dirs3); (void)hipFree(m->tj_off); (void)hipFree(m->tj_idx); (void)hipFree(m->tj_w);
-  (void)hipFree(m->pick_slot); (void)hipFree(m->pick_tiles); (void)hipFree(m->vflags); (void)hipFree(m->vorig); (void)hipFree(m->pc); (void)hipFree(m->marker_slot);
+  (void)hipFree(m->pick_slot); (void)hipFree(m->pick_tiles); (void)hipFree(m->sdf_tiles); (void)hipFree(m->vflags); (void)hipFree(m->vorig); (void)hipFree(m->pc); (void)hipFree(m->marker_slot);
   (void)hipFree(m->extra_slot); (void)hipFree(m->lmk_slot); (void)hipFree(m->lmk_bary);
   delete m;
 }
 
 extern "C" int egx_body_model_num_verts(const egx_body_model* m) { return m ? m->V : 0; }
 extern "C" int egx_body_model_nnz(const egx_body_model* m) { return m ? m->NW : 0; }
+extern "C" int egx_body_model_lbs_vertices(const egx_body_model* m, int with_sdf) {
+  return m ? (with_sdf ? m->verts_sdf_tiles : m->verts_pick_tiles) : 0;
+}
 
 namespace {
 constexpr int kMaxDevices = 64;
@@ -1242,9 +1260,9 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
 #endif
     p.verts = out_verts; p.picked = picked; p.R0 = R0; p.T0 = T0; p.pene = out_pene_count;
     // markers and joints only: the vertex tiles without a picked vertex are never looked at
-    const bool picks_only = !out_verts && !sdf;
-    p.tiles = picks_only ? m->pick_tiles : nullptr;
-    p.n_tiles = picks_only ? m->n_pick_tiles : m->NVT;
+    // (with SDF counts: nor the tiles made of feet vertices only, which the count excludes)
+    p.tiles = out_verts ? nullptr : (sdf ? m->sdf_tiles : m->pick_tiles);
+    p.n_tiles = out_verts ? m->NVT : (sdf ? m->n_sdf_tiles : m->n_pick_tiles);
     std::memset(&p.sdf, 0, sizeof(p.sdf));
     if (sdf) {
       p.sdf.grid = sdf->grid; p.sdf.d0 = sdf->d0; p.sdf.d1 = sdf->d1; p.sdf.d2 = sdf->d2;

@@ -69,6 +69,10 @@ int egx_body_model_create(const egx_body_model_host* desc, egx_body_model** out)
 void egx_body_model_destroy(egx_body_model* m);
 int egx_body_model_num_verts(const egx_body_model* m);
 int egx_body_model_nnz(const egx_body_model* m);
+/* Vertices egx_lbs_forward evaluates when no vertex output is requested: those of the 32-vertex tiles that hold a picked vertex
+ * (marker, vertex joint, landmark corner) - with_sdf = 0 - or, with_sdf = 1, also a vertex of the penetration count
+ * (crowd_env_2f.py:163-175 excludes the feet).  num_verts when every tile is needed.  Work accounting for bench.py. */
+int egx_body_model_lbs_vertices(const egx_body_model* m, int with_sdf);
 
 /* Scene SDF (crowd_ppo/utils.py:54-84 `sdf_dict`): grid[d0][d1][d2] indexed by the vertex (x,y,z). */
 typedef struct egx_sdf_grid {
