@@ -358,3 +358,45 @@ def test_lbs_blend_mode_accuracy_report():
         print("%-7s  %.2e       %.2e      %5d         %5d         %d" % r)
     # the two-plane mode stays within a factor of a few of fp32 round-off thanks to the template's third term
     assert rows[2][1] < 4 * max(rows[0][1], 1e-6)
+
+
+def test_lbs_tile_lists_skip_only_what_contributes_nothing(blend_mode):
+    """Calls without vertex output walk a subset of the 32-vertex tiles: those with a picked vertex (markers / joints only),
+    plus those with a vertex of the penetration count (SDF calls; the count excludes the feet).  With the feet chosen as
+    whole joint clusters - the kernel sorts vertices by the set of joints they are bound to, so they fill tiles of their own,
+    as the feet of the real model do - tiles ARE skipped, and nothing may change: markers / joints equal the all-tiles (vertex-writing) call in
+    the same arithmetic, counts equal the recount from its vertices."""
+    from egogen_amd.body_model import BodyModelHandle, SdfScene
+    from egogen_amd.utils import calc_sdf
+    V, A, T = 4096, 3, 20
+    bm = synth.make_body_model(0, num_verts=V)
+    first = (np.asarray(bm["lbs_weights"]) != 0).argmax(1)                        # lowest joint a vertex is bound to = sort key
+    feet = np.flatnonzero(np.isin(first, [7, 8, 9, 10])).astype(np.int32)          # a contiguous run of the kernel's vertex order
+    mk = synth.marker_ids(V)
+    h = BodyModelHandle(bm, mk, feet)
+    assert h.lbs_vertices["picks"] < h.lbs_vertices["sdf"] < V, h.lbs_vertices    # both lists skip something here
+    xb, betas = _poses(A, T, seed=5)
+    xb[:, 2] = 0.1
+    scene = SdfScene(synth.make_sdf_scene(48))
+    R0 = torch.eye(3).repeat(A, 1, 1).cuda()
+    T0 = torch.zeros(A, 3).cuda()
+    full = h.forward(xb.cuda(), betas.cuda(), T, want_verts=True, sdf=scene, R0=R0, T0=T0)
+    full = {k: v.clone() for k, v in full.items()}
+    picks = h.forward(xb.cuda(), betas.cuda(), T)
+    with_sdf = h.forward(xb.cuda(), betas.cuda(), T, sdf=scene, R0=R0, T0=T0)
+    if blend_mode == "f32":     # the vertex-writing call always uses the fp32 kernel: same arithmetic -> same bits
+        assert torch.equal(picks["markers"], full["markers"]) and torch.equal(picks["joints"], full["joints"])
+        assert torch.equal(with_sdf["pene_count"], full["pene_count"])
+    else:
+        assert float((picks["markers"] - full["markers"]).abs().max()) < 3e-6
+        assert float((picks["joints"] - full["joints"]).abs().max()) < 3e-6
+    assert torch.equal(with_sdf["markers"], picks["markers"]) and torch.equal(with_sdf["joints"], picks["joints"])
+    # recount from the written vertices (feet excluded): exact up to vertices at the level set
+    sc = synth.make_sdf_scene(48)
+    sd = {k: torch.as_tensor(np.asarray(sc[k])).cuda() for k in ("sdf", "center", "scale")}
+    s = calc_sdf(full["vertices"].reshape(A * T, V, 3), sd)
+    s[:, torch.as_tensor(feet).long().cuda()] = 1.0
+    ref = s.lt(0).sum(-1).cpu()
+    near = (s.abs() < 2e-5).sum(-1).cpu()
+    assert ((with_sdf["pene_count"].cpu().long() - ref).abs() <= near).all()
+    assert int(with_sdf["pene_count"].max()) > 20
