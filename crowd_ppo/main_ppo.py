@@ -68,8 +68,9 @@ def get_args(argv=None, extra=()):
     p.add_argument("--wandb-project", type=str, default="mujoco.benchmark")
     p.add_argument("--watch", default=False, action="store_true", help="watch the play of pre-trained policy only")
     # extensions (not in the reference)
-    p.add_argument("--scene", type=str, default=None, choices=["room0", "single_box", "box"],
-                   help="scene set (default: room0 for main_ppo, box for main_ppo_box)")
+    p.add_argument("--scene", type=str, default=None,
+                   help="scene set: room0 | single_box | box (default: room0 for main_ppo, box for main_ppo_box), or the .npz of a "
+                        "scene prepared with egogen_amd.scene_gen.save_scene")
     p.add_argument("--sdf-res", type=int, default=256)
     p.add_argument("--save-rollout", type=int, default=None, help="write log/eval_results/motion_*.pkl (default: only with --watch)")
     p.add_argument("--num-verts", type=int, default=synth.NUM_VERTS, help="reduced synthetic body (tests)")

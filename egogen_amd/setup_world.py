@@ -215,9 +215,26 @@ def build_policy(args, device="cuda", policy_cfg: Optional[dict] = None) -> GAMM
     return policy
 
 
+def load_scene_file(path: str) -> dict:
+    """A scene prepared with `egogen_amd.scene_gen` (`save_scene`): with an SDF grid -> the room kind (SDF penetration term,
+    walkable polygon for the egosensing rays, start / target pairs); without -> one scene of the box kind (walkability map)."""
+    with np.load(path) as z:
+        d = {k: z[k] for k in z.files}
+    off = d["ring_off"]
+    rings = [d["ring_xy"][off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    if "sdf_sdf" in d:
+        return dict(scene_kind="sdf", sdf_dict={"sdf": d["sdf_sdf"], "center": d["sdf_center"], "scale": d["sdf_scale"]}, rings=rings,
+                    pairs=d["pairs"])
+    return dict(scene_kind="box", box_scenes=[{"edges": d["edges"], "tris": d["tris"], "floor_height": float(d["floor_height"]),
+                                               "pairs": d["pairs"]}])
+
+
 def build_scene(kind: str, sdf_res: int = 256, seed: int = 0, data_dir: str = "data"):
     """kind: 'room0' (Replica room0 polygon + pairs, SDF from data/room0_sdf.pkl if present else a synthetic room0-shaped
-    grid), 'single_box' (BASELINE config 2) or 'box' (random_box_obstacle_new stand-in)."""
+    grid), 'single_box' (BASELINE config 2), 'box' (random_box_obstacle_new stand-in), or the path of a `.npz` scene
+    prepared with `egogen_amd.scene_gen.save_scene` (new scenes)."""
+    if kind.endswith(".npz"):
+        return load_scene_file(kind)
     if kind == "box":
         return dict(scene_kind="box", box_scenes=synth.make_box_scenes(64, 2048, seed=seed))
     if kind == "room0":

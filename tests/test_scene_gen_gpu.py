@@ -95,3 +95,48 @@ def test_mesh_sdf_full_size_properties():
     octa = 4 / 3 * 0.8 ** 3
     assert abs(vol - (sphere + octa)) < 0.02 * (sphere + octa)   # inscribed polyhedron + voxel counting
     assert float(g.max()) < 1.5 + 1e-3 and float(g.min()) < -2.0
+
+
+def test_prepared_scene_file_drives_the_env_like_the_analytic_scene(tmp_path):
+    """N4 -> E1: a scene prepared from meshes (room shell + box obstacle: SDF grid by egx_mesh_sdf, polygon and navmesh from the
+    raster, pairs), saved and loaded back through setup_world.build_scene, gives the environment the same rewards, penetration
+    counts and egosensing as the analytic single-box scene it models; and the same file as one scene of the box kind drives the
+    walkability-map environment."""
+    from egogen_amd import setup_world as sw
+    from egogen_amd.crowd_env import VecCrowdEnv
+    from tests.helpers import build_world
+    res = 48
+    w = build_world(V=1536, A=6, scene_kind="sdf", sdf_res=res)
+    env_a = w["env"]
+    ref = w["scene"]
+    room = sg.box_mesh(ref["room_lo"], ref["room_hi"])
+    obs = sg.box_mesh(ref["obs_lo"], ref["obs_hi"])
+    sc = sg.box_scene_from_meshes(ref["room_lo"], ref["room_hi"], obs, radius=0.0, cell=0.1, n_pairs=64, seed=2)
+    sdf = sg.scene_sdf_dict(room, obs, res=res, center=ref["center"], half=1.0 / float(ref["scale"]))
+    sg.save_scene(str(tmp_path / "my_scene.npz"), sc, sdf)
+    loaded = sw.build_scene(str(tmp_path / "my_scene.npz"))
+    assert loaded["scene_kind"] == "sdf" and len(loaded["rings"]) == 2
+    loaded["pairs"] = w["pairs"]                                        # same start / target pairs as the analytic env
+    env_b = VecCrowdEnv(6, w["handle"], env_a.prior, env_a.vposer, seed=0, **loaded)
+    assert torch.equal(env_a.pair_valid_mask, env_b.pair_valid_mask)   # the SDF start check agrees pair by pair
+    cand = env_a.valid_pairs[:6].reshape(6, 1, 2, 3)
+    g = torch.Generator().manual_seed(1)
+    for e in (env_a, env_b):
+        e.set_candidates(cand)
+        e.reset()
+    assert float((env_a.obs_ego - env_b.obs_ego).abs().max()) < 2e-4      # polygon from the raster == analytic polygon
+    for _ in range(3):
+        z = torch.randn(6, 128, generator=g).cuda()
+        (oa, ra, ta), (ob, rb, tb) = env_a.step(z, auto_reset=False), env_b.step(z, auto_reset=False)
+        assert (env_a.pene_count - env_b.pene_count).abs().max() <= 1     # grids agree to 5e-6: only level-set vertices may flip
+        assert float((ra - rb).abs().max()) < 2e-3 and torch.equal(ta, tb)
+        assert float((oa["egosensing"] - ob["egosensing"]).abs().max()) < 2e-4
+    # the same preparation without an SDF grid = one scene of the box kind (walkability map from the navmesh triangles)
+    sg.save_scene(str(tmp_path / "my_box_scene.npz"), sg.box_scene_from_meshes([-4, -4, 0], [4, 4, 0], obs, radius=0.2, cell=0.1,
+                                                                              n_pairs=256, seed=3))
+    box = sw.build_scene(str(tmp_path / "my_box_scene.npz"))
+    assert box["scene_kind"] == "box"
+    env_c = VecCrowdEnv(4, w["handle"], env_a.prior, env_a.vposer, seed=1, **box)
+    o = env_c.reset()
+    o2, r2, t2 = env_c.step(torch.randn(4, 128, generator=g).cuda())
+    assert torch.isfinite(r2).all() and torch.isfinite(o2["state"]).all() and set(o["state"].shape) == {4, 2, 402}
