@@ -9,7 +9,7 @@ polygon, tests/test_egobody_cpu.py)."""
 from __future__ import annotations
 
 import struct
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 
