@@ -9,7 +9,7 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 cat, calls = collections.Counter(), collections.Counter()
 for r in rows:
     n = r["Name"]
-    if n.startswith("Cijk"): k = "hipBLASLt GEMMs (Cijk_*)"
+    if n.startswith("Cijk"): k = "library GEMMs (Cijk_*: hipBLASLt / rocBLAS Tensile kernels)"
     elif "egx_" in n: k = n.split("(")[0].replace("void ", "")[:48]
     elif "at::native" in n: k = "torch " + n.split("at::native::")[1].split("<")[0][:40]
     else: k = n[:48]
