@@ -89,23 +89,37 @@ struct LinArgs2 {
   int blocks0;  // blocks [0, blocks0) work on p0, the rest on p1 (independent GEMMs sharing one launch)
 };
 
+// One 32 x (32 NW) output tile per workgroup; each of the four waves owns a quarter of K and walks it in blocks of 32.
+//   DIRECT (K <= 512): operands go from global memory straight into MFMA operand registers - lane (i, h) fetches
+//     k = 8 q + 4 h .. + 3 of row m0 + i of X and of row n0 + i of W with one 16-byte load each and feeds them to four
+//     consecutive MFMA steps (which k a step multiplies is free as long as both operands agree, so the steps of a lane simply
+//     walk its own four elements).  No LDS staging, no wave barrier.  NW = 2: the X fragments serve two column tiles, so a
+//     launch that would need more workgroups than the chip holds at once gets by with half as many.
+//   staged (K > 512: the policy's 1152-wide layers): row-contiguous 16-byte loads (8 lanes cover one 128-byte row segment,
+//     every cache line is requested once), parked in a wave-private LDS strip (36-float pitch) and read back as operand
+//     fragments; the direct form touches 32 lines per load instruction, which costs more than the staging once a wave walks
+//     many blocks.
+// No software prefetch in either: on gfx950 a wave that issues v_mfma_f32_32x32x2_f32 while its own global loads are in
+// flight runs the matrix pipe at about half rate (scripts/ubench/mfma_loads.hip); the load latency of one wave is covered by
+// the other waves of the SIMD.  Two k-blocks per round trip: these layers are latency-bound (a wave walks 2..9 blocks, a round
+// trip to L2 / Infinity Cache costs ~2 us against 0.4 us of MFMAs per block), so the number of trips is what counts.
+template <bool DIRECT, int NW>
 __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
+  static_assert(DIRECT || NW == 1, "the staged form computes one column tile");
   const bool second = (int)blockIdx.x >= two.blocks0;
   const LinArgs& a = second ? two.p1 : two.p0;
   const int bid = second ? (int)blockIdx.x - two.blocks0 : (int)blockIdx.x;
-  // Each wave owns a quarter of K and walks it in blocks of 32: the 32x32 X block and the 32x32 W block are fetched
-  // with row-contiguous 16-byte loads (8 lanes cover one 128-byte row segment: every cache line is requested once and
-  // used completely), parked in a wave-private LDS strip with a 36-float row pitch, and read back as MFMA operand
-  // fragments with conflict-free ds_read_b128.  The next block's global loads are in flight during the 16 MFMAs.
-  __shared__ __attribute__((aligned(16))) float stage[4][2][32 * 36];
+  __shared__ __attribute__((aligned(16))) float stage[DIRECT ? NW * 4 * 16 * 64 : 4 * 2 * 32 * 36];
+  float* red = stage;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   // XCD-aware tile map (blocks are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2): every XCD gets a
   // contiguous chunk of tiles along the LONGER tile axis and sweeps the other axis, so it touches 1/8 of one operand
   // and all of the other instead of everything.
+  constexpr int TW = 32 * NW;
   int mt, nt;
   {
-    const int MT = (a.M + 31) >> 5, NT = (a.N + 31) >> 5;
+    const int MT = (a.M + 31) >> 5, NT = (a.N + TW - 1) / TW;
     const int xcd = bid & 7, local = bid >> 3;
     if (NT >= MT) {
       const int per = (NT + 7) >> 3;
@@ -119,83 +133,130 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
       if (local >= per * NT || mt >= MT) return;
     }
   }
-  const int m0 = mt * 32, n0 = nt * 32;
+  const int m0 = mt * 32, n0 = nt * TW;
   const int nblk = (a.K + 31) >> 5;
   const int per = (nblk + 3) >> 2;
   const int b0 = wave * per, b1 = min(nblk, b0 + per);
-  const int lr = lane >> 3, lc = (lane & 7) * 4;  // loader role: row lr (+8q), k offset lc
-  float* xs = stage[wave][0];
-  float* ws = stage[wave][1];
-  f32x16 acc;
+  f32x16 acc[NW];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // No software prefetch: on gfx950 a wave that issues v_mfma_f32_32x32x2_f32 while its own global loads are in flight
-  // runs the matrix pipe at about half rate (scripts/ubench/mfma_loads.hip); the load latency of one wave is covered
-  // by the other waves of the SIMD (4 workgroups per CU) instead.
-  // Two k-blocks per round trip: the loads of both are issued together and waited for once, then the blocks go through
-  // the wave's staging strip one after the other.  These layers are latency-bound (a wave walks 2..9 blocks, each a
-  // dependent round trip to L2 / Infinity Cache of ~2 us against 0.4 us of MFMAs), so halving the trips is what counts.
-  for (int b = b0; b < b1; b += 2) {
-    f32x4 gx[2][4], gw[2][4];
-    const bool two = b + 1 < b1;
+  for (int t = 0; t < NW; ++t)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (u == 0 || two) {
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  if (DIRECT) {
+    const int xrow = min(m0 + i, a.M - 1);
+    int wrow[NW];
+#pragma unroll
+    for (int t = 0; t < NW; ++t) wrow[t] = min(n0 + 32 * t + i, a.N - 1);
+    for (int b = b0; b < b1; b += 2) {
+      f32x4 gx[2][4], gw[2][NW][4];
+      const bool two_blocks = b + 1 < b1;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 0 || two_blocks) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            gx[u][q] = load_x4(a, xrow, (b + u) * 32 + q * 8 + 4 * h);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) gw[u][t][q] = load_w4(a, wrow[t], (b + u) * 32 + q * 8 + 4 * h);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two_blocks) break;
+        if (a.bf16) {
+          // k sub-blocks of 16: lane (i, h) holds 8 consecutive k of its row as bf16 (A and B alike) = two of its fp32 quads
+#pragma unroll
+          for (int sb = 0; sb < 2; ++sb) {
+            bf16x8 xa;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xa[e] = (short)egx_bf16_rne(gx[u][2 * sb][e]); xa[4 + e] = (short)egx_bf16_rne(gx[u][2 * sb + 1][e]); }
+#pragma unroll
+            for (int t = 0; t < NW; ++t) {
+              bf16x8 wb;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { wb[e] = (short)egx_bf16_rne(gw[u][t][2 * sb][e]); wb[4 + e] = (short)egx_bf16_rne(gw[u][t][2 * sb + 1][e]); }
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wb, acc[t], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gx[u][q][e], gw[u][t][q][e], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    const int lr = lane >> 3, lc = (lane & 7) * 4;  // loader role: row lr (+8q), k offset lc
+    float* xs = stage + (wave * 2 + 0) * (32 * 36);
+    float* ws = stage + (wave * 2 + 1) * (32 * 36);
+    for (int b = b0; b < b1; b += 2) {
+      f32x4 gx[2][4], gw[2][4];
+      const bool two_blocks = b + 1 < b1;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 0 || two_blocks) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            gx[u][q] = load_x4(a, min(m0 + q * 8 + lr, a.M - 1), (b + u) * 32 + lc);
+            gw[u][q] = load_w4(a, min(n0 + q * 8 + lr, a.N - 1), (b + u) * 32 + lc);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two_blocks) break;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          gx[u][q] = load_x4(a, min(m0 + q * 8 + lr, a.M - 1), (b + u) * 32 + lc);
-          gw[u][q] = load_w4(a, min(n0 + q * 8 + lr, a.N - 1), (b + u) * 32 + lc);
+          *reinterpret_cast<f32x4*>(xs + (q * 8 + lr) * 36 + lc) = gx[u][q];
+          *reinterpret_cast<f32x4*>(ws + (q * 8 + lr) * 36 + lc) = gw[u][q];
         }
-      }
-    }
+        if (a.bf16) {
+          // two 16-wide k sub-blocks: lane (i, h) holds k = 16 s + 8 h + 0..7 of row i as 8 bf16 (A and B alike)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (u == 1 && !two) break;
+          for (int sb = 0; sb < 2; ++sb) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h), x1 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h + 4);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h), w1 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h + 4);
+            bf16x8 xa, wb;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<f32x4*>(xs + (q * 8 + lr) * 36 + lc) = gx[u][q];
-        *reinterpret_cast<f32x4*>(ws + (q * 8 + lr) * 36 + lc) = gw[u][q];
-      }
-      if (a.bf16) {
-        // two 16-wide k sub-blocks: lane (i, h) holds k = 16 s + 8 h + 0..7 of row i as 8 bf16 (A and B alike)
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h), x1 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h + 4);
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h), w1 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h + 4);
-          bf16x8 xa, wb;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            xa[e] = (short)egx_bf16_rne(x0[e]); xa[4 + e] = (short)egx_bf16_rne(x1[e]);
-            wb[e] = (short)egx_bf16_rne(w0[e]); wb[4 + e] = (short)egx_bf16_rne(w1[e]);
+            for (int e = 0; e < 4; ++e) {
+              xa[e] = (short)egx_bf16_rne(x0[e]); xa[4 + e] = (short)egx_bf16_rne(x1[e]);
+              wb[e] = (short)egx_bf16_rne(w0[e]); wb[4 + e] = (short)egx_bf16_rne(w1[e]);
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wb, acc[0], 0, 0, 0);
           }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wb, acc, 0, 0, 0);
-        }
-      } else {
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
-          const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc[0], 0, 0, 0);
+          }
         }
       }
     }
   }
-  // split-K reduction through the (now idle) staging strips
+  // split-K reduction through LDS; every wave then finishes four of the lane's sixteen rows (bias, activation, residual)
   __syncthreads();
-  float* red = &stage[0][0][0];
-  if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave * 2304 + r * 64 + lane] = acc[r];
-  }
+  for (int t = 0; t < NW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t][r];
   __syncthreads();
-  if (wave == 0) {
-    const int n = n0 + i;
+#pragma unroll
+  for (int t = 0; t < NW; ++t) {
+    const int n = n0 + 32 * t + i;
     const float bsv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = wave * 4 + rr;
       const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      float v = acc[r] + red[2304 + r * 64 + lane] + red[2 * 2304 + r * 64 + lane] + red[3 * 2304 + r * 64 + lane] + bsv;
+      float v = ((red[((t * 4 + 0) * 16 + r) * 64 + lane] + red[((t * 4 + 1) * 16 + r) * 64 + lane]) +
+                 red[((t * 4 + 2) * 16 + r) * 64 + lane]) + red[((t * 4 + 3) * 16 + r) * 64 + lane] + bsv;
       v = apply_act(v, a.act, a.slope);
       if (m < a.M && n < a.N) {
         if (a.res) v += a.res[(size_t)m * a.ldr + n];
@@ -539,9 +600,19 @@ static LinArgs make_lin_args(int M, int N, const EgxSeg* segs, int nseg, const f
   a.M = M; a.N = N; a.K = K; a.act = act; a.slope = slope;
   return a;
 }
-static int lin_blocks(const LinArgs& a) {
-  const int MT = egx_ceil_div(a.M, 32), NT = egx_ceil_div(a.N, 32);
+static int lin_blocks(const LinArgs& a, int nw) {
+  const int MT = egx_ceil_div(a.M, 32), NT = egx_ceil_div(a.N, 32 * nw);
   return (NT >= MT) ? 8 * egx_ceil_div(NT, 8) * MT : 8 * egx_ceil_div(MT, 8) * NT;
+}
+// Form of a launch: direct operand loads up to K = 512 (one or two round trips per wave), LDS-staged coalesced loads above.
+// (Two column tiles per workgroup - the NW = 2 instantiation - halve the workgroups of the 768-tile paired launches but
+// double the MFMA chain of every wave: 17.7 -> 20.9 us at 512 x 1536 x 402, so one tile per workgroup it stays.)
+static void launch_linear2(hipStream_t st, LinArgs2& two, bool pair) {
+  const bool direct = std::max(two.p0.K, pair ? two.p1.K : 0) <= 512;
+  two.blocks0 = lin_blocks(two.p0, 1);
+  const int blocks = two.blocks0 + (pair ? lin_blocks(two.p1, 1) : 0);
+  if (direct) hipLaunchKernelGGL((egx_linear_kernel<true, 1>), dim3(blocks), dim3(256), 0, st, two);
+  else hipLaunchKernelGGL((egx_linear_kernel<false, 1>), dim3(blocks), dim3(256), 0, st, two);
 }
 
 int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg, const float* W, const float* b,
@@ -555,8 +626,7 @@ int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg
     return EGX_OK;
   }
   two.p1 = two.p0;
-  two.blocks0 = lin_blocks(two.p0);
-  hipLaunchKernelGGL(egx_linear_kernel, dim3(two.blocks0), dim3(256), 0, st, two);
+  launch_linear2(st, two, false);
   return EGX_OK;
 }
 
@@ -564,8 +634,7 @@ int egx_launch_linear_one(hipStream_t st, const EgxLin& A) {
   LinArgs2 two;
   two.p0 = make_lin_args(A.M, A.N, A.segs, A.nseg, A.W, A.ldw, A.b, A.act, A.slope, A.res, A.ldr, A.out, A.ldo, A.bf16);
   two.p1 = two.p0;
-  two.blocks0 = lin_blocks(two.p0);
-  hipLaunchKernelGGL(egx_linear_kernel, dim3(two.blocks0), dim3(256), 0, st, two);
+  launch_linear2(st, two, false);
   return EGX_OK;
 }
 
@@ -574,8 +643,7 @@ int egx_launch_linear_pair(hipStream_t st, const EgxLin& A, const EgxLin& B) {
   LinArgs2 two;
   two.p0 = make_lin_args(A.M, A.N, A.segs, A.nseg, A.W, A.ldw, A.b, A.act, A.slope, A.res, A.ldr, A.out, A.ldo, A.bf16);
   two.p1 = make_lin_args(B.M, B.N, B.segs, B.nseg, B.W, B.ldw, B.b, B.act, B.slope, B.res, B.ldr, B.out, B.ldo, B.bf16);
-  two.blocks0 = lin_blocks(two.p0);
-  hipLaunchKernelGGL(egx_linear_kernel, dim3(two.blocks0 + lin_blocks(two.p1)), dim3(256), 0, st, two);
+  launch_linear2(st, two, true);
   return EGX_OK;
 }
 
