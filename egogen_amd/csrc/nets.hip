@@ -103,7 +103,7 @@ struct LinArgs2 {
 // flight runs the matrix pipe at about half rate (scripts/ubench/mfma_loads.hip); the load latency of one wave is covered by
 // the other waves of the SIMD.  Two k-blocks per round trip: these layers are latency-bound (a wave walks 2..9 blocks, a round
 // trip to L2 / Infinity Cache costs ~2 us against 0.4 us of MFMAs per block), so the number of trips is what counts.
-template <bool DIRECT, int NW>
+template <bool DIRECT, int NW, int TRIP = 2>
 __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
   static_assert(DIRECT || NW == 1, "the staged form computes one column tile");
   const bool second = (int)blockIdx.x >= two.blocks0;
@@ -147,12 +147,12 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
     int wrow[NW];
 #pragma unroll
     for (int t = 0; t < NW; ++t) wrow[t] = min(n0 + 32 * t + i, a.N - 1);
-    for (int b = b0; b < b1; b += 2) {
-      f32x4 gx[2][4], gw[2][NW][4];
-      const bool two_blocks = b + 1 < b1;
+    for (int b = b0; b < b1; b += TRIP) {
+      f32x4 gx[TRIP][4], gw[TRIP][NW][4];
+      const int nbt = min(TRIP, b1 - b);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (u == 0 || two_blocks) {
+      for (int u = 0; u < TRIP; ++u) {
+        if (u < nbt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             gx[u][q] = load_x4(a, xrow, (b + u) * 32 + q * 8 + 4 * h);
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
         }
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (u == 1 && !two_blocks) break;
+      for (int u = 0; u < TRIP; ++u) {
+        if (u >= nbt) break;
         if (a.bf16) {
           // k sub-blocks of 16: lane (i, h) holds 8 consecutive k of its row as bf16 (A and B alike) = two of its fp32 quads
 #pragma unroll
@@ -606,7 +606,9 @@ static int lin_blocks(const LinArgs& a, int nw) {
 }
 // Form of a launch: direct operand loads up to K = 512 (one or two round trips per wave), LDS-staged coalesced loads above.
 // (Two column tiles per workgroup - the NW = 2 instantiation - halve the workgroups of the 768-tile paired launches but
-// double the MFMA chain of every wave: 17.7 -> 20.9 us at 512 x 1536 x 402, so one tile per workgroup it stays.)
+// double the MFMA chain of every wave: 17.7 -> 20.9 us at 512 x 1536 x 402, so one tile per workgroup it stays.  The direct
+// form at K = 1152 with two / three blocks per trip: 39.7 / 40.3 us against 37.0 staged - that launch moves 170 MB through
+// the L2s (576 tiles x two 32 x 1152 operand strips), which is what bounds it.)
 static void launch_linear2(hipStream_t st, LinArgs2& two, bool pair) {
   const bool direct = std::max(two.p0.K, pair ? two.p1.K : 0) <= 512;
   two.blocks0 = lin_blocks(two.p0, 1);
