@@ -614,7 +614,9 @@ static int lin_blocks(const LinArgs& a, int nw) {
 // (Two column tiles per workgroup - the NW = 2 instantiation - halve the workgroups of the 768-tile paired launches but
 // double the MFMA chain of every wave: 17.7 -> 20.9 us at 512 x 1536 x 402, so one tile per workgroup it stays.  The direct
 // form at K = 1152 with two / three blocks per trip: 39.7 / 40.3 us against 37.0 staged - that launch moves 170 MB through
-// the L2s (576 tiles x two 32 x 1152 operand strips), which is what bounds it.)
+// the L2s (576 tiles x two 32 x 1152 operand strips); a 64 x 64 tile per 8-wave workgroup (four quadrants x two halves of K)
+// halves those bytes but makes every wave walk 18 blocks in 9 trips: 39.2 us against 28.9 - the trip count, not the byte
+// count, is what such a launch pays for.)
 static void launch_linear2(hipStream_t st, LinArgs2& two, bool pair) {
   const bool direct = std::max(two.p0.K, pair ? two.p1.K : 0) <= 512;
   two.blocks0 = lin_blocks(two.p0, 1);
