@@ -73,3 +73,37 @@ def test_oracle_mesh_sdf_against_closed_forms():
     got = mesh_signed_distance(*sg.box_mesh(lo, hi), P, inside_positive=True)
     ref = -synth._box_sdf(P, lo, hi)            # _box_sdf < 0 inside
     assert np.abs(got - ref).max() < 1e-9
+
+
+def test_outline_and_triangle_cover_agree_with_the_raster_on_random_grids():
+    """Property: for any free / blocked raster the rings (even-odd) and the rectangle cover contain exactly the free cells -
+    including diagonal touches, holes inside holes and one-cell corridors."""
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        nx, ny = int(rng.integers(3, 14)), int(rng.integers(3, 14))
+        free = rng.random((nx, ny)) < (0.45 + 0.4 * rng.random())
+        if not free.any():
+            continue
+        origin, cell = np.array([-1.5, 2.0]), 0.25
+        rings = sg.grid_to_rings(free, origin, cell, largest_only=False)
+        cx = origin[0] + (np.arange(nx) + 0.5) * cell
+        cy = origin[1] + (np.arange(ny) + 0.5) * cell
+        X, Y = np.meshgrid(cx, cy, indexing="ij")
+        inside = sg.rings_contain(rings, X.ravel(), Y.ravel()).reshape(nx, ny)
+        assert np.array_equal(inside, free), trial
+        assert all(np.array_equal(r[0], r[-1]) and len(r) >= 5 for r in rings)
+        v, f = sg.grid_to_navmesh(free, origin, cell)
+        tri = v[f][:, :, :2]
+        area = 0.5 * np.abs((tri[:, 1, 0] - tri[:, 0, 0]) * (tri[:, 2, 1] - tri[:, 0, 1]) - (tri[:, 2, 0] - tri[:, 0, 0]) * (tri[:, 1, 1] - tri[:, 0, 1]))
+        assert abs(area.sum() - free.sum() * cell * cell) < 1e-9
+        # every cell centre is covered by a triangle iff the cell is free
+        p = np.stack([X.ravel(), Y.ravel()], 1)
+        def side(a, b):
+            return (p[:, None, 0] - b[None, :, 0]) * (a[None, :, 1] - b[None, :, 1]) - (a[None, :, 0] - b[None, :, 0]) * (p[:, None, 1] - b[None, :, 1])
+        d1, d2, d3 = side(tri[:, 0], tri[:, 1]), side(tri[:, 1], tri[:, 2]), side(tri[:, 2], tri[:, 0])
+        cover = (~(((d1 < 0) | (d2 < 0) | (d3 < 0)) & ((d1 > 0) | (d2 > 0) | (d3 > 0)))).any(1).reshape(nx, ny)
+        assert np.array_equal(cover, free), trial
+        # largest component only: a subset of the free cells, connected
+        big = sg.grid_to_rings(free, origin, cell, largest_only=True)
+        inside_big = sg.rings_contain(big, X.ravel(), Y.ravel()).reshape(nx, ny)
+        assert (inside_big <= free).all() and inside_big.any()
