@@ -51,7 +51,8 @@ class PriorWeights(C.Structure):
                [(n, C.c_void_p) for n in ("d_rnn_w_ih", "d_rnn_w_hh", "d_rnn_b_ih", "d_rnn_b_hh")] + \
                [("d_mlp_w", C.c_void_p * 2), ("d_mlp_b", C.c_void_p * 2), ("d_out_w", C.c_void_p), ("d_out_b", C.c_void_p),
                 ("reg_in_w", C.c_void_p), ("reg_in_b", C.c_void_p), ("reg_blk_w", C.c_void_p * 20), ("reg_blk_b", C.c_void_p * 20),
-                ("reg_out_w", C.c_void_p), ("reg_out_b", C.c_void_p), ("d_comb_w", C.c_void_p), ("d_comb_b", C.c_void_p)]
+                ("reg_out_w", C.c_void_p), ("reg_out_b", C.c_void_p), ("d_comb_w", C.c_void_p), ("d_comb_b", C.c_void_p),
+                ("reg_packed_in", C.c_void_p), ("reg_packed_blk", C.c_void_p), ("reg_packed_out", C.c_void_p)]
 
 
 class PolicyWeights(C.Structure):

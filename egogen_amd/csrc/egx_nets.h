@@ -37,6 +37,10 @@ struct RegWeights {
   const float* in_w; const float* in_b;
   const float* blk_w[20]; const float* blk_b[20];
   const float* out_w; const float* out_b;
+  // optional copies of the weights in MFMA operand lane order (egx_prior_weights.reg_packed_*), all three or none
+  const f32x4* pk_in;    // [4 column groups][47 chunks][64 lanes] float4   (K 370 zero-padded to 376)
+  const f32x4* pk_blk;   // [20 layers][4][16][64]
+  const f32x4* pk_out;   // [5][16][64]                                    (N 159 padded to 160 by repeating the last row)
 };
 int egx_launch_regressor_fused(hipStream_t st, const RegWeights& w, const float* Y, const float* betas, int A, int M,
                                float* out_Yb);

@@ -391,6 +391,12 @@ __device__ __forceinline__ void rg_load_w128(const float* W, int col, int h, f32
 #pragma unroll
   for (int c = 0; c < 16; ++c) wf[c] = *reinterpret_cast<const f32x4a*>(p + c * 8);
 }
+// the same fragments from a copy packed in lane order ([32-column group][chunk][lane] float4): one contiguous 1 KiB per load
+__device__ __forceinline__ void rg_load_w128_packed(const f32x4* P, int group, int lane, f32x4 (&wf)[16]) {
+  const f32x4* p = P + (size_t)group * 16 * 64 + lane;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) wf[c] = p[c * 64];
+}
 __device__ __forceinline__ f32x16 rg_mma128(const float* xs, int i, int h, const f32x4 (&wf)[16]) {
   f32x16 acc;
 #pragma unroll
@@ -406,6 +412,7 @@ __device__ __forceinline__ f32x16 rg_mma128(const float* xs, int i, int h, const
 }
 }  // namespace
 
+template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void egx_regressor_fused_kernel(RegWeights w, const float* __restrict__ Y,
                                                                      const float* __restrict__ betas, int A, int M,
                                                                      float* __restrict__ out_Yb) {
@@ -430,14 +437,32 @@ __global__ __launch_bounds__(256, 2) void egx_regressor_fused_kernel(RegWeights 
   f32x4 wcur[16], wnext[16];
   for (int rc = 0; rc < 3; ++rc) {
     // prefetch the first block layer's weights; they are independent of the activations
-    rg_load_w128(w.blk_w[0], n0 + i, h, wcur);
+    if (PACKED) rg_load_w128_packed(w.pk_blk, wave, lane, wcur);
+    else rg_load_w128(w.blk_w[0], n0 + i, h, wcur);
     // ---- in_fc: [32,370] x [128,370]^T, streamed in groups of 4 chunks
     {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* wrow = w.in_w + (size_t)(n0 + i) * RG_KIN + 4 * h;
       const float* xr = xin + i * RG_LDX + 4 * h;
+      if (PACKED) {
+        // 47 chunks of 8 k (370 padded with zeros to 376): four chunks per round trip
+        const f32x4* pw = w.pk_in + (size_t)wave * 47 * 64 + lane;
+        constexpr int NCHP = 47;
+        for (int c = 0; c < NCHP; c += 4) {
+          f32x4 wf4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) wf4[u] = pw[(size_t)min(c + u, NCHP - 1) * 64];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (c + u >= NCHP) break;
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(xr + (c + u) * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wf4[u][e], acc, 0, 0, 0);
+          }
+        }
+      } else {
+      const float* wrow = w.in_w + (size_t)(n0 + i) * RG_KIN + 4 * h;
       constexpr int NCH = 46;  // full 8-wide chunks; k = 368,369 handled below
       f32x4 wf[2][2];
       wf[0][0] = *reinterpret_cast<const f32x4a*>(wrow);
@@ -462,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void egx_regressor_fused_kernel(RegWeights 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wt[e], acc, 0, 0, 0);
       }
+      }
       const float b = w.in_b[n0 + i];
 #pragma unroll
       for (int r = 0; r < 16; ++r) hb[((r & 3) + 8 * (r >> 2) + 4 * h) * RG_LDH + n0 + i] = acc[r] + b;
@@ -478,7 +504,8 @@ __global__ __launch_bounds__(256, 2) void egx_regressor_fused_kernel(RegWeights 
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc = rg_mma128(src, i, h, wcur);
       __builtin_amdgcn_sched_barrier(0);
-      rg_load_w128(Wn, n0 + i, h, wnext);
+      if (PACKED) rg_load_w128_packed((l + 1 < 20) ? w.pk_blk + (size_t)(l + 1) * 4 * 16 * 64 : w.pk_out, wave, lane, wnext);
+      else rg_load_w128(Wn, n0 + i, h, wnext);
       const float b = w.blk_b[l][n0 + i];
       if ((l & 1) == 0) {
 #pragma unroll
@@ -497,7 +524,10 @@ __global__ __launch_bounds__(256, 2) void egx_regressor_fused_kernel(RegWeights 
     // ---- out_fc: N = 159 -> tiles 0..4; wave w owns tile w (weights already in wcur), wave 0 also tile 4
     for (int tI = wave; tI < 5; tI += 4) {
       const int nn = tI * 32 + i;
-      if (tI >= 4) rg_load_w128(w.out_w, min(nn, RG_NOUT - 1), h, wcur);
+      if (tI >= 4) {
+        if (PACKED) rg_load_w128_packed(w.pk_out, tI, lane, wcur);
+        else rg_load_w128(w.out_w, min(nn, RG_NOUT - 1), h, wcur);
+      }
       f32x16 acc = rg_mma128(hb, i, h, wcur);
       if (nn < RG_NOUT) {
         const float b = w.out_b[nn];
@@ -522,11 +552,16 @@ int egx_launch_regressor_fused(hipStream_t st, const RegWeights& w, const float*
   const size_t lds = (size_t)(RG_RT * RG_LDX + 2 * RG_RT * RG_LDH) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {  // 80 KiB of dynamic LDS: above the 64 KiB default cap
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel),
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(egx_regressor_fused_kernel, dim3(egx_ceil_div(M, RG_RT)), dim3(256), lds, st, w, Y, betas, A, M, out_Yb);
+  if (w.pk_in && w.pk_blk && w.pk_out)
+    hipLaunchKernelGGL(egx_regressor_fused_kernel<true>, dim3(egx_ceil_div(M, RG_RT)), dim3(256), lds, st, w, Y, betas, A, M, out_Yb);
+  else
+    hipLaunchKernelGGL(egx_regressor_fused_kernel<false>, dim3(egx_ceil_div(M, RG_RT)), dim3(256), lds, st, w, Y, betas, A, M, out_Yb);
   return EGX_OK;
 }
 

@@ -121,6 +121,10 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
     RegWeights rw;
     rw.in_w = w->reg_in_w; rw.in_b = w->reg_in_b; rw.out_w = w->reg_out_w; rw.out_b = w->reg_out_b;
     for (int l = 0; l < 20; ++l) { rw.blk_w[l] = w->reg_blk_w[l]; rw.blk_b[l] = w->reg_blk_b[l]; }
+    const bool packed = w->reg_packed_in && w->reg_packed_blk && w->reg_packed_out;
+    rw.pk_in = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_in) : nullptr;
+    rw.pk_blk = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_blk) : nullptr;
+    rw.pk_out = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_out) : nullptr;
     int rc = egx_launch_regressor_fused(st, rw, out_Y, betas, A, M, out_Yb);
     if (rc) return rc;
   }

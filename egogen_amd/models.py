@@ -155,6 +155,7 @@ class MoshRegressor(nn.Module):
         self.pnet = ResNetBlock(self.in_dim + self.body_dim + 10, 128, self.body_dim, 10, "relu")
 
 
+PACK_REGRESSOR_WEIGHTS = os.environ.get("EGX_PACK_REGRESSOR", "1") == "1"
 FOLD_DECODER_OUTPUT = os.environ.get("EGX_FOLD_DECODER_OUTPUT", "1") == "1"
 
 
@@ -170,8 +171,9 @@ class GAMMAPrimitiveCombo(nn.Module):
     def _weights(self) -> _lib.PriorWeights:
         p, r = self.predictor, self.regressor.pnet
         # pointer + in-place version of the tensors the folded decoder weights depend on
+        reg_w = [r.in_fc.weight, r.out_fc.weight] + [r.layers[b].layers[k].weight for b in range(10) for k in range(2)]
         key = (p.x_enc.weight_ih_l0.data_ptr(), r.out_fc.weight.data_ptr(), p.d_rnn.weight_ih._version, p.d_out.weight._version,
-               p.d_out.bias._version)
+               p.d_out.bias._version) + tuple(t._version for t in reg_w)
         if self._wstruct is not None and self._wkey == key:
             return self._wstruct
         w = _lib.PriorWeights()
@@ -195,6 +197,20 @@ class GAMMAPrimitiveCombo(nn.Module):
             self._comb_w = (wy @ p.d_out.weight.double()).float().contiguous()
             self._comb_b = (wy @ p.d_out.bias.double()).float().contiguous()
         w.d_comb_w, w.d_comb_b = (_p(self._comb_w), _p(self._comb_b)) if FOLD_DECODER_OUTPUT else (None, None)
+        # the regressor's weights once more in the lane order of the MFMA B operand (egx_prior_weights.reg_packed_*):
+        # P[g][c][32 h + i][e] = W[32 g + i][8 c + 4 h + e], so that each weight load of the fused kernel is one contiguous KiB
+        if PACK_REGRESSOR_WEIGHTS and r.in_fc.weight.is_cuda:
+            with torch.no_grad():
+                def pack(W, groups, chunks):
+                    Wp = torch.zeros(groups * 32, chunks * 8, dtype=torch.float32, device=W.device)
+                    Wp[:W.shape[0], :W.shape[1]] = W
+                    if W.shape[0] < groups * 32:
+                        Wp[W.shape[0]:, :W.shape[1]] = W[-1]
+                    return Wp.view(groups, 32, chunks, 2, 4).permute(0, 2, 3, 1, 4).contiguous()
+                self._pk_in = pack(r.in_fc.weight, 4, 47)
+                self._pk_blk = torch.stack([pack(r.layers[b].layers[k].weight, 4, 16) for b in range(10) for k in range(2)]).contiguous()
+                self._pk_out = pack(r.out_fc.weight, 5, 16)
+            w.reg_packed_in, w.reg_packed_blk, w.reg_packed_out = _p(self._pk_in), _p(self._pk_blk), _p(self._pk_out)
         self._wstruct, self._wkey = w, key
         return w
 

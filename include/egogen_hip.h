@@ -240,6 +240,12 @@ typedef struct egx_prior_weights {
    * gi_(i+1) = gi_i + h_i . d_comb_w^T + d_comb_b: with the two folded tensors the output layer leaves the 18-step
    * critical path and is evaluated for all steps at once afterwards. */
   const float *d_comb_w, *d_comb_b;
+  /* Optional (all three or none; NULL = read the torch-layout weights above): the regressor's weights repacked in the lane
+   * order of the matrix instruction's B operand, so that every weight load of the fused kernel is one contiguous 1 KiB:
+   *   P[group g][chunk c][lane l = 32 h + i][e] = W[32 g + i][8 c + 4 h + e]
+   * reg_packed_in  [4][47][64][4] (in_fc, K 370 zero-padded to 376), reg_packed_blk [20][4][16][64][4] (the 20 block
+   * layers), reg_packed_out [5][16][64][4] (out_fc, rows past 158 repeat row 158). */
+  const float *reg_packed_in, *reg_packed_blk, *reg_packed_out;
 } egx_prior_weights;
 
 size_t egx_sample_prior_workspace_bytes(int num_agents);
