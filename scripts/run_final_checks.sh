@@ -1,3 +1,7 @@
+#!/bin/bash
+# End-of-round checks on the GPU box: the whole `-m gpu` suite, __graft_entry__.smoke(), the default bench line and the
+# rocprofv3 kernel-trace summary of the bench command; everything lands under gpurun_out/final/.
+#   gpurun --timeout 4500 -- 'bash scripts/run_final_checks.sh'
 set -u
 mkdir -p gpurun_out/final
 timeout 2400 python -m pytest tests -x -q -m gpu < /dev/null > gpurun_out/final/gpu_tests.log 2>&1
