@@ -162,6 +162,8 @@ SIGNATURES = {
     "egx_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "egx_event_destroy": (C.c_int, [C.c_void_p]),
     "egx_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "egx_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
+    "egx_stream_destroy": (C.c_int, [C.c_void_p]),
     "egx_vposer_workspace_bytes": (C.c_size_t, [C.c_int]),
     "egx_vposer_encode": (C.c_int, [C.POINTER(VposerWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),

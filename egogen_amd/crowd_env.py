@@ -361,7 +361,18 @@ class VecCrowdEnv:
             self.sample_candidates()
         self._injected = False
         self._launch_reset(mask)
+        if mask is None:
+            self.invalid.zero_()
         return self.obs()
+
+    def clear_invalid(self, mask: Optional[torch.Tensor] = None):
+        """Forget the EgoBody filter flags (`invalid`, OR-accumulated by the step kernel) of the masked agents (all without a
+        mask).  A full `reset()` starts new episodes everywhere and clears them; the auto-reset inside `step` does not, so that
+        the evaluation driver can still read which scenes tripped a filter after their episodes ended."""
+        if mask is None:
+            self.invalid.zero_()
+        else:
+            self.invalid.mul_((mask == 0).to(self.invalid.dtype))
 
     # ------------------------------------------------------------------------------------------
     def _step_core(self):
@@ -488,6 +499,7 @@ class CrowdGroupEnv:
             m.sample_candidates()
             m._injected = True
             m._launch_reset(None)
+            m.invalid.zero_()            # new episodes everywhere: the filter flags of the previous ones are history
         obs = []
         for m in self.members:
             m._launch_reset(None)        # same candidates: identical state, observation now sees all boxes

@@ -47,6 +47,19 @@ extern "C" int egx_event_elapsed_ms(void* start_event, void* stop_event, float* 
   EGX_HIP_CHECK(hipEventElapsedTime(out_ms, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event)));
   return EGX_OK;
 }
+// Streams restricted to part of the device, for running a throughput-bound launch (the fused LBS kernel) beside a chain of
+// latency-bound launches of another shard of agents: bit i of `mask` (num_words x 32 bits) enables compute unit i.
+extern "C" int egx_stream_create_cu_mask(const uint32_t* mask, int num_words, void** out_stream) {
+  EGX_REQUIRE(mask && num_words > 0 && out_stream, "bad arguments");
+  hipStream_t s;
+  EGX_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)num_words, mask));
+  *out_stream = s;
+  return EGX_OK;
+}
+extern "C" int egx_stream_destroy(void* stream) {
+  if (stream) EGX_HIP_CHECK(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return EGX_OK;
+}
 extern "C" int egx_profile_next_lbs(void* start_event, void* stop_event) {
   g_prof_start = static_cast<hipEvent_t>(start_event);
   g_prof_stop = static_cast<hipEvent_t>(stop_event);
@@ -282,8 +295,12 @@ struct LbsParams {
   int* pene;           // [B]
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_fma(float a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(f32x2{a, a}, b, c); }
+// one v_fma_f32, opaque to the SLP vectoriser (which would pair adjacent rows into v_pk_fma_f32 again)
+__device__ __forceinline__ float lbs_fma(float a, float b, float c) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 
 // fp32-MFMA variant (blend mode 0 and every vertex-writing call): persistent workgroups, one per CU, eight waves = two
 // SETS of four waves; each set walks its own stream of work items (vertex tile x 256 bodies: 4 waves x 64 bodies), so
@@ -404,9 +421,9 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
     const f32x4* Aq = p.A4 + (size_t)min(bt0 + q, num_bt - 1) * NJ * 3 * 32 + n;
     // rows are handled in adjacent pairs (r, r+1): the accumulator registers, weights and outputs of a pair are
     // neighbours, so the nine transform FMAs and three weight FMAs map onto packed fp32 instructions
-    f32x2 o2[8][3];
+    float o[16][3];
 #pragma unroll
-    for (int r2 = 0; r2 < 8; ++r2) { o2[r2][0] = f32x2{0.f, 0.f}; o2[r2][1] = f32x2{0.f, 0.f}; o2[r2][2] = f32x2{0.f, 0.f}; }
+    for (int r = 0; r < 16; ++r) { o[r][0] = tr[q][0]; o[r][1] = tr[q][1]; o[r][2] = tr[q][2]; }
     f32x4 a0, a1, a2;
     {
       const int j = s_jl[0];
@@ -422,28 +439,21 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
       for (int rg = 0; rg < 4; ++rg) {
         const f32x4 w4 = wq[rg];
         if (__builtin_amdgcn_ballot_w64((w4[0] != 0.f) | (w4[1] != 0.f) | (w4[2] != 0.f) | (w4[3] != 0.f)) == 0) continue;
+        // plain v_fma_f32 on purpose (lbs_fma): packed fp32 FMAs beside another wave's MFMAs cost more than they save on
+        // gfx950 (MI355X_MICROARCH.md, price of a filler), and the row pairs they need cost two v_mov per operand
 #pragma unroll
-        for (int e2 = 0; e2 < 2; ++e2) {
-          const int r = rg * 4 + e2 * 2;
-          const f32x2 vx = {acc[0][q][r], acc[0][q][r + 1]}, vy = {acc[1][q][r], acc[1][q][r + 1]},
-                      vz = {acc[2][q][r], acc[2][q][r + 1]};
-          const f32x2 w2 = {w4[e2 * 2], w4[e2 * 2 + 1]};
-          const f32x2 px = pk_fma(a0[0], vx, pk_fma(a0[1], vy, pk_fma(a0[2], vz, f32x2{a0[3], a0[3]})));
-          const f32x2 py = pk_fma(a1[0], vx, pk_fma(a1[1], vy, pk_fma(a1[2], vz, f32x2{a1[3], a1[3]})));
-          const f32x2 pz = pk_fma(a2[0], vx, pk_fma(a2[1], vy, pk_fma(a2[2], vz, f32x2{a2[3], a2[3]})));
-          o2[r >> 1][0] = __builtin_elementwise_fma(w2, px, o2[r >> 1][0]);
-          o2[r >> 1][1] = __builtin_elementwise_fma(w2, py, o2[r >> 1][1]);
-          o2[r >> 1][2] = __builtin_elementwise_fma(w2, pz, o2[r >> 1][2]);
+        for (int e = 0; e < 4; ++e) {
+          const int r = rg * 4 + e;
+          const float vx = acc[0][q][r], vy = acc[1][q][r], vz = acc[2][q][r], wv = w4[e];
+          const float px = lbs_fma(a0[0], vx, lbs_fma(a0[1], vy, lbs_fma(a0[2], vz, a0[3])));
+          const float py = lbs_fma(a1[0], vx, lbs_fma(a1[1], vy, lbs_fma(a1[2], vz, a1[3])));
+          const float pz = lbs_fma(a2[0], vx, lbs_fma(a2[1], vy, lbs_fma(a2[2], vz, a2[3])));
+          o[r][0] = lbs_fma(wv, px, o[r][0]);
+          o[r][1] = lbs_fma(wv, py, o[r][1]);
+          o[r][2] = lbs_fma(wv, pz, o[r][2]);
         }
       }
       a0 = n0; a1 = n1; a2 = n2;
-    }
-    float o[16][3];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o[r][0] = o2[r >> 1][0][r & 1] + tr[q][0];
-      o[r][1] = o2[r >> 1][1][r & 1] + tr[q][1];
-      o[r][2] = o2[r >> 1][2][r & 1] + tr[q][2];
     }
 #ifdef EGX_LBS_TIMING
     __builtin_amdgcn_sched_barrier(0);
@@ -1148,6 +1158,7 @@ constexpr int kMaxDevices = 64;
 struct LbsDeviceInfo {
   std::mutex mu;
   int num_cu = 0;
+  std::map<hipStream_t, int> stream_cus;   // CUs a stream may use (CU-masked streams), looked up on first use
 };
 LbsDeviceInfo g_lbs_dev[kMaxDevices];
 // blend mode of the fused kernel: 0 = fp32 MFMA, 1 = 3-term bf16 split, 2 = 2-term bf16 split (default); vertex-writing
@@ -1238,10 +1249,11 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   const bool need_picks = out_joints || out_markers;
   float* picked = need_picks ? reinterpret_cast<float*>(ws + wl.picked) : nullptr;
 
-  const bool split3 = blend_mode() >= 1 && !out_verts;
+  const int mode = blend_mode();   // read ONCE per call: the feature flag of column 470 and the kernel choice must agree
+  const bool split3 = mode >= 1 && !out_verts;
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, stream, m->pc, xb, betas, B, fpa,
                      split3 ? nullptr : feat, split3 ? reinterpret_cast<unsigned short*>(feat) : nullptr, A4, out_joints,
-                     EGX_NUM_JOINTS_OUT, (split3 && blend_mode() == 2) ? 1.f : 0.f);
+                     EGX_NUM_JOINTS_OUT, (split3 && mode == 2) ? 1.f : 0.f);
   if (out_verts || need_picks || sdf) {
     LbsParams p;
     p.dirs = m->dirs; p.tj_off = m->tj_off; p.tj_idx = m->tj_idx; p.tj_w = m->tj_w; p.pick_slot = m->pick_slot;
@@ -1296,7 +1308,23 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
         di.num_cu = prop.multiProcessorCount;
       }
     }
-    const int num_cu = di.num_cu;
+    // a stream created with a CU mask (hipExtStreamCreateWithCUMask / egx_stream_create_cu_mask) runs on part of the device:
+    // the persistent grid is sized for the CUs that stream may use (looked up once per stream)
+    int num_cu = di.num_cu;
+    if (stream) {
+      std::lock_guard<std::mutex> lk(di.mu);
+      auto it = di.stream_cus.find(stream);
+      if (it == di.stream_cus.end()) {
+        uint32_t mask[16] = {0};
+        int n = 0;
+        if (hipExtStreamGetCUMask(stream, 16, mask) == hipSuccess)
+          for (uint32_t m32 : mask) n += __builtin_popcount(m32);
+        else
+          (void)hipGetLastError();
+        it = di.stream_cus.emplace(stream, (n > 0 && n < di.num_cu) ? n : di.num_cu).first;
+      }
+      num_cu = it->second;
+    }
     p.bg_block = 2;
 #ifdef EGX_LBS_DEVELOPMENT
     if (const char* e = getenv("EGX_LBS_BG_BLOCK")) p.bg_block = atoi(e);
@@ -1309,7 +1337,6 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     if (ev0) EGX_HIP_CHECK(hipEventRecord(ev0, stream));
     if (split3) {
       // two persistent 4-wave workgroups per CU: one's VALU epilogue runs under the other's MFMA stages
-      const int mode = blend_mode();
       constexpr size_t lds3 = (size_t)LBS3_SHARED_BYTES + 4 * LBS3_WAVE_BYTES;
       const int grid3 = std::max(1, std::min(2 * num_cu, n_items));
       if (mode == 2) {

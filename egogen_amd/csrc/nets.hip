@@ -6,6 +6,7 @@
 // fused into the epilogue.  Inputs may be the concatenation of up to 4 row-major segments (the reference
 // builds them with torch.cat: models_GAMMA_primitive.py:93,257; models_policy_ppo.py:305) - no copy is made.
 // Weights are read in torch's own [N,K] layout so the same storage serves the autograd update path.
+#include <mutex>
 #include "egx_nets.h"
 
 namespace {
@@ -550,13 +551,20 @@ __global__ __launch_bounds__(256, 2) void egx_regressor_fused_kernel(RegWeights 
 int egx_launch_regressor_fused(hipStream_t st, const RegWeights& w, const float* Y, const float* betas, int A, int M,
                                float* out_Yb) {
   const size_t lds = (size_t)(RG_RT * RG_LDX + 2 * RG_RT * RG_LDH) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {  // 80 KiB of dynamic LDS: above the 64 KiB default cap
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+  {  // 80 KiB of dynamic LDS: above the 64 KiB default cap; raised once per DEVICE (the attribute is per device)
+    static std::mutex mu;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    EGX_HIP_CHECK(hipGetDevice(&dev));
+    EGX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
+    std::lock_guard<std::mutex> lk(mu);
+    if (!attr_set[dev]) {
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set[dev] = true;
+    }
   }
   if (w.pk_in && w.pk_blk && w.pk_out)
     hipLaunchKernelGGL(egx_regressor_fused_kernel<true>, dim3(egx_ceil_div(M, RG_RT)), dim3(256), lds, st, w, Y, betas, A, M, out_Yb);

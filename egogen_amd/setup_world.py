@@ -68,8 +68,9 @@ def load_model(box: bool = False, cfg_dir: Optional[str] = None) -> dict:
     cfg.update(dirs)
     cfg["trainconfig"]["save_dir"] = dirs["cfg_ckpt_dir"]
     cfg["trainconfig"]["log_dir"] = dirs["cfg_log_dir"]
-    with open(os.path.join(dirs["cfg_exp_dir"], "config.yaml"), "w") as fh:
-        yaml.safe_dump(cfg, fh, sort_keys=False)
+    if int(os.environ.get("RANK", "0")) == 0:   # data-parallel ranks share the directory: one writer
+        with open(os.path.join(dirs["cfg_exp_dir"], "config.yaml"), "w") as fh:
+            yaml.safe_dump(cfg, fh, sort_keys=False)
     return cfg
 
 

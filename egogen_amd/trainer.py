@@ -68,6 +68,19 @@ class Collector:
         self.ep_ret *= (1 - d)
         self.ep_len *= (1 - d)
 
+    def _fusable(self, obs, rew, term) -> bool:
+        """egx_rollout_store reads raw pointers: fp32 state[A,2,402] / egosensing[A,2,32] / dist[A] / time[A] / reward[A] and
+        int32 terminated[A], all contiguous on the device.  Anything else (an env wrapper returning bool flags, views, other
+        dtypes) goes through the converting copy_ path instead."""
+        A = self.A
+        want = (("state", (A, 2, 402)), ("egosensing", (A, 2, 32)), ("dist", (A,)), ("time", (A,)))
+        for k, shape in want:
+            t = obs.get(k)
+            if t is None or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape:
+                return False
+        return (rew.is_cuda and rew.dtype == torch.float32 and rew.is_contiguous() and tuple(rew.shape) == (A,) and
+                term.is_cuda and term.dtype == torch.int32 and term.is_contiguous() and tuple(term.shape) == (A,))
+
     def _save_rollouts(self, term):
         """save_rollout_results per finished episode (crowd_env_2f.py:154-155,305-309) - host side, only when asked."""
         from .utils import save_rollout_results
@@ -92,7 +105,7 @@ class Collector:
         if b is None:
             b = RolloutBatch(n_vec_steps, self.A, self.env.dev)
             self._batches[n_vec_steps] = b
-        fused = self._episodes is None and self.obs["state"].is_cuda
+        fused = self._episodes is None and self._fusable(self.obs, self.env.reward, self.env.terminated)
         if fused:
             from . import _lib
             lib, ptr = _lib.load(), _lib.ptr

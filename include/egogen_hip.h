@@ -440,6 +440,14 @@ int egx_event_create(void** out_event);
 int egx_event_destroy(void* event);
 int egx_event_elapsed_ms(void* start_event, void* stop_event, float* out_ms); /* synchronises on stop_event */
 
+/* Streams restricted to part of the device (bit i of `mask`, num_words x 32 bits, enables compute unit i): the collector
+ * steps two shards of agents on separate streams and launches the throughput-bound SMPL-X kernel of one shard on such a
+ * stream, so that the other shard's chain of small dependent launches keeps the remaining compute units (the reference
+ * steps its environments one after the other on the default stream, crowd_ppo/main_ppo.py:97,177-183).  egx_lbs_forward
+ * sizes its persistent grid for the compute units of the stream it is given. */
+int egx_stream_create_cu_mask(const uint32_t* mask, int num_words, void** out_stream);
+int egx_stream_destroy(void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * PPO update: fused loss + gradient of one minibatch (crowd_ppo/ppo_policy.py:189-241) and the backward of the
  * GRU gate math.  Used as custom autograd nodes by the host; dense-layer backward stays on rocBLAS this round.
