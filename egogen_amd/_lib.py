@@ -45,6 +45,12 @@ class LinearDesc(C.Structure):
                 ("out", C.c_void_p), ("out_ld", C.c_int), ("activation", C.c_int), ("leaky_slope", C.c_float)]
 
 
+class PriorPacked3(C.Structure):
+    _fields_ = [("x_enc_w_ih", C.c_void_p), ("x_enc_w_hh", C.c_void_p), ("drnn_w", C.c_void_p * 3), ("d_rnn_w_hz", C.c_void_p),
+                ("d_rnn_w_y", C.c_void_p), ("d_rnn_w_hh", C.c_void_p), ("d_comb_w", C.c_void_p), ("d_mlp_w", C.c_void_p * 2),
+                ("d_out_w", C.c_void_p)]
+
+
 class PriorWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x_enc_w_ih", "x_enc_w_hh", "x_enc_b_ih", "x_enc_b_hh")] + \
                [("drnn_w", C.c_void_p * 3), ("drnn_b", C.c_void_p * 3)] + \
@@ -52,7 +58,8 @@ class PriorWeights(C.Structure):
                [("d_mlp_w", C.c_void_p * 2), ("d_mlp_b", C.c_void_p * 2), ("d_out_w", C.c_void_p), ("d_out_b", C.c_void_p),
                 ("reg_in_w", C.c_void_p), ("reg_in_b", C.c_void_p), ("reg_blk_w", C.c_void_p * 20), ("reg_blk_b", C.c_void_p * 20),
                 ("reg_out_w", C.c_void_p), ("reg_out_b", C.c_void_p), ("d_comb_w", C.c_void_p), ("d_comb_b", C.c_void_p),
-                ("reg_packed_in", C.c_void_p), ("reg_packed_blk", C.c_void_p), ("reg_packed_out", C.c_void_p)]
+                ("reg_packed_in", C.c_void_p), ("reg_packed_blk", C.c_void_p), ("reg_packed_out", C.c_void_p),
+                ("packed3", C.POINTER(PriorPacked3))]
 
 
 class PolicyWeights(C.Structure):
@@ -162,6 +169,8 @@ SIGNATURES = {
     "egx_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "egx_event_destroy": (C.c_int, [C.c_void_p]),
     "egx_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "egx_pack3_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "egx_pack3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "egx_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
     "egx_stream_destroy": (C.c_int, [C.c_void_p]),
     "egx_vposer_workspace_bytes": (C.c_size_t, [C.c_int]),

@@ -47,3 +47,63 @@ int egx_launch_regressor_fused(hipStream_t st, const RegWeights& w, const float*
 int egx_launch_linear_one(hipStream_t st, const EgxLin& A);  // honours EgxLin::bf16 (always the 32x32 split-K kernel)
 // y[t][a][c] += y[t-1][a][c] for t = 0..T-1 with y[-1] = x_last[a][c] (row stride x_ld): residual chain of the decoder
 void egx_launch_frame_scan(hipStream_t st, float* y, const float* x_last, int x_ld, int A, int width, int T);
+
+// ---- dense3.hip: dense layers on the bf16 matrix pipe, operands as three bf16 planes in MFMA fragment order -------------
+// Packed image of a row-major fp32 matrix [R, K]: [2 ceil(R/32) row tiles of 16][K/32 k-steps][3 planes][64 lanes] x 16 bytes.
+struct D3Pack {
+  const float* src;
+  int R, K, ld, col0;   // rows, columns taken, leading dimension, first column
+  void* dst;
+  int S_total, s0;      // k-steps per row tile of the destination buffer, k-step this image starts at
+};
+void egx_launch_pack3(hipStream_t st, const D3Pack* jobs, int njobs);  // njobs <= 3, one launch
+
+// out = act(A B^T + bias) + res.  A: packed activations (k-steps sa0 .. sa0 + S of a buffer with SA k-steps per row tile);
+// B: packed weights [N, K = 32 S].  Outputs: fp32 row-major `out` and / or packed `out3` (the consumer's A operand: this
+// layer's 32-column tile nt is k-step s30 + nt of a buffer with S3 k-steps per row tile; needs N % 32 == 0).  `batches`
+// > 1: the same layer for several row blocks (A advances by batch_strideA fragments, out3 by batch_stride3, fp32 rows by
+// batch_rows_out).
+struct D3Plain {
+  const bf16x8* A = nullptr;
+  int SA = 0, sa0 = 0;
+  const bf16x8* B = nullptr;
+  int S = 0;
+  const float* bias = nullptr;
+  const float* res = nullptr;
+  int ldr = 0;
+  float* out = nullptr;
+  int ldo = 0;
+  bf16x8* out3 = nullptr;
+  int S3 = 0, s30 = 0;
+  int M = 0, N = 0, act = 0;
+  float slope = 0.f;
+  int batches = 1;
+  size_t batch_strideA = 0, batch_stride3 = 0;
+  int batch_rows_out = 0;
+};
+void egx_launch_dense3(hipStream_t st, const D3Plain& p);
+void egx_launch_dense3_pair(hipStream_t st, const D3Plain& p, const D3Plain& q);  // two independent layers, one launch
+
+// One GRU cell step (gate order r, z, n; weights [3H, K] packed): see egx_gru3_kernel.
+struct D3Gru {
+  const bf16x8* Ai = nullptr;   // x side
+  int SAi = 0, sai0 = 0;
+  const bf16x8* Bi = nullptr;
+  int Si = 0;
+  const float* bias_i = nullptr;
+  const float* gi_in = nullptr;   // [M, 3H] added to the x-side product (null = 0)
+  float* gi_out = nullptr;        // [M, 3H] or null (may alias gi_in)
+  const bf16x8* Ah = nullptr;   // h side (null: zero previous state)
+  int SAh = 0, sah0 = 0;
+  const bf16x8* Bh = nullptr;
+  int Sh = 0;
+  const float* bias_h = nullptr;
+  const float* h_prev = nullptr;  // fp32 [M, H] (ld ldh) or null
+  int ldh = 0;
+  float* h_out = nullptr;         // fp32 [M, H] (ld ldo) or null
+  int ldo = 0;
+  bf16x8* h_out3 = nullptr;       // packed, k-steps s30 .. s30 + H / 32 of a buffer with S3 per row tile, or null
+  int S3 = 0, s30 = 0;
+  int M = 0, H = 0;
+};
+int egx_launch_gru3(hipStream_t st, const D3Gru& g);

@@ -1,5 +1,6 @@
 // Whole-network entry points: the motion prior (C-VAE decode + body regressor), the policy networks and
 // the VPoser encoder, each as one C call that enqueues its chain of fused dense-layer kernels.
+#include <algorithm>
 #include <atomic>
 #include "egx_nets.h"
 
@@ -23,11 +24,114 @@ size_t carve_bytes(std::initializer_list<size_t> nfloats) {
 }
 }  // namespace
 
+// packed-activation buffers of the dense3 decoder path: row tiles (of 16) x k-steps x 3072 bytes
+constexpr size_t FRAG_FLOATS = 3 * 64 * 4;   // one (row tile, k-step): three planes of 64 lanes x 16 bytes, in floats
+inline size_t rt16(int A) { return 2 * (size_t)egx_ceil_div(A, 32); }
+constexpr int S_MK = 7, S_H = 8, S_HZ = 12, S_512 = 16;   // k-steps of 201 / 256 / 384 / 512 columns
+
 extern "C" size_t egx_sample_prior_workspace_bytes(int A) {
   if (A <= 0) return 0;
   const size_t a = A, m = (size_t)A * T_PRED;
-  (void)m;
-  return carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 3 * H, a * 512, a * H, m * H});
+  const size_t fp32_path = carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 3 * H, a * 512, a * H, m * H});
+  const size_t rt = rt16(A);
+  const size_t packed_path = carve_bytes({rt * S_MK * FRAG_FLOATS, rt * S_MK * FRAG_FLOATS, rt * S_HZ * FRAG_FLOATS,
+                                          rt * S_H * FRAG_FLOATS, rt * S_512 * FRAG_FLOATS, rt * S_H * FRAG_FLOATS,
+                                          rt * S_H * FRAG_FLOATS, rt * S_H * FRAG_FLOATS, T_PRED * rt * S_H * FRAG_FLOATS,
+                                          a * 3 * H, a * 3 * H, a * H, a * H, a * H});
+  return std::max(fp32_path, packed_path);
+}
+
+// The decoder on packed operands (dense3.hip): every activation between two products lives as three bf16 planes in MFMA
+// fragment order, written by its producer; the GRU cell is one launch.  Same arithmetic as the fp32 path below up to the
+// 2^-24 of the split products.
+static int sample_prior_packed(const egx_prior_weights* w, const float* x0, const float* x1, int x_ld, const float* z, int A,
+                               float* out_Y, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const egx_prior_packed3& P = *w->packed3;
+  Carver cv(workspace, workspace_bytes);
+  const size_t rt = rt16(A);
+  auto take3 = [&](size_t ksteps) { return reinterpret_cast<bf16x8*>(cv.take(rt * ksteps * FRAG_FLOATS)); };
+  bf16x8* x0p = take3(S_MK);
+  bf16x8* x1p = take3(S_MK);
+  bf16x8* hz3 = take3(S_HZ);      // [hx | z]
+  bf16x8* hB3 = take3(S_H);
+  bf16x8* t512 = take3(S_512);
+  bf16x8* t256 = take3(S_H);
+  bf16x8* h3[2] = {take3(S_H), take3(S_H)};
+  bf16x8* hfc_all = reinterpret_cast<bf16x8*>(cv.take(T_PRED * rt * S_H * FRAG_FLOATS));
+  const size_t hfc_stride = rt * S_H * 3 * 64;   // fragments per decode step
+  float* gi = cv.take((size_t)A * 3 * H);
+  float* gconst = cv.take((size_t)A * 3 * H);
+  float* hBf = cv.take((size_t)A * H);
+  float* hf[2] = {cv.take((size_t)A * H), cv.take((size_t)A * H)};
+  auto B3 = [](const void* p) { return static_cast<const bf16x8*>(p); };
+  {
+    const D3Pack jobs[3] = {{x0, A, MK, x_ld, 0, x0p, S_MK, 0}, {x1, A, MK, x_ld, 0, x1p, S_MK, 0}, {z, A, ZD, ZD, 0, hz3, S_HZ, S_H}};
+    egx_launch_pack3(st, jobs, 3);
+  }
+  // ---- x_enc GRU over the two history frames (zero initial state) -> hx = k-steps 0..7 of [hx | z]
+  {
+    D3Gru g;
+    g.M = A; g.H = H;
+    g.Ai = x0p; g.SAi = S_MK; g.Bi = B3(P.x_enc_w_ih); g.Si = S_MK; g.bias_i = w->x_enc_b_ih;
+    g.bias_h = w->x_enc_b_hh;
+    g.h_out = hBf; g.ldo = H; g.h_out3 = hB3; g.S3 = S_H;
+    egx_launch_gru3(st, g);
+    g.Ai = x1p;
+    g.Ah = hB3; g.SAh = S_H; g.Bh = B3(P.x_enc_w_hh); g.Sh = S_H; g.h_prev = hBf; g.ldh = H;
+    g.h_out = nullptr; g.h_out3 = hz3; g.S3 = S_HZ;
+    egx_launch_gru3(st, g);
+  }
+  // ---- h_rnn = drnn_mlp(hx) (tanh after every layer); beside its first layer: the part of the decoder cell's input product
+  // that does not change over the 18 steps, gconst = [hx | z] W_ih[:, :384]^T + b_ih
+  {
+    D3Plain l0, gc;
+    l0.M = A; l0.N = 512; l0.A = hz3; l0.SA = S_HZ; l0.S = S_H; l0.B = B3(P.drnn_w[0]); l0.bias = w->drnn_b[0]; l0.act = 1;
+    l0.out3 = t512; l0.S3 = S_512;
+    gc.M = A; gc.N = 3 * H; gc.A = hz3; gc.SA = S_HZ; gc.S = S_HZ; gc.B = B3(P.d_rnn_w_hz); gc.bias = w->d_rnn_b_ih;
+    gc.out = gconst; gc.ldo = 3 * H;
+    egx_launch_dense3_pair(st, l0, gc);
+    D3Plain l1;
+    l1.M = A; l1.N = H; l1.A = t512; l1.SA = S_512; l1.S = S_512; l1.B = B3(P.drnn_w[1]); l1.bias = w->drnn_b[1]; l1.act = 1;
+    l1.out3 = t256; l1.S3 = S_H;
+    egx_launch_dense3(st, l1);
+    D3Plain l2;
+    l2.M = A; l2.N = H; l2.A = t256; l2.SA = S_H; l2.S = S_H; l2.B = B3(P.drnn_w[2]); l2.bias = w->drnn_b[2]; l2.act = 1;
+    l2.out = hf[0]; l2.ldo = H; l2.out3 = h3[0]; l2.S3 = S_H;
+    egx_launch_dense3(st, l2);
+  }
+  // ---- 18 decode steps of three launches: GRU cell (input product as the running sum gi, see d_comb_w), two MLP layers
+  int cur = 0;
+  for (int i = 0; i < T_PRED; ++i) {
+    D3Gru g;
+    g.M = A; g.H = H;
+    if (i == 0) {   // y_p = x1: gi = gconst + y_p W_ih[:, 384:]^T
+      g.Ai = x1p; g.SAi = S_MK; g.Bi = B3(P.d_rnn_w_y); g.Si = S_MK; g.gi_in = gconst;
+    } else {        // gi += hfc_(i-1) d_comb_w^T + d_comb_b
+      g.Ai = hfc_all + (size_t)(i - 1) * hfc_stride; g.SAi = S_H; g.Bi = B3(P.d_comb_w); g.Si = S_H; g.bias_i = w->d_comb_b; g.gi_in = gi;
+    }
+    g.gi_out = gi;
+    g.Ah = h3[cur]; g.SAh = S_H; g.Bh = B3(P.d_rnn_w_hh); g.Sh = S_H; g.bias_h = w->d_rnn_b_hh;
+    g.h_prev = hf[cur]; g.ldh = H; g.h_out = hf[cur ^ 1]; g.ldo = H; g.h_out3 = h3[cur ^ 1]; g.S3 = S_H;
+    egx_launch_gru3(st, g);
+    cur ^= 1;
+    D3Plain m0;
+    m0.M = A; m0.N = 512; m0.A = h3[cur]; m0.SA = S_H; m0.S = S_H; m0.B = B3(P.d_mlp_w[0]); m0.bias = w->d_mlp_b[0]; m0.act = 1;
+    m0.out3 = t512; m0.S3 = S_512;
+    egx_launch_dense3(st, m0);
+    D3Plain m1;
+    m1.M = A; m1.N = H; m1.A = t512; m1.SA = S_512; m1.S = S_512; m1.B = B3(P.d_mlp_w[1]); m1.bias = w->d_mlp_b[1]; m1.act = 1;
+    m1.out3 = hfc_all + (size_t)i * hfc_stride; m1.S3 = S_H;
+    egx_launch_dense3(st, m1);
+  }
+  // ---- all 18 output layers as one launch (d_i = d_out(hfc_i)), then the residual chain y_i = d_i + y_(i-1) as a scan
+  {
+    D3Plain o;
+    o.M = A; o.N = MK; o.A = hfc_all; o.SA = S_H; o.S = S_H; o.B = B3(P.d_out_w); o.bias = w->d_out_b;
+    o.out = out_Y; o.ldo = MK; o.batches = T_PRED; o.batch_strideA = hfc_stride; o.batch_rows_out = A;
+    egx_launch_dense3(st, o);
+    egx_launch_frame_scan(st, out_Y, x1, x_ld, A, MK, T_PRED);
+  }
+  return EGX_OK;
 }
 
 extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, const float* x1, int x_ld,
@@ -40,8 +144,28 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
     return EGX_ERR_WORKSPACE;
   }
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  Carver cv(workspace, workspace_bytes);
   const int M = A * T_PRED;
+  auto regress = [&]() -> int {
+    // regressor on all 18*A frames (rows ordered [t][a] like Y_gen.view(nt*nb,-1); betas row = a): one fused launch,
+    // 66 dense layers + the 6D -> axis-angle tail
+    RegWeights rw;
+    rw.in_w = w->reg_in_w; rw.in_b = w->reg_in_b; rw.out_w = w->reg_out_w; rw.out_b = w->reg_out_b;
+    for (int l = 0; l < 20; ++l) { rw.blk_w[l] = w->reg_blk_w[l]; rw.blk_b[l] = w->reg_blk_b[l]; }
+    const bool packed = w->reg_packed_in && w->reg_packed_blk && w->reg_packed_out;
+    rw.pk_in = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_in) : nullptr;
+    rw.pk_blk = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_blk) : nullptr;
+    rw.pk_out = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_out) : nullptr;
+    return egx_launch_regressor_fused(st, rw, out_Y, betas, A, M, out_Yb);
+  };
+  if (w->packed3) {
+    EGX_REQUIRE(w->d_comb_w && w->d_comb_b, "the packed decoder path needs the folded output layer (d_comb_w / d_comb_b)");
+    int rc = sample_prior_packed(w, x0, x1, x_ld, z, A, out_Y, workspace, workspace_bytes, st);
+    if (rc) return rc;
+    if ((rc = regress())) return rc;
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_OK;
+  }
+  Carver cv(workspace, workspace_bytes);
   float* hx = cv.take((size_t)A * H);
   float* hA = cv.take((size_t)A * H);
   float* hB = cv.take((size_t)A * H);
@@ -115,17 +239,8 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
     egx_launch_linear(st, M, MK, &sa, 1, w->d_out_w, w->d_out_b, 0, 0.f, nullptr, 0, out_Y, MK);
     egx_launch_frame_scan(st, out_Y, x1, x_ld, A, MK, T_PRED);
   }
-  // ---- regressor on all 18*A frames (rows ordered [t][a] like Y_gen.view(nt*nb,-1); betas row = a):
-  // one fused launch, 66 dense layers + the 6D -> axis-angle tail
   {
-    RegWeights rw;
-    rw.in_w = w->reg_in_w; rw.in_b = w->reg_in_b; rw.out_w = w->reg_out_w; rw.out_b = w->reg_out_b;
-    for (int l = 0; l < 20; ++l) { rw.blk_w[l] = w->reg_blk_w[l]; rw.blk_b[l] = w->reg_blk_b[l]; }
-    const bool packed = w->reg_packed_in && w->reg_packed_blk && w->reg_packed_out;
-    rw.pk_in = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_in) : nullptr;
-    rw.pk_blk = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_blk) : nullptr;
-    rw.pk_out = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_out) : nullptr;
-    int rc = egx_launch_regressor_fused(st, rw, out_Y, betas, A, M, out_Yb);
+    int rc = regress();
     if (rc) return rc;
   }
   EGX_HIP_CHECK(hipGetLastError());

@@ -35,6 +35,20 @@ def _p(t: torch.Tensor) -> int:
     return t.data_ptr()
 
 
+def pack3(W: torch.Tensor, col0: int = 0, ncols: Optional[int] = None) -> torch.Tensor:
+    """Packed image (three bf16 planes in MFMA fragment order, `egx_pack3`) of the columns [col0, col0 + ncols) of a
+    row-major fp32 device matrix; returned as an opaque byte tensor."""
+    lib = _lib.load()
+    W = W.to(torch.float32)
+    if W.stride(-1) != 1:
+        W = W.contiguous()
+    R, K = int(W.shape[0]), int(W.shape[1] - col0 if ncols is None else ncols)
+    buf = torch.zeros(lib.egx_pack3_bytes(R, K), dtype=torch.uint8, device=W.device)
+    _lib.check(lib.egx_pack3(C.c_void_p(W.data_ptr()), R, K, int(W.stride(0)), int(col0), _lib.ptr(buf), (K + 31) // 32, 0,
+                             _lib.current_stream_ptr()), "egx_pack3")
+    return buf
+
+
 class _Workspace:
     """Scratch of the network entry points, one buffer per stream (calls on distinct streams never share scratch)."""
 
@@ -155,6 +169,7 @@ class MoshRegressor(nn.Module):
         self.pnet = ResNetBlock(self.in_dim + self.body_dim + 10, 128, self.body_dim, 10, "relu")
 
 
+PACK_DECODER_WEIGHTS = os.environ.get("EGX_DECODER_PACKED", "1") != "0"   # development switch: 0 = fp32-MFMA layer kernels
 PACK_REGRESSOR_WEIGHTS = os.environ.get("EGX_PACK_REGRESSOR", "1") == "1"
 FOLD_DECODER_OUTPUT = os.environ.get("EGX_FOLD_DECODER_OUTPUT", "1") == "1"
 
@@ -173,7 +188,8 @@ class GAMMAPrimitiveCombo(nn.Module):
         # pointer + in-place version of the tensors the folded decoder weights depend on
         reg_w = [r.in_fc.weight, r.out_fc.weight] + [r.layers[b].layers[k].weight for b in range(10) for k in range(2)]
         key = (p.x_enc.weight_ih_l0.data_ptr(), r.out_fc.weight.data_ptr(), p.d_rnn.weight_ih._version, p.d_out.weight._version,
-               p.d_out.bias._version) + tuple(t._version for t in reg_w)
+               p.d_out.bias._version) + tuple(t._version for t in reg_w) + \
+              tuple(t._version for t in p.parameters())   # the packed decoder images are copies: stale once a weight changes
         if self._wstruct is not None and self._wkey == key:
             return self._wstruct
         w = _lib.PriorWeights()
@@ -211,6 +227,28 @@ class GAMMAPrimitiveCombo(nn.Module):
                 self._pk_blk = torch.stack([pack(r.layers[b].layers[k].weight, 4, 16) for b in range(10) for k in range(2)]).contiguous()
                 self._pk_out = pack(r.out_fc.weight, 5, 16)
             w.reg_packed_in, w.reg_packed_blk, w.reg_packed_out = _p(self._pk_in), _p(self._pk_blk), _p(self._pk_out)
+        # the decoder's dense weights as three bf16 planes in MFMA fragment order (egx_prior_packed3, csrc/dense3.hip)
+        if PACK_DECODER_WEIGHTS and FOLD_DECODER_OUTPUT and p.x_enc.weight_ih_l0.is_cuda:
+            self._p3_bufs = {}
+            p3 = _lib.PriorPacked3()
+            wih = p.d_rnn.weight_ih
+            jobs = {"x_enc_w_ih": (p.x_enc.weight_ih_l0, 0, None), "x_enc_w_hh": (p.x_enc.weight_hh_l0, 0, None),
+                    "d_rnn_w_hz": (wih, 0, 384), "d_rnn_w_y": (wih, 384, wih.shape[1] - 384), "d_rnn_w_hh": (p.d_rnn.weight_hh, 0, None),
+                    "d_comb_w": (self._comb_w, 0, None), "d_out_w": (p.d_out.weight, 0, None)}
+            for i in range(3):
+                jobs[f"drnn_w{i}"] = (p.drnn_mlp.layers[i].weight, 0, None)
+            for i in range(2):
+                jobs[f"d_mlp_w{i}"] = (p.d_mlp.layers[i].weight, 0, None)
+            for name, (W, col0, ncols) in jobs.items():
+                self._p3_bufs[name] = pack3(W.detach(), col0, ncols)
+            for name in ("x_enc_w_ih", "x_enc_w_hh", "d_rnn_w_hz", "d_rnn_w_y", "d_rnn_w_hh", "d_comb_w", "d_out_w"):
+                setattr(p3, name, self._p3_bufs[name].data_ptr())
+            for i in range(3):
+                p3.drnn_w[i] = self._p3_bufs[f"drnn_w{i}"].data_ptr()
+            for i in range(2):
+                p3.d_mlp_w[i] = self._p3_bufs[f"d_mlp_w{i}"].data_ptr()
+            self._p3 = p3
+            w.packed3 = C.pointer(p3)
         self._wstruct, self._wkey = w, key
         return w
 

@@ -225,6 +225,30 @@ int egx_posenc(const float* dist, const float* time, int num_agents, float* out,
  *     3 recurrences of a 10-block ResNet, 6D -> axis-angle).
  * Weight pointers alias the torch parameters of the same state_dict keys (`predictor.*`, `regressor.*`).
  * ------------------------------------------------------------------------------------------- */
+/* "Packed" matrices of the rollout dense layers (csrc/dense3.hip).  The rollout networks run their products on the bf16
+ * matrix pipe with every fp32 operand carried as three bf16 terms (x = hi + mid + lo, six partial products, fp32
+ * accumulation: 2^-24 relative, the arithmetic of an fp32 product).  A packed image of a row-major fp32 matrix [R, K] is
+ *   [2 ceil(R/32) row tiles of 16][ceil(K/32) k-steps][3 planes][64 lanes] x 8 bf16,
+ *   lane l of a fragment = row (l & 15), columns 32 s + 8 (l >> 4) .. + 7   (operand order of v_mfma_f32_16x16x32_bf16),
+ * zero beyond R / K.  egx_pack3 writes such an image at k-step `dst_kstep0` of a buffer that holds `dst_ksteps` k-steps per
+ * row tile (a concatenated input is several images side by side in one buffer).  Weights [N, K] in torch layout are packed
+ * as they are (row = output feature). */
+size_t egx_pack3_bytes(int num_rows, int num_cols);
+int egx_pack3(const float* src, int num_rows, int num_cols, int src_ld, int src_col0, void* dst, int dst_ksteps,
+              int dst_kstep0, void* stream);
+
+/* Packed images of the C-VAE decoder's dense weights (all of them or none). */
+typedef struct egx_prior_packed3 {
+  const void *x_enc_w_ih, *x_enc_w_hh; /* [768,201], [768,256]                                  */
+  const void *drnn_w[3];               /* [512,256], [256,512], [256,256]                       */
+  const void *d_rnn_w_hz;              /* d_rnn_w_ih[:, 0:384]   (columns of [hx | z])           */
+  const void *d_rnn_w_y;               /* d_rnn_w_ih[:, 384:585] (columns of y_p)                */
+  const void *d_rnn_w_hh;              /* [768,256]                                             */
+  const void *d_comb_w;                /* [768,256] (see d_comb_w below)                        */
+  const void *d_mlp_w[2];              /* [512,256], [256,512]                                  */
+  const void *d_out_w;                 /* [201,256]                                             */
+} egx_prior_packed3;
+
 typedef struct egx_prior_weights {
   const float *x_enc_w_ih, *x_enc_w_hh, *x_enc_b_ih, *x_enc_b_hh; /* predictor.x_enc  GRU(201,256)      */
   const float *drnn_w[3], *drnn_b[3];                             /* predictor.drnn_mlp 256-512-256-256  */
@@ -246,6 +270,10 @@ typedef struct egx_prior_weights {
    * reg_packed_in  [4][47][64][4] (in_fc, K 370 zero-padded to 376), reg_packed_blk [20][4][16][64][4] (the 20 block
    * layers), reg_packed_out [5][16][64][4] (out_fc, rows past 158 repeat row 158). */
   const float *reg_packed_in, *reg_packed_blk, *reg_packed_out;
+  /* Optional (needs d_comb_*): packed images of the decoder's weights.  With them egx_sample_prior runs the decoder on the
+   * bf16 matrix pipe (three-term splits, fp32-equivalent) with the GRU cell as one launch: 3 launches per decode step
+   * instead of 4, each about half as long.  NULL = the fp32-MFMA layer kernels on the torch-layout weights above. */
+  const egx_prior_packed3* packed3;
 } egx_prior_weights;
 
 size_t egx_sample_prior_workspace_bytes(int num_agents);
