@@ -62,11 +62,17 @@ class PriorWeights(C.Structure):
                 ("packed3", C.POINTER(PriorPacked3))]
 
 
+class PolicyPacked3(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x_enc_w_ih", "x_enc_w_hh", "ego_enc_w_ih", "ego_enc_w_hh")] + \
+               [("actor_w", C.c_void_p * 4), ("actor_out_w", C.c_void_p), ("critic_w", C.c_void_p * 4), ("critic_out_w", C.c_void_p)]
+
+
 class PolicyWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x_enc_w_ih", "x_enc_w_hh", "x_enc_b_ih", "x_enc_b_hh",
                                           "ego_enc_w_ih", "ego_enc_w_hh", "ego_enc_b_ih", "ego_enc_b_hh")] + \
                [("actor_w", C.c_void_p * 4), ("actor_b", C.c_void_p * 4), ("actor_out_w", C.c_void_p), ("actor_out_b", C.c_void_p),
-                ("critic_w", C.c_void_p * 4), ("critic_b", C.c_void_p * 4), ("critic_out_w", C.c_void_p), ("critic_out_b", C.c_void_p)]
+                ("critic_w", C.c_void_p * 4), ("critic_b", C.c_void_p * 4), ("critic_out_w", C.c_void_p), ("critic_out_b", C.c_void_p),
+                ("packed3", C.POINTER(PolicyPacked3))]
 
 
 class VposerWeights(C.Structure):

@@ -38,8 +38,10 @@ __device__ __forceinline__ void d3_split(const float (&x)[8], bf16x8 (&pl)[3]) {
   }
 }
 
-// acc += a . b with the six significant partial products, small ones first
-__device__ __forceinline__ f32x4 d3_mma(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
+// acc += a . b with the six significant partial products, small ones first; `one`: the leading product only (operands
+// rounded to bf16, fp32 accumulation - the "bf16 MFMA policy" of BASELINE config 5, egx_policy_set_precision)
+__device__ __forceinline__ f32x4 d3_mma(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc, bool one) {
+  if (one) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
@@ -75,7 +77,7 @@ __host__ __device__ inline int d3_blocks(int MT, int NT) { return 8 * ((NT + 7) 
 // packing: fp32 rows [R, K] (leading dimension ld, starting at column col0) -> [2 ceil(R/32)][S][3][64] fragments at k-step
 // offset s0 of a buffer with S_total k-steps per row tile.  Fragment lane l = (r & 15) + 16 ((k >> 3) & 3), element k & 7.
 // Rows >= R and columns >= K are zero; the row-tile count is even so that a 32-row workgroup tile always finds both of its
-// 16-row halves.  Up to three jobs per launch (the motion prior's x0 / x1 / z).
+// 16-row halves.  Up to four jobs per launch (the motion prior's x0 / x1 / z, the policy's two frames of state and egosensing).
 // ---------------------------------------------------------------------------------------------------------
 struct D3PackJob {
   const float* src;
@@ -84,15 +86,15 @@ struct D3PackJob {
   int S_total, s0;
 };
 struct D3PackJobs {
-  D3PackJob j0, j1, j2;
-  int frags0, frags1;   // fragment counts of jobs 0 and 1 (job 2 takes the rest)
+  D3PackJob j0, j1, j2, j3;
+  int end0, end1, end2;   // running fragment counts: job i owns fragments [end(i-1), end(i))
 };
 
 __global__ __launch_bounds__(256) void egx_pack3_kernel(D3PackJobs jobs) {
   int frag = blockIdx.x * 4 + (threadIdx.x >> 6);   // (rt, s) of one of the jobs
-  const int which = frag < jobs.frags0 ? 0 : (frag < jobs.frags0 + jobs.frags1 ? 1 : 2);
-  const D3PackJob& j = which == 0 ? jobs.j0 : (which == 1 ? jobs.j1 : jobs.j2);
-  frag -= which == 0 ? 0 : (which == 1 ? jobs.frags0 : jobs.frags0 + jobs.frags1);
+  const int which = frag < jobs.end0 ? 0 : (frag < jobs.end1 ? 1 : (frag < jobs.end2 ? 2 : 3));
+  const D3PackJob& j = which == 0 ? jobs.j0 : (which == 1 ? jobs.j1 : (which == 2 ? jobs.j2 : jobs.j3));
+  frag -= which == 0 ? 0 : (which == 1 ? jobs.end0 : (which == 2 ? jobs.end1 : jobs.end2));
   const int lane = threadIdx.x & 63;
   const int RT = 2 * ((j.R + 31) >> 5), S = (j.K + 31) >> 5;
   if (!j.src || frag >= RT * S) return;
@@ -112,9 +114,9 @@ static int d3_pack_frags(int R, int K) { return 2 * egx_ceil_div(R, 32) * egx_ce
 
 void egx_launch_pack3(hipStream_t st, const D3Pack* jobs, int njobs) {
   D3PackJobs J;
-  D3PackJob* dst[3] = {&J.j0, &J.j1, &J.j2};
-  int frags[3] = {0, 0, 0};
-  for (int i = 0; i < 3; ++i) {
+  D3PackJob* dst[4] = {&J.j0, &J.j1, &J.j2, &J.j3};
+  int frags[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
     D3PackJob& d = *dst[i];
     if (i < njobs) {
       d.src = jobs[i].src; d.R = jobs[i].R; d.K = jobs[i].K; d.ld = jobs[i].ld; d.col0 = jobs[i].col0;
@@ -124,25 +126,25 @@ void egx_launch_pack3(hipStream_t st, const D3Pack* jobs, int njobs) {
       d.src = nullptr; d.R = d.K = d.ld = d.col0 = d.S_total = d.s0 = 0; d.dst = nullptr;
     }
   }
-  J.frags0 = frags[0]; J.frags1 = frags[1];
-  const int total = frags[0] + frags[1] + frags[2];
+  J.end0 = frags[0]; J.end1 = J.end0 + frags[1]; J.end2 = J.end1 + frags[2];
+  const int total = J.end2 + frags[3];
   hipLaunchKernelGGL(egx_pack3_kernel, dim3(egx_ceil_div(total, 4)), dim3(256), 0, st, J);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // plain layer: out = act(A B^T + bias) + res for a 32 x 32 output tile per workgroup, the reduction split over the four
-// waves; `two` independent layers may share a launch (blocks [0, blocks0) work on p0).
+// waves; up to three independent layers may share a launch.
 // ---------------------------------------------------------------------------------------------------------
-struct D3Args2 {
-  D3Plain p0, p1;
-  int blocks0;
+struct D3Args3 {
+  D3Plain p0, p1, p2;
+  int end0, end1;   // blocks [0, end0) work on p0, [end0, end1) on p1, the rest on p2
 };
 
 template <int TRIP>
-__global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args2 two) {
-  const bool second = (int)blockIdx.x >= two.blocks0;
-  const D3Plain& a = second ? two.p1 : two.p0;
-  const int bid = second ? (int)blockIdx.x - two.blocks0 : (int)blockIdx.x;
+__global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args3 three) {
+  const int which = (int)blockIdx.x < three.end0 ? 0 : ((int)blockIdx.x < three.end1 ? 1 : 2);
+  const D3Plain& a = which == 0 ? three.p0 : (which == 1 ? three.p1 : three.p2);
+  const int bid = (int)blockIdx.x - (which == 0 ? 0 : (which == 1 ? three.end0 : three.end1));
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ __attribute__((aligned(16))) float tile[32 * 36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args2 two) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d3_mma(fa[u][mi], fb[u][ni], acc[mi][ni]);
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d3_mma(fa[u][mi], fb[u][ni], acc[mi][ni], a.prec != 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru a) {
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) acc[sd][g][mi] = d3_mma(fa[u][mi], fb[u][g], acc[sd][g][mi]);
+          for (int mi = 0; mi < 2; ++mi) acc[sd][g][mi] = d3_mma(fa[u][mi], fb[u][g], acc[sd][g][mi], a.prec != 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -366,24 +368,63 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru a) {
   }
 }
 
+// positional_encoding (models_policy_ppo.py:276-285) of dist and time as the last 128 columns of the policy's [hx | he | pe]
+// input: fp32 into `out` (row stride ld, the residual of the first MLP unit) and packed into k-steps s0 .. s0 + 3 of `out3`.
+__global__ __launch_bounds__(256) void egx_posenc3_kernel(const float* __restrict__ dist, const float* __restrict__ time, int n,
+                                                          float* __restrict__ out, int ld, bf16x8* __restrict__ out3, int S3, int s0) {
+  const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int RT = 2 * ((n + 31) >> 5);
+  if (frag >= RT * 4) return;
+  const int rt = frag >> 2, s = frag & 3;
+  const int row = rt * 16 + (lane & 15), c0 = s * 32 + 8 * (lane >> 4);
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c0 + e;
+    float v = 0.f;
+    if (row < n) {
+      const float f = ((c < 64) ? dist[row] : time[row]) * exp2f((float)((c & 63) >> 1));
+      v = (c & 1) ? cosf(f) : sinf(f);
+      out[(size_t)row * ld + c] = v;
+    }
+    x[e] = v;
+  }
+  bf16x8 pl[3];
+  d3_split(x, pl);
+  bf16x8* o = out3 + ((size_t)rt * S3 + s0 + s) * 3 * 64 + lane;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+}
+void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, int n, float* out, int ld, void* out3, int S3, int s0) {
+  const int frags = 2 * egx_ceil_div(n, 32) * 4;
+  hipLaunchKernelGGL(egx_posenc3_kernel, dim3(egx_ceil_div(frags, 4)), dim3(256), 0, st, dist, time, n, out, ld,
+                     static_cast<bf16x8*>(out3), S3, s0);
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------
-static void d3_launch_plain(hipStream_t st, D3Args2& two, bool pair) {
+static void d3_launch_plain(hipStream_t st, D3Args3& three, int n) {
   auto blocks = [](const D3Plain& p) { return d3_blocks((p.M + 31) >> 5, (p.N + 31) >> 5) * std::max(1, p.batches); };
-  two.blocks0 = blocks(two.p0);
-  const int total = two.blocks0 + (pair ? blocks(two.p1) : 0);
-  const int smax = std::max(two.p0.S, pair ? two.p1.S : 0);
-  if (smax > 16) hipLaunchKernelGGL(egx_dense3_kernel<3>, dim3(total), dim3(256), 0, st, two);
-  else hipLaunchKernelGGL(egx_dense3_kernel<2>, dim3(total), dim3(256), 0, st, two);
+  three.end0 = blocks(three.p0);
+  three.end1 = three.end0 + (n > 1 ? blocks(three.p1) : 0);
+  const int total = three.end1 + (n > 2 ? blocks(three.p2) : 0);
+  const int smax = std::max(three.p0.S, std::max(n > 1 ? three.p1.S : 0, n > 2 ? three.p2.S : 0));
+  if (smax > 16) hipLaunchKernelGGL(egx_dense3_kernel<3>, dim3(total), dim3(256), 0, st, three);
+  else hipLaunchKernelGGL(egx_dense3_kernel<2>, dim3(total), dim3(256), 0, st, three);
 }
 void egx_launch_dense3(hipStream_t st, const D3Plain& p) {
-  D3Args2 two;
-  two.p0 = p; two.p1 = p;
-  d3_launch_plain(st, two, false);
+  D3Args3 t;
+  t.p0 = p; t.p1 = p; t.p2 = p;
+  d3_launch_plain(st, t, 1);
 }
 void egx_launch_dense3_pair(hipStream_t st, const D3Plain& p, const D3Plain& q) {
-  D3Args2 two;
-  two.p0 = p; two.p1 = q;
-  d3_launch_plain(st, two, true);
+  D3Args3 t;
+  t.p0 = p; t.p1 = q; t.p2 = q;
+  d3_launch_plain(st, t, 2);
+}
+void egx_launch_dense3_triple(hipStream_t st, const D3Plain& p, const D3Plain& q, const D3Plain& r) {
+  D3Args3 t;
+  t.p0 = p; t.p1 = q; t.p2 = r;
+  d3_launch_plain(st, t, 3);
 }
 int egx_launch_gru3(hipStream_t st, const D3Gru& g) {
   constexpr size_t lds = (size_t)(4 * 48 * 64 + 32 * 20) * sizeof(float);   // 50.5 KiB: within the default dynamic-LDS cap

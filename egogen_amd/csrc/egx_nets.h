@@ -56,7 +56,7 @@ struct D3Pack {
   void* dst;
   int S_total, s0;      // k-steps per row tile of the destination buffer, k-step this image starts at
 };
-void egx_launch_pack3(hipStream_t st, const D3Pack* jobs, int njobs);  // njobs <= 3, one launch
+void egx_launch_pack3(hipStream_t st, const D3Pack* jobs, int njobs);  // njobs <= 4, one launch
 
 // out = act(A B^T + bias) + res.  A: packed activations (k-steps sa0 .. sa0 + S of a buffer with SA k-steps per row tile);
 // B: packed weights [N, K = 32 S].  Outputs: fp32 row-major `out` and / or packed `out3` (the consumer's A operand: this
@@ -80,9 +80,12 @@ struct D3Plain {
   int batches = 1;
   size_t batch_strideA = 0, batch_stride3 = 0;
   int batch_rows_out = 0;
+  int prec = 0;   // 0: six partial products (fp32-equivalent); 1: leading product only (operands rounded to bf16)
 };
 void egx_launch_dense3(hipStream_t st, const D3Plain& p);
 void egx_launch_dense3_pair(hipStream_t st, const D3Plain& p, const D3Plain& q);  // two independent layers, one launch
+void egx_launch_dense3_triple(hipStream_t st, const D3Plain& p, const D3Plain& q, const D3Plain& r);
+void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, int n, float* out, int ld, void* out3, int S3, int s0);
 
 // One GRU cell step (gate order r, z, n; weights [3H, K] packed): see egx_gru3_kernel.
 struct D3Gru {
@@ -105,5 +108,6 @@ struct D3Gru {
   bf16x8* h_out3 = nullptr;       // packed, k-steps s30 .. s30 + H / 32 of a buffer with S3 per row tile, or null
   int S3 = 0, s30 = 0;
   int M = 0, H = 0;
+  int prec = 0;   // as D3Plain::prec
 };
 int egx_launch_gru3(hipStream_t st, const D3Gru& g);

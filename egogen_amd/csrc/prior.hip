@@ -248,22 +248,111 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
 }
 
 // ---------------------------------------------------------------------------------------------------------
-extern "C" size_t egx_policy_workspace_bytes(int n) {
-  if (n <= 0) return 0;
-  const size_t m = n;
-  return carve_bytes({m * 1536, m * 1536, m * 512, m * 512, m * 512, m * 128, m * 1152, m * 1152, m * 256,
-                      m * 1536, m * 1536, m * 512, m * 1152, m * 1152, m * 1152});
-}
-
 namespace {
 std::atomic<int> g_policy_bf16{0};
 }
+constexpr int PS_ST = 13, PS_EGO = 1, PS_HD = 16, PS_CAT = 36;   // k-steps of 402 / 32 / 512 / 1152 columns
+
+extern "C" size_t egx_policy_workspace_bytes(int n) {
+  if (n <= 0) return 0;
+  const size_t m = n;
+  const size_t fp32_path = carve_bytes({m * 1536, m * 1536, m * 512, m * 512, m * 512, m * 128, m * 1152, m * 1152, m * 256,
+                                        m * 1536, m * 1536, m * 512, m * 1152, m * 1152, m * 1152});
+  const size_t rt = rt16(n);
+  const size_t packed_path = carve_bytes({rt * PS_ST * FRAG_FLOATS, rt * PS_ST * FRAG_FLOATS, rt * PS_EGO * FRAG_FLOATS,
+                                          rt * PS_EGO * FRAG_FLOATS, rt * PS_HD * FRAG_FLOATS, rt * PS_HD * FRAG_FLOATS,
+                                          rt * PS_CAT * FRAG_FLOATS, rt * PS_CAT * FRAG_FLOATS, rt * PS_CAT * FRAG_FLOATS,
+                                          rt * PS_CAT * FRAG_FLOATS, rt * PS_CAT * FRAG_FLOATS, m * 512, m * 512, m * 1152,
+                                          m * 1152, m * 1152});
+  return std::max(fp32_path, packed_path);
+}
+
 extern "C" int egx_policy_set_precision(int bf16) {
   EGX_REQUIRE(bf16 == 0 || bf16 == 1, "precision must be 0 (fp32 MFMA) or 1 (bf16 operands, fp32 accumulate)");
   g_policy_bf16.store(bf16);
   return EGX_OK;
 }
 extern "C" int egx_policy_get_precision(void) { return g_policy_bf16.load(); }
+
+// The policy networks on packed operands (dense3.hip): GAMMAPolicyBase (two 2-step GRUs + positional encoding, outputs written
+// side by side into one [hx | he | pe] buffer), then the actor and critic MLP blocks layer by layer in shared launches.
+static int policy_forward_packed(const egx_policy_weights* w, const float* state, const float* ego, const float* dist,
+                                 const float* time, int n, float* out_mu, float* out_logvar, float* out_value, void* workspace,
+                                 size_t workspace_bytes, hipStream_t st) {
+  const egx_policy_packed3& P = *w->packed3;
+  const int prec = g_policy_bf16.load();
+  Carver cv(workspace, workspace_bytes);
+  const size_t rt = rt16(n), m = n;
+  auto take3 = [&](size_t ksteps) { return reinterpret_cast<bf16x8*>(cv.take(rt * ksteps * FRAG_FLOATS)); };
+  bf16x8* s0p = take3(PS_ST);
+  bf16x8* s1p = take3(PS_ST);
+  bf16x8* e0p = take3(PS_EGO);
+  bf16x8* e1p = take3(PS_EGO);
+  bf16x8* hx1 = take3(PS_HD);
+  bf16x8* he1 = take3(PS_HD);
+  bf16x8* cat3 = take3(PS_CAT);
+  bf16x8* a1 = take3(PS_CAT);
+  bf16x8* a2 = take3(PS_CAT);
+  bf16x8* c1 = take3(PS_CAT);
+  bf16x8* c2 = take3(PS_CAT);
+  float* hx1f = cv.take(m * 512);
+  float* he1f = cv.take(m * 512);
+  float* catf = cv.take(m * 1152);   // [hx | he | pe] fp32: residual of the first MLP unit
+  float* a2f = cv.take(m * 1152);    // first unit's output, fp32: residual of the second
+  float* c2f = cv.take(m * 1152);
+  constexpr int HD = 512;
+  auto B3 = [](const void* p) { return static_cast<const bf16x8*>(p); };
+  {
+    const D3Pack jobs[4] = {{state, n, 402, 804, 0, s0p, PS_ST, 0}, {state, n, 402, 804, 402, s1p, PS_ST, 0},
+                            {ego, n, 32, 64, 0, e0p, PS_EGO, 0}, {ego, n, 32, 64, 32, e1p, PS_EGO, 0}};
+    egx_launch_pack3(st, jobs, 4);
+  }
+  egx_launch_posenc3(st, dist, time, n, catf + 2 * HD, 1152, cat3, PS_CAT, 2 * PS_HD);
+  auto gru2 = [&](const bf16x8* x0, const bf16x8* x1, int Sx, const void* w_ih, const void* w_hh, const float* b_ih,
+                  const float* b_hh, bf16x8* h1, float* h1f, int col0, int s30) {
+    D3Gru g;
+    g.M = n; g.H = HD; g.prec = prec;
+    g.Ai = x0; g.SAi = Sx; g.Bi = B3(w_ih); g.Si = Sx; g.bias_i = b_ih; g.bias_h = b_hh;
+    g.h_out = h1f; g.ldo = HD; g.h_out3 = h1; g.S3 = PS_HD;
+    egx_launch_gru3(st, g);
+    g.Ai = x1;
+    g.Ah = h1; g.SAh = PS_HD; g.Bh = B3(w_hh); g.Sh = PS_HD; g.h_prev = h1f; g.ldh = HD;
+    g.h_out = catf + col0; g.ldo = 1152; g.h_out3 = cat3; g.S3 = PS_CAT; g.s30 = s30;
+    egx_launch_gru3(st, g);
+  };
+  gru2(s0p, s1p, PS_ST, P.x_enc_w_ih, P.x_enc_w_hh, w->x_enc_b_ih, w->x_enc_b_hh, hx1, hx1f, 0, 0);
+  gru2(e0p, e1p, PS_EGO, P.ego_enc_w_ih, P.ego_enc_w_hh, w->ego_enc_b_ih, w->ego_enc_b_hh, he1, he1f, HD, PS_HD);
+  const float slope = 0.01f;  // torch.nn.LeakyReLU() default (baseops.py:627-628)
+  const bool do_a = out_mu != nullptr, do_c = out_value != nullptr;
+  auto layer = [&](const bf16x8* xin, const void* W, const float* b, const float* res, float* outf, bf16x8* out3) {
+    D3Plain l;
+    l.M = n; l.N = 1152; l.A = xin; l.SA = PS_CAT; l.S = PS_CAT; l.B = B3(W); l.bias = b; l.act = 3; l.slope = slope;
+    l.res = res; l.ldr = 1152; l.out = outf; l.ldo = 1152; l.out3 = out3; l.S3 = PS_CAT; l.prec = prec;
+    return l;
+  };
+  auto run = [&](const D3Plain& la, const D3Plain& lc) {
+    if (do_a && do_c) egx_launch_dense3_pair(st, la, lc);
+    else egx_launch_dense3(st, do_a ? la : lc);
+  };
+  // h = hx; for unit: h = lrelu(fc2(lrelu(fc1(h)))) + h; y = out_fc(h)  - actor and critic layer i share a launch
+  run(layer(cat3, P.actor_w[0], w->actor_b[0], nullptr, nullptr, a1), layer(cat3, P.critic_w[0], w->critic_b[0], nullptr, nullptr, c1));
+  run(layer(a1, P.actor_w[1], w->actor_b[1], catf, a2f, a2), layer(c1, P.critic_w[1], w->critic_b[1], catf, c2f, c2));
+  run(layer(a2, P.actor_w[2], w->actor_b[2], nullptr, nullptr, a1), layer(c2, P.critic_w[2], w->critic_b[2], nullptr, nullptr, c1));
+  run(layer(a1, P.actor_w[3], w->actor_b[3], a2f, nullptr, a2), layer(c1, P.critic_w[3], w->critic_b[3], c2f, nullptr, c2));
+  // heads: mu = rows 0..127 and logvar = rows 128..255 of actor.out_fc go straight to their own outputs
+  D3Plain hm, hl, hv;
+  hm.M = n; hm.N = 128; hm.A = a2; hm.SA = PS_CAT; hm.S = PS_CAT; hm.B = B3(P.actor_out_w); hm.bias = w->actor_out_b;
+  hm.out = out_mu; hm.ldo = 128; hm.prec = prec;
+  hl = hm;
+  hl.B = B3(P.actor_out_w) + (size_t)8 * PS_CAT * 3 * 64;   // row tiles 8..15 of the packed [256,1152] image
+  hl.bias = w->actor_out_b + 128; hl.out = out_logvar;
+  hv.M = n; hv.N = 1; hv.A = c2; hv.SA = PS_CAT; hv.S = PS_CAT; hv.B = B3(P.critic_out_w); hv.bias = w->critic_out_b;
+  hv.out = out_value; hv.ldo = 1; hv.prec = prec;
+  if (do_a && do_c) egx_launch_dense3_triple(st, hm, hl, hv);
+  else if (do_a) egx_launch_dense3_pair(st, hm, hl);
+  else egx_launch_dense3(st, hv);
+  return EGX_OK;
+}
 
 extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* state, const float* ego, const float* dist,
                                   const float* time, int n, float* out_mu, float* out_logvar, float* out_value,
@@ -276,6 +365,12 @@ extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* stat
     return EGX_ERR_WORKSPACE;
   }
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (w->packed3) {
+    int rc = policy_forward_packed(w, state, ego, dist, time, n, out_mu, out_logvar, out_value, workspace, workspace_bytes, st);
+    if (rc) return rc;
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_OK;
+  }
   Carver cv(workspace, workspace_bytes);
   const size_t m = n;
   float* gi = cv.take(m * 1536);

@@ -169,7 +169,8 @@ class MoshRegressor(nn.Module):
         self.pnet = ResNetBlock(self.in_dim + self.body_dim + 10, 128, self.body_dim, 10, "relu")
 
 
-PACK_DECODER_WEIGHTS = os.environ.get("EGX_DECODER_PACKED", "1") != "0"   # development switch: 0 = fp32-MFMA layer kernels
+PACK_DECODER_WEIGHTS = os.environ.get("EGX_DECODER_PACKED", "1") != "0"   # development switches: 0 = fp32-MFMA layer kernels
+PACK_POLICY_WEIGHTS = os.environ.get("EGX_POLICY_PACKED", "1") != "0"
 PACK_REGRESSOR_WEIGHTS = os.environ.get("EGX_PACK_REGRESSOR", "1") == "1"
 FOLD_DECODER_OUTPUT = os.environ.get("EGX_FOLD_DECODER_OUTPUT", "1") == "1"
 
@@ -497,6 +498,7 @@ class PolicyHipRunner:
         self._ws = _Workspace()
         self._wstruct = None
         self._wkey = None
+        self._p3, self._dirty, self._p3_ver = None, True, -1
 
     def _weights(self) -> _lib.PolicyWeights:
         s, a, c = self.shared_net, self.actor.pnet, self.critic.vnet
@@ -514,8 +516,48 @@ class PolicyHipRunner:
                 w.critic_w[2 * b + k], w.critic_b[2 * b + k] = _p(c.layers[b].layers[k].weight), _p(c.layers[b].layers[k].bias)
         w.actor_out_w, w.actor_out_b = _p(a.out_fc.weight), _p(a.out_fc.bias)
         w.critic_out_w, w.critic_out_b = _p(c.out_fc.weight), _p(c.out_fc.bias)
+        self._p3 = None
+        if PACK_POLICY_WEIGHTS and s.x_enc.weight_ih_l0.is_cuda:
+            self._p3_src = [("x_enc_w_ih", None, s.x_enc.weight_ih_l0), ("x_enc_w_hh", None, s.x_enc.weight_hh_l0),
+                            ("ego_enc_w_ih", None, s.ego_enc.weight_ih_l0), ("ego_enc_w_hh", None, s.ego_enc.weight_hh_l0),
+                            ("actor_out_w", None, a.out_fc.weight), ("critic_out_w", None, c.out_fc.weight)]
+            for b in range(2):
+                for k in range(2):
+                    self._p3_src.append(("actor_w", 2 * b + k, a.layers[b].layers[k].weight))
+                    self._p3_src.append(("critic_w", 2 * b + k, c.layers[b].layers[k].weight))
+            lib = _lib.load()
+            self._p3_bufs = [torch.zeros(lib.egx_pack3_bytes(int(W.shape[0]), int(W.shape[1])), dtype=torch.uint8, device=W.device)
+                             for _, _, W in self._p3_src]
+            p3 = _lib.PolicyPacked3()
+            for (name, idx, _), buf in zip(self._p3_src, self._p3_bufs):
+                if idx is None:
+                    setattr(p3, name, buf.data_ptr())
+                else:
+                    getattr(p3, name)[idx] = buf.data_ptr()
+            self._p3 = p3
+            w.packed3 = C.pointer(p3)
+            self._dirty = True
         self._wstruct, self._wkey = w, key
         return w
+
+    def mark_dirty(self):
+        """The parameters changed through a path torch does not version (the flat AdamW kernel writes them by address):
+        the packed images are re-made before the next forward."""
+        self._dirty = True
+
+    def _refresh_packed(self):
+        """Re-pack the dense weights (three bf16 planes in MFMA fragment order) when any parameter changed since the images
+        were made: explicit mark (learn()), or an in-place edit torch saw (optim.step(), load_state_dict, copy_)."""
+        if self._p3 is None:
+            return
+        ver = sum(int(W._version) for _, _, W in self._p3_src)
+        if not self._dirty and ver == self._p3_ver:
+            return
+        lib, st = _lib.load(), _lib.current_stream_ptr()
+        for (_, _, W), buf in zip(self._p3_src, self._p3_bufs):
+            R, K = int(W.shape[0]), int(W.shape[1])
+            _lib.check(lib.egx_pack3(C.c_void_p(W.data_ptr()), R, K, K, 0, _lib.ptr(buf), (K + 31) // 32, 0, st), "egx_pack3")
+        self._dirty, self._p3_ver = False, ver
 
     @torch.no_grad()
     def forward(self, obs: Dict[str, torch.Tensor], want_actor=True, want_critic=True, out: Optional[dict] = None):
@@ -534,6 +576,7 @@ class PolicyHipRunner:
             out["value"] = torch.empty(n, dtype=torch.float32, device=st.device)
         ws = self._ws.get(lib.egx_policy_workspace_bytes(n), st.device)
         w = self._weights()
+        self._refresh_packed()
         rc = lib.egx_policy_forward(C.byref(w), _lib.ptr(st), _lib.ptr(ego), _lib.ptr(dist), _lib.ptr(time), n,
                                     _lib.ptr(out["mu"]) if want_actor else None,
                                     _lib.ptr(out["logvar"]) if want_actor else None,

@@ -257,6 +257,7 @@ class GAMMAPPOPolicy(nn.Module):
                                          float(b2), float(g["eps"]), float(g["weight_decay"]), _lib.ptr(self._step_t),
                                          _lib.ptr(self._adamw_ws), _lib.current_stream_ptr())
             _lib.check(rc, "egx_adamw_clip_step")
+            self._runner.mark_dirty()   # parameters written by address: the rollout runner's packed images are stale
             return
         if self._grad_norm:
             nn.utils.clip_grad_norm_(self._actor_critic.parameters(), max_norm=self._grad_norm)
@@ -516,6 +517,7 @@ class GAMMAPPOPolicy(nn.Module):
                     dist.all_reduce(kl)
                 if float(kl.item()) >= 0.02:
                     break
+        self._runner.mark_dirty()   # replayed graphs update the parameters by address: re-pack before the next rollout forward
         if logs:
             L = torch.stack(logs)
             if ws > 1:

@@ -292,6 +292,15 @@ int egx_sample_prior(const egx_prior_weights* w, const float* x_hist0, const flo
  * (models_policy_ppo.py:287-306,326-330,348-350).  Pointers alias the torch parameters
  * `shared_net.*`, `actor.pnet.*`, `critic.vnet.*`.
  * ------------------------------------------------------------------------------------------- */
+/* Packed images (egx_pack3) of the policy's dense weights, all of them or none; refreshed by the host after every change
+ * of the parameters (once per collect during training). */
+typedef struct egx_policy_packed3 {
+  const void *x_enc_w_ih, *x_enc_w_hh;     /* [1536,402], [1536,512] */
+  const void *ego_enc_w_ih, *ego_enc_w_hh; /* [1536,32],  [1536,512] */
+  const void *actor_w[4], *actor_out_w;    /* [1152,1152] x 4, [256,1152] */
+  const void *critic_w[4], *critic_out_w;  /* [1152,1152] x 4, [1,1152]   */
+} egx_policy_packed3;
+
 typedef struct egx_policy_weights {
   const float *x_enc_w_ih, *x_enc_w_hh, *x_enc_b_ih, *x_enc_b_hh;         /* shared_net.x_enc   GRU(402,512) */
   const float *ego_enc_w_ih, *ego_enc_w_hh, *ego_enc_b_ih, *ego_enc_b_hh; /* shared_net.ego_enc GRU(32,512)  */
@@ -299,6 +308,10 @@ typedef struct egx_policy_weights {
   const float *actor_out_w, *actor_out_b; /* actor.pnet.out_fc   256x1152                    */
   const float *critic_w[4], *critic_b[4]; /* critic.vnet.layers.{0,1}.layers.{0,1}           */
   const float *critic_out_w, *critic_out_b; /* critic.vnet.out_fc 1x1152                     */
+  /* Optional: with the packed images egx_policy_forward runs on the bf16 matrix pipe with three-term splits
+   * (fp32-equivalent; precision 1 of egx_policy_set_precision keeps the leading product only), each GRU cell as one
+   * launch, [hx | he | posenc] assembled in place.  NULL = the fp32-MFMA layer kernels. */
+  const egx_policy_packed3* packed3;
 } egx_policy_weights;
 
 /* Arithmetic of the dense layers inside egx_policy_forward (process-wide): 0 = fp32 MFMA (default; 1e-4 parity with the

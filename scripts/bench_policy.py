@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Development aid: egx_policy_forward wall time on the GPU (EGX_POLICY_PACKED=0: the fp32-MFMA layer kernels)."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from egogen_amd.models import ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase, POLICY_CFG, PolicyHipRunner
+torch.manual_seed(0)
+ac = ActorCritic(GAMMAActor(POLICY_CFG), GAMMACritic(POLICY_CFG), GAMMAPolicyBase(POLICY_CFG)).cuda()
+run = PolicyHipRunner(ac.shared_net, ac.actor, ac.critic)
+for A in (64, 256, 512, 2560):
+    g = torch.Generator().manual_seed(0)
+    obs = {"state": (torch.randn(A, 2, 402, generator=g) * 0.3).cuda(), "egosensing": torch.rand(A, 2, 32, generator=g).cuda(),
+           "dist": torch.rand(A, generator=g).cuda(), "time": torch.rand(A, generator=g).cuda()}
+    out = {}
+    for _ in range(3):
+        run.forward(obs, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run.forward(obs, out=out)
+    e1.record(); torch.cuda.synchronize()
+    print(f"A={A:5d}  policy forward {e0.elapsed_time(e1) / 20:7.3f} ms", flush=True)
