@@ -48,7 +48,8 @@ class LinearDesc(C.Structure):
 class PriorPacked3(C.Structure):
     _fields_ = [("x_enc_w_ih", C.c_void_p), ("x_enc_w_hh", C.c_void_p), ("drnn_w", C.c_void_p * 3), ("d_rnn_w_hz", C.c_void_p),
                 ("d_rnn_w_y", C.c_void_p), ("d_rnn_w_hh", C.c_void_p), ("d_comb_w", C.c_void_p), ("d_mlp_w", C.c_void_p * 2),
-                ("d_out_w", C.c_void_p)]
+                ("d_out_w", C.c_void_p), ("reg_in_m", C.c_void_p), ("reg_in_xb", C.c_void_p), ("reg_in_betas", C.c_void_p),
+                ("reg_blk", C.c_void_p), ("reg_out", C.c_void_p), ("reg_blk_b", C.c_void_p)]
 
 
 class PriorWeights(C.Structure):

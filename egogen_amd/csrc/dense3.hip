@@ -401,6 +401,237 @@ void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, in
                      static_cast<bf16x8*>(out3), S3, s0);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused body regressor on the bf16 matrix pipe: MoshRegressor.forward (models_GAMMA_primitive.py:222-301) for 48 rows per
+// workgroup - all 3 recurrences x (in_fc + 10 residual blocks + out_fc) and the 6D -> axis-angle tail in ONE launch.
+//   * 48 rows: 18 x 512 = 9216 rows give 192 workgroups, one per CU and all equally loaded (the fp32 kernel's 288 32-row
+//     workgroups put two on 32 of the 256 CUs, which then set the launch time);
+//   * eight waves, wave w owns output columns 16 w .. 16 w + 15 of every 128-wide layer for all three 16-row tiles; the
+//     activations live in LDS as packed planes (A-operand fragments), written by the producing layer's epilogue through a
+//     wave-private transposition strip; the residual stream h stays in registers (a lane owns the same elements in every layer);
+//   * in_fc([markers | xb | betas]) = W_m markers + W_b betas + b (the same in all three recurrences: computed once, kept
+//     in registers) + W_xb xb (159 of the 370 columns, zero in the first recurrence);
+//   * weights are read from packed images (one contiguous KiB per fragment), the next layer's prefetched under the epilogue.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int R3_ROWS = 48, R3_XB = 159, R3_XBP = 164, R3_NOUT = 159;
+constexpr int R3_ACT_FRAGS = 3 * 4 * 3 * 64;            // one 48 x 128 activation buffer, in bf16x8 fragments-lanes
+constexpr int R3_STRIP = R3_ROWS * 20;                  // floats per wave: 48 rows x 16 columns, pitch 20
+constexpr size_t R3_LDS = (size_t)R3_ROWS * R3_XBP * 4 + 2 * (size_t)R3_ACT_FRAGS * 16 + 8 * (size_t)R3_STRIP * 4;
+
+// this wave's weight fragments of one 128-deep layer: column tile `tile`, 4 k-steps x 3 planes
+__device__ __forceinline__ void r3_load_w(const bf16x8* P, int tile, int S, int lane, bf16x8 (&wf)[4][3]) {
+  const bf16x8* p = P + (size_t)tile * S * 3 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wf[s][pl] = p[(s * 3 + pl) * 64];
+}
+// acc[rt] += act(48 x 128, packed in LDS) . w^T for the wave's 16 columns
+__device__ __forceinline__ void r3_mma128(const bf16x8* act, int lane, const bf16x8 (&wf)[4][3], f32x4 (&acc)[3]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[pl] = act[((rt * 4 + s) * 3 + pl) * 64 + lane];
+      acc[rt] = d3_mma(a, wf[s], acc[rt], false);
+    }
+}
+// v[rt][r] (C layout: column lane & 15 of the wave's tile, rows 16 rt + 4 (lane >> 4) + r) -> packed planes of k-group pair
+// (wave & 1) of k-step wave >> 1 of `dst`, through the wave's transposition strip
+__device__ __forceinline__ void r3_store_packed(const float (&v)[3][4], float* strip, bf16x8* dst, int wave, int lane) {
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) strip[(16 * rt + 4 * (lane >> 4) + r) * 20 + (lane & 15)] = v[rt][r];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 32) {
+    const int kg = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+      const float* sp = strip + (16 * rt + (lane & 15)) * 20 + 8 * kg;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(sp), x1 = *reinterpret_cast<const f32x4*>(sp + 4);
+      const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      bf16x8 pl[3];
+      d3_split(x, pl);
+      bf16x8* o = dst + ((rt * 4 + (wave >> 1)) * 3) * 64 + 32 * (wave & 1) + lane;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+}  // namespace
+
+__global__ __launch_bounds__(512, 2) void egx_regressor3_kernel(RegWeights3 w, const float* __restrict__ Y,
+                                                                const float* __restrict__ betas, int A, int M,
+                                                                float* __restrict__ out_Yb) {
+  extern __shared__ __attribute__((aligned(16))) char r3_smem[];
+  float* xb = reinterpret_cast<float*>(r3_smem);                                      // [48][164] fp32: the running 6D parameters
+  bf16x8* hb3 = reinterpret_cast<bf16x8*>(r3_smem + (size_t)R3_ROWS * R3_XBP * 4);    // packed h (also: scratch of the prologue)
+  bf16x8* tb3 = hb3 + R3_ACT_FRAGS;                                                   // packed t
+  float* strips = reinterpret_cast<float*>(tb3 + R3_ACT_FRAGS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* strip = strips + wave * R3_STRIP;
+  const int m0 = blockIdx.x * R3_ROWS;
+  const int col = 16 * wave + (lane & 15);   // this lane's output column in every 128-wide layer
+  for (int i = tid; i < R3_ROWS * R3_XBP; i += 512) xb[i] = 0.f;
+  // ---- prologue: [markers | betas] as packed planes in the (still unused) activation region: 3 row tiles x (7 + 1) k-steps
+  bf16x8* in3 = hb3;
+  for (int f = wave; f < 3 * 8; f += 8) {
+    const int rt = f >> 3, s = f & 7;
+    const int row = min(m0 + 16 * rt + (lane & 15), M - 1), k0 = 8 * (lane >> 4);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * s + k0 + e;
+      x[e] = (s < 7) ? (k < 201 ? Y[(size_t)row * 201 + k] : 0.f) : (k0 + e < 10 ? betas[(size_t)(row % A) * 10 + k0 + e] : 0.f);
+    }
+    bf16x8 pl[3];
+    d3_split(x, pl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) in3[((rt * 8 + s) * 3 + p) * 64 + lane] = pl[p];
+  }
+  __syncthreads();
+  f32x4 base[3];   // W_m markers + W_b betas + b_in for this wave's columns
+  {
+    const float b = w.in_b[col];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) base[rt] = f32x4{b, b, b, b};
+    for (int s = 0; s < 8; ++s) {
+      bf16x8 wf[3];
+      const bf16x8* pw = (s < 7) ? w.in_m + ((size_t)(wave * 7 + s) * 3) * 64 + lane : w.in_b3 + ((size_t)wave * 3) * 64 + lane;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wf[pl] = pw[pl * 64];
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = in3[((rt * 8 + s) * 3 + pl) * 64 + lane];
+        base[rt] = d3_mma(a, wf, base[rt], false);
+      }
+    }
+  }
+  __syncthreads();
+  bf16x8 wcur[4][3], wnext[4][3];
+  float hres[3][4];   // residual stream h of this lane's elements
+  for (int rc = 0; rc < 3; ++rc) {
+    r3_load_w(w.blk, wave, 4, lane, wcur);   // first block layer's weights: independent of the activations
+    // ---- in_fc: h = base + W_xb xb (xb is zero in the first recurrence)
+    f32x4 acc[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) acc[rt] = base[rt];
+    if (rc > 0) {
+      bf16x8* xb3 = hb3;   // 3 row tiles x 5 k-steps of packed xb, made by all waves (the activation region is free here)
+      for (int f = wave; f < 3 * 5; f += 8) {
+        const int rt = f / 5, s = f % 5;
+        const float* sp = xb + (16 * rt + (lane & 15)) * R3_XBP + 32 * s + 8 * (lane >> 4);
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(sp), x1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        bf16x8 pl[3];
+        d3_split(x, pl);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xb3[((rt * 5 + s) * 3 + p) * 64 + lane] = pl[p];
+      }
+      __syncthreads();
+      for (int s = 0; s < 5; ++s) {
+        bf16x8 wf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wf[pl] = w.in_xb[((size_t)(wave * 5 + s) * 3 + pl) * 64 + lane];
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) {
+          bf16x8 a[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) a[pl] = xb3[((rt * 5 + s) * 3 + pl) * 64 + lane];
+          acc[rt] = d3_mma(a, wf, acc[rt], false);
+        }
+      }
+      __syncthreads();   // everyone is done reading xb3 before h overwrites the region
+    }
+    {
+      float v[3][4];
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[rt][r] = acc[rt][r]; hres[rt][r] = acc[rt][r]; }
+      r3_store_packed(v, strip, hb3, wave, lane);
+    }
+    __syncthreads();
+    // ---- 10 residual blocks: t = relu(W1 h + b1); h = relu(W2 t + b2) + h
+    for (int l = 0; l < 20; ++l) {
+      const bf16x8* src = (l & 1) ? tb3 : hb3;
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_sched_barrier(0);
+      r3_mma128(src, lane, wcur, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      // the next layer's weights (or out_fc's tile `wave`) fly during the epilogue and the barrier
+      if (l + 1 < 20) r3_load_w(w.blk + (size_t)(l + 1) * 8 * 4 * 3 * 64, wave, 4, lane, wnext);
+      else r3_load_w(w.out, wave, 4, lane, wnext);
+      const float b = w.blk_b[l * 128 + col];
+      float v[3][4];
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y = fmaxf(acc[rt][r] + b, 0.f);
+          if (l & 1) { y += hres[rt][r]; hres[rt][r] = y; }
+          v[rt][r] = y;
+        }
+      r3_store_packed(v, strip, (l & 1) ? hb3 : tb3, wave, lane);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wcur[s][pl] = wnext[s][pl];
+      __syncthreads();
+    }
+    // ---- out_fc: N = 159 -> column tiles 0..9; wave w owns tile w (weights already in wcur), waves 0 and 1 also tiles 8, 9
+    for (int tI = wave; tI < 10; tI += 8) {
+      if (tI >= 8) r3_load_w(w.out, tI, 4, lane, wcur);
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      r3_mma128(hb3, lane, wcur, acc);
+      const int nn = tI * 16 + (lane & 15);
+      if (nn < R3_NOUT) {
+        const float b = w.out_b[nn];
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* xp = xb + (16 * rt + 4 * (lane >> 4) + r) * R3_XBP + nn;
+            *xp = *xp + (acc[rt][r] + b);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- 6D -> axis-angle tail straight from LDS
+  for (int idx = tid; idx < R3_ROWS * 23; idx += 512) {
+    const int r = idx / 23, j = idx % 23;
+    if (m0 + r < M) egx_cont6d_item(xb + r * R3_XBP, out_Yb + (size_t)(m0 + r) * 93, j);
+  }
+}
+
+int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, const float* betas, int A, int M, float* out_Yb) {
+  {  // 133 KiB of dynamic LDS: above the 64 KiB default cap; raised once per device
+    static std::mutex mu;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    EGX_HIP_CHECK(hipGetDevice(&dev));
+    EGX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
+    std::lock_guard<std::mutex> lk(mu);
+    if (!attr_set[dev]) {
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)R3_LDS));
+      attr_set[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(egx_regressor3_kernel, dim3(egx_ceil_div(M, R3_ROWS)), dim3(512), R3_LDS, st, w, Y, betas, A, M, out_Yb);
+  return EGX_OK;
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------
 static void d3_launch_plain(hipStream_t st, D3Args3& three, int n) {
   auto blocks = [](const D3Plain& p) { return d3_blocks((p.M + 31) >> 5, (p.N + 31) >> 5) * std::max(1, p.batches); };

@@ -111,3 +111,38 @@ struct D3Gru {
   int prec = 0;   // as D3Plain::prec
 };
 int egx_launch_gru3(hipStream_t st, const D3Gru& g);
+
+// Fused regressor on packed weights (dense3.hip): in_fc split into its marker / xb / betas column blocks
+struct RegWeights3 {
+  const bf16x8 *in_m, *in_xb, *in_b3;   // packed in_fc[:, 0:201] (7 k-steps), [:, 201:360] (5), [:, 360:370] (1)
+  const float* in_b;
+  const bf16x8* blk;                    // [20 layers] packed [128,128]
+  const float* blk_b;                   // [20][128]
+  const bf16x8* out;                    // packed [159 -> 160,128]
+  const float* out_b;
+};
+int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, const float* betas, int A, int M, float* out_Yb);
+
+// MoshRegressor tail (models_GAMMA_primitive.py:208-219 + baseops.py:119-162): xb6[159] -> xb[93] =
+// transl3 | 22 x (6D -> Gram-Schmidt rotmat -> axis-angle) | hands 24.  One call per (row, item j in 0..22).
+__device__ __forceinline__ void egx_cont6d_item(const float* src, float* dst, int j) {
+  if (j == 22) {  // transl + hands copied through
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    for (int e = 0; e < 24; ++e) dst[69 + e] = src[135 + e];
+    return;
+  }
+  const float* a = src + 3 + 6 * j;  // viewed as (3,2): a1 = (a[0],a[2],a[4]), a2 = (a[1],a[3],a[5])
+  float b1[3] = {a[0], a[2], a[4]}, a2[3] = {a[1], a[3], a[5]};
+  const float n1 = fmaxf(sqrtf(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]), 1e-12f);
+  b1[0] /= n1; b1[1] /= n1; b1[2] /= n1;
+  const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+  float b2[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+  const float n2 = fmaxf(sqrtf(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]), 1e-12f);
+  b2[0] /= n2; b2[1] /= n2; b2[2] /= n2;
+  const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+  const float R[9] = {b1[0], b2[0], b3[0], b1[1], b2[1], b3[1], b1[2], b2[2], b3[2]};  // columns b1,b2,b3
+  float aa[3];
+  egx_tgm_rotmat_to_aa(R, aa);
+  dst[3 + 3 * j + 0] = aa[0]; dst[3 + 3 * j + 1] = aa[1]; dst[3 + 3 * j + 2] = aa[2];
+}
+

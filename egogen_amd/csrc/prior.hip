@@ -161,7 +161,18 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
     EGX_REQUIRE(w->d_comb_w && w->d_comb_b, "the packed decoder path needs the folded output layer (d_comb_w / d_comb_b)");
     int rc = sample_prior_packed(w, x0, x1, x_ld, z, A, out_Y, workspace, workspace_bytes, st);
     if (rc) return rc;
-    if ((rc = regress())) return rc;
+    const egx_prior_packed3& P = *w->packed3;
+    if (P.reg_in_m && P.reg_in_xb && P.reg_in_betas && P.reg_blk && P.reg_out && P.reg_blk_b) {
+      RegWeights3 r3;
+      r3.in_m = static_cast<const bf16x8*>(P.reg_in_m); r3.in_xb = static_cast<const bf16x8*>(P.reg_in_xb);
+      r3.in_b3 = static_cast<const bf16x8*>(P.reg_in_betas); r3.in_b = w->reg_in_b;
+      r3.blk = static_cast<const bf16x8*>(P.reg_blk); r3.blk_b = P.reg_blk_b;
+      r3.out = static_cast<const bf16x8*>(P.reg_out); r3.out_b = w->reg_out_b;
+      rc = egx_launch_regressor3(st, r3, out_Y, betas, A, M, out_Yb);
+    } else {
+      rc = regress();
+    }
+    if (rc) return rc;
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_OK;
   }

@@ -171,6 +171,7 @@ class MoshRegressor(nn.Module):
 
 PACK_DECODER_WEIGHTS = os.environ.get("EGX_DECODER_PACKED", "1") != "0"   # development switches: 0 = fp32-MFMA layer kernels
 PACK_POLICY_WEIGHTS = os.environ.get("EGX_POLICY_PACKED", "1") != "0"
+PACK_REGRESSOR3 = os.environ.get("EGX_REGRESSOR_PACKED", "1") != "0"
 PACK_REGRESSOR_WEIGHTS = os.environ.get("EGX_PACK_REGRESSOR", "1") == "1"
 FOLD_DECODER_OUTPUT = os.environ.get("EGX_FOLD_DECODER_OUTPUT", "1") == "1"
 
@@ -190,7 +191,7 @@ class GAMMAPrimitiveCombo(nn.Module):
         reg_w = [r.in_fc.weight, r.out_fc.weight] + [r.layers[b].layers[k].weight for b in range(10) for k in range(2)]
         key = (p.x_enc.weight_ih_l0.data_ptr(), r.out_fc.weight.data_ptr(), p.d_rnn.weight_ih._version, p.d_out.weight._version,
                p.d_out.bias._version) + tuple(t._version for t in reg_w) + \
-              tuple(t._version for t in p.parameters())   # the packed decoder images are copies: stale once a weight changes
+              tuple(t._version for t in self.parameters())   # the packed images are copies: stale once a weight changes
         if self._wstruct is not None and self._wkey == key:
             return self._wstruct
         w = _lib.PriorWeights()
@@ -248,6 +249,22 @@ class GAMMAPrimitiveCombo(nn.Module):
                 p3.drnn_w[i] = self._p3_bufs[f"drnn_w{i}"].data_ptr()
             for i in range(2):
                 p3.d_mlp_w[i] = self._p3_bufs[f"d_mlp_w{i}"].data_ptr()
+            if PACK_REGRESSOR3:
+                lib = _lib.load()
+                win = r.in_fc.weight.detach()
+                self._p3_bufs["reg_in_m"] = pack3(win, 0, 201)
+                self._p3_bufs["reg_in_xb"] = pack3(win, 201, 159)
+                self._p3_bufs["reg_in_betas"] = pack3(win, 360, 10)
+                self._p3_bufs["reg_out"] = pack3(r.out_fc.weight.detach())
+                blk = [r.layers[b].layers[k] for b in range(10) for k in range(2)]
+                per = lib.egx_pack3_bytes(128, 128)
+                allb = torch.zeros(20 * per, dtype=torch.uint8, device=win.device)
+                for i, fc in enumerate(blk):
+                    allb[i * per:(i + 1) * per].copy_(pack3(fc.weight.detach()))
+                self._p3_bufs["reg_blk"] = allb
+                self._p3_bufs["reg_blk_b"] = torch.stack([fc.bias.detach().float() for fc in blk]).contiguous()
+                for name in ("reg_in_m", "reg_in_xb", "reg_in_betas", "reg_blk", "reg_out", "reg_blk_b"):
+                    setattr(p3, name, self._p3_bufs[name].data_ptr())
             self._p3 = p3
             w.packed3 = C.pointer(p3)
         self._wstruct, self._wkey = w, key

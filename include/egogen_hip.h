@@ -247,6 +247,11 @@ typedef struct egx_prior_packed3 {
   const void *d_comb_w;                /* [768,256] (see d_comb_w below)                        */
   const void *d_mlp_w[2];              /* [512,256], [256,512]                                  */
   const void *d_out_w;                 /* [201,256]                                             */
+  /* body regressor (regressor.pnet): in_fc [128,370] as its three column blocks (markers 0:201, 6D parameters 201:360,
+   * betas 360:370), the 20 block layers [128,128] one after the other, out_fc [159,128]; reg_blk_b = the 20 block biases
+   * as one fp32 array [20][128] */
+  const void *reg_in_m, *reg_in_xb, *reg_in_betas, *reg_blk, *reg_out;
+  const float* reg_blk_b;
 } egx_prior_packed3;
 
 typedef struct egx_prior_weights {
@@ -271,8 +276,9 @@ typedef struct egx_prior_weights {
    * layers), reg_packed_out [5][16][64][4] (out_fc, rows past 158 repeat row 158). */
   const float *reg_packed_in, *reg_packed_blk, *reg_packed_out;
   /* Optional (needs d_comb_*): packed images of the decoder's weights.  With them egx_sample_prior runs the decoder on the
-   * bf16 matrix pipe (three-term splits, fp32-equivalent) with the GRU cell as one launch: 3 launches per decode step
-   * instead of 4, each about half as long.  NULL = the fp32-MFMA layer kernels on the torch-layout weights above. */
+   * bf16 matrix pipe (three-term splits, fp32-equivalent) with the GRU cell as one launch (3 launches per decode step
+   * instead of 4) and the fused body regressor on the same arithmetic (48-row workgroups, one per compute unit).
+   * NULL = the fp32-MFMA kernels on the torch-layout weights above. */
   const egx_prior_packed3* packed3;
 } egx_prior_weights;
 
