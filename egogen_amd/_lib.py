@@ -76,6 +76,13 @@ class PolicyWeights(C.Structure):
                 ("packed3", C.POINTER(PolicyPacked3))]
 
 
+class PolicyGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x_enc_w_ih", "x_enc_w_hh", "x_enc_b_ih", "x_enc_b_hh",
+                                          "ego_enc_w_ih", "ego_enc_w_hh", "ego_enc_b_ih", "ego_enc_b_hh")] + \
+               [("actor_w", C.c_void_p * 4), ("actor_b", C.c_void_p * 4), ("actor_out_w", C.c_void_p), ("actor_out_b", C.c_void_p),
+                ("critic_w", C.c_void_p * 4), ("critic_b", C.c_void_p * 4), ("critic_out_w", C.c_void_p), ("critic_out_b", C.c_void_p)]
+
+
 class VposerWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mu_w", "mu_b")]
 
@@ -176,6 +183,12 @@ SIGNATURES = {
     "egx_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "egx_event_destroy": (C.c_int, [C.c_void_p]),
     "egx_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "egx_policy_train_create": (C.c_int, [C.POINTER(PolicyWeights), C.POINTER(PolicyGrads), C.c_int, C.POINTER(C.c_void_p)]),
+    "egx_policy_train_destroy": (None, [C.c_void_p]),
+    "egx_policy_train_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "egx_policy_train_packed": (C.c_int, [C.c_void_p, C.POINTER(PolicyPacked3)]),
+    "egx_policy_train_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egx_policy_train_step": (C.c_int, [C.c_void_p] * 9 + [C.c_float] * 6 + [C.c_void_p, C.c_void_p]),
     "egx_pack3_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "egx_pack3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "egx_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),

@@ -60,6 +60,16 @@ __device__ __forceinline__ float d3_act(float v, int act, float slope) {
   }
 }
 
+// derivative of the activation as a function of its OUTPUT a = act(z) (tanh: 1 - a^2; relu / leaky relu keep the sign of z)
+__device__ __forceinline__ float d3_act_grad(float a, int act, float slope) {
+  switch (act) {
+    case 1: return 1.f - a * a;
+    case 2: return a > 0.f ? 1.f : 0.f;
+    case 3: return a > 0.f ? 1.f : slope;
+    default: return 1.f;
+  }
+}
+
 // XCD-aware tile map (blocks are dealt round-robin to the 8 XCDs, each with a private L2): every XCD owns a contiguous chunk
 // of column tiles - i.e. of the weights - and sweeps the row tiles.
 __device__ __forceinline__ bool d3_tile(int bid, int MT, int NT, int& mt, int& nt) {
@@ -135,16 +145,17 @@ void egx_launch_pack3(hipStream_t st, const D3Pack* jobs, int njobs) {
 // plain layer: out = act(A B^T + bias) + res for a 32 x 32 output tile per workgroup, the reduction split over the four
 // waves; up to three independent layers may share a launch.
 // ---------------------------------------------------------------------------------------------------------
-struct D3Args3 {
-  D3Plain p0, p1, p2;
-  int end0, end1;   // blocks [0, end0) work on p0, [end0, end1) on p1, the rest on p2
+struct D3Args4 {
+  D3Plain p0, p1, p2, p3;
+  int end0, end1, end2;   // blocks [0, end0) work on p0, [end0, end1) on p1, [end1, end2) on p2, the rest on p3
 };
 
 template <int TRIP>
-__global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args3 three) {
-  const int which = (int)blockIdx.x < three.end0 ? 0 : ((int)blockIdx.x < three.end1 ? 1 : 2);
-  const D3Plain& a = which == 0 ? three.p0 : (which == 1 ? three.p1 : three.p2);
-  const int bid = (int)blockIdx.x - (which == 0 ? 0 : (which == 1 ? three.end0 : three.end1));
+__global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args4 four) {
+  const int bx = (int)blockIdx.x;
+  const int which = bx < four.end0 ? 0 : (bx < four.end1 ? 1 : (bx < four.end2 ? 2 : 3));
+  const D3Plain& a = which == 0 ? four.p0 : (which == 1 ? four.p1 : (which == 2 ? four.p2 : four.p3));
+  const int bid = bx - (which == 0 ? 0 : (which == 1 ? four.end0 : (which == 2 ? four.end1 : four.end2)));
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ __attribute__((aligned(16))) float tile[32 * 36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -219,14 +230,35 @@ __global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args3 three) {
       v = d3_act(v, a.act, a.slope);
       const int row = 16 * mi + 4 * (lane >> 4) + r, m = mt * 32 + row;
       const bool live = m < a.M && n < a.N;
+      if (live && a.out_act) a.out_act[(size_t)m * a.ldact + n] = v;   // activation before the skip connection (saved for backward)
       if (live && a.res) v += a.res[(size_t)(row_base + m) * a.ldr + n];
-      if (live && a.out) a.out[(size_t)(row_base + m) * a.ldo + n] = v;
+      if (live && a.n_split > 0 && n >= a.n_split) {
+        // weight-gradient launch: the B operand's extra row of ones makes column n_split the bias gradient
+        if (n == a.n_split && a.bias_out) a.bias_out[m] = v;
+      } else if (live && a.out) {
+        a.out[(size_t)(row_base + m) * a.ldo + n] = v;
+      }
+      // gradient launches: what goes on to the next products is v x act'(saved activation of the layer below)
+      if (live && a.dact) v *= d3_act_grad(a.dact[(size_t)m * a.lddact + n], a.dact_code, a.dact_slope);
       tile[row * 36 + col] = live ? v : 0.f;
     }
   }
+  if (a.out3 || a.out3T) __syncthreads();
+  if (a.out3T && wave >= 2) {
+    // transposed image (rows = this layer's columns, reduction index = its rows): the tile is k-step (s3T0 + mt) of row tiles
+    // 2 nt, 2 nt + 1 - what a weight-gradient product reads as its A (gradients) or B (activations) operand
+    const int half = wave - 2, c = 16 * half + (lane & 15), kg = lane >> 4;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = tile[(8 * kg + e) * 36 + c];
+    bf16x8 pl[3];
+    d3_split(x, pl);
+    bf16x8* o = a.out3T + ((size_t)(2 * nt + half) * a.S3T + a.s3T0 + mt) * 3 * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+  }
   if (a.out3) {
     // the tile is k-step (s30 + nt) of the consumer's A operand: two 16-row fragments x three planes
-    __syncthreads();
     if (wave < 2) {
       const int row = 16 * wave + (lane & 15), g = lane >> 4;
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(&tile[row * 36 + 8 * g]), x1 = *reinterpret_cast<const f32x4*>(&tile[row * 36 + 8 * g + 4]);
@@ -248,15 +280,22 @@ __global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args3 three) {
 //   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h = (1 - z) n + z h_prev
 // h is written fp32 row-major (the next cell's h_prev) and packed (the next products' A operand).
 // ---------------------------------------------------------------------------------------------------------
+struct D3Gru2 {
+  D3Gru g0, g1;
+  int blocks0;   // blocks [0, blocks0) work on g0, the rest on g1 (the policy's two encoders)
+};
 template <int TRIP>
-__global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru a) {
+__global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
+  const bool second = (int)blockIdx.x >= two.blocks0;
+  const D3Gru& a = second ? two.g1 : two.g0;
+  const int gru_bid = second ? (int)blockIdx.x - two.blocks0 : (int)blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) float gsm[];
   float* red = gsm;                  // [4 waves][48][64]
   float* tile = gsm + 4 * 48 * 64;   // [32][20]: h of this workgroup's 32 x 16 block
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int MT = (a.M + 31) >> 5, CT = a.H >> 4;
   int mt, ct;
-  if (!d3_tile(blockIdx.x, MT, CT, mt, ct)) return;
+  if (!d3_tile(gru_bid, MT, CT, mt, ct)) return;
   f32x4 acc[2][3][2];   // [side][gate][row half]
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd)
@@ -341,6 +380,7 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru a) {
           gi[g] = (a.gi_in ? a.gi_in[(size_t)m * 3 * a.H + n] : 0.f) + gv[0][g] + (a.bias_i ? a.bias_i[n] : 0.f);
           gh[g] = gv[1][g] + a.bias_h[n];
           if (a.gi_out) a.gi_out[(size_t)m * 3 * a.H + n] = gi[g];
+          if (a.gh_out) a.gh_out[(size_t)m * 3 * a.H + n] = gh[g];
         }
         const float rg = 1.f / (1.f + expf(-(gi[0] + gh[0])));
         const float zg = 1.f / (1.f + expf(-(gi[1] + gh[1])));
@@ -352,9 +392,21 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru a) {
       tile[row * 20 + col] = hv;
     }
   }
+  if (a.h_out3 || a.h_out3T) __syncthreads();
+  if (a.h_out3T && wave == 2) {
+    // transposed image (rows = hidden columns, reduction index = batch rows): one whole fragment, row tile col0T / 16 + ct
+    const int c = lane & 15, kg = lane >> 4;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = tile[(8 * kg + e) * 20 + c];
+    bf16x8 pl[3];
+    d3_split(x, pl);
+    bf16x8* o = a.h_out3T + ((size_t)((a.col0T >> 4) + ct) * a.S3T + a.s3T0 + mt) * 3 * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+  }
   if (a.h_out3) {
     // 16 columns = k groups 2 (ct & 1), 2 (ct & 1) + 1 of k-step s30 + ct / 2: half of the lanes of each fragment
-    __syncthreads();
     if (wave < 2 && lane < 32) {
       const int row = 16 * wave + (lane & 15), g = lane >> 4;   // g in {0, 1}
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(&tile[row * 20 + 8 * g]), x1 = *reinterpret_cast<const f32x4*>(&tile[row * 20 + 8 * g + 4]);
@@ -371,10 +423,36 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru a) {
 // positional_encoding (models_policy_ppo.py:276-285) of dist and time as the last 128 columns of the policy's [hx | he | pe]
 // input: fp32 into `out` (row stride ld, the residual of the first MLP unit) and packed into k-steps s0 .. s0 + 3 of `out3`.
 __global__ __launch_bounds__(256) void egx_posenc3_kernel(const float* __restrict__ dist, const float* __restrict__ time, int n,
-                                                          float* __restrict__ out, int ld, bf16x8* __restrict__ out3, int S3, int s0) {
-  const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                          float* __restrict__ out, int ld, bf16x8* __restrict__ out3, int S3, int s0,
+                                                          bf16x8* __restrict__ out3T, int S3T, int col0T) {
+  int frag = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   const int RT = 2 * ((n + 31) >> 5);
-  if (frag >= RT * 4) return;
+  if (frag >= RT * 4) {
+    // training: the same 128 columns as rows col0T .. col0T + 127 of the transposed image (reduction index = batch row)
+    frag -= RT * 4;
+    const int Sn = (n + 31) >> 5;
+    if (!out3T || frag >= 8 * Sn) return;
+    const int t = frag / Sn, s = frag % Sn;
+    const int c = 16 * t + (lane & 15), m0 = 32 * s + 8 * (lane >> 4);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = m0 + e;
+      float v = 0.f;
+      if (m < n) {
+        const float f = ((c < 64) ? dist[m] : time[m]) * exp2f((float)((c & 63) >> 1));
+        v = (c & 1) ? cosf(f) : sinf(f);
+      }
+      x[e] = v;
+    }
+    bf16x8 pl[3];
+    d3_split(x, pl);
+    bf16x8* o = out3T + ((size_t)((col0T >> 4) + t) * S3T + s) * 3 * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+    return;
+  }
   const int rt = frag >> 2, s = frag & 3;
   const int row = rt * 16 + (lane & 15), c0 = s * 32 + 8 * (lane >> 4);
   float x[8];
@@ -395,10 +473,11 @@ __global__ __launch_bounds__(256) void egx_posenc3_kernel(const float* __restric
 #pragma unroll
   for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
 }
-void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, int n, float* out, int ld, void* out3, int S3, int s0) {
-  const int frags = 2 * egx_ceil_div(n, 32) * 4;
+void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, int n, float* out, int ld, void* out3, int S3, int s0,
+                        void* out3T, int S3T, int col0T) {
+  const int frags = 2 * egx_ceil_div(n, 32) * 4 + (out3T ? 8 * egx_ceil_div(n, 32) : 0);
   hipLaunchKernelGGL(egx_posenc3_kernel, dim3(egx_ceil_div(frags, 4)), dim3(256), 0, st, dist, time, n, out, ld,
-                     static_cast<bf16x8*>(out3), S3, s0);
+                     static_cast<bf16x8*>(out3), S3, s0, static_cast<bf16x8*>(out3T), S3T, col0T);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -633,34 +712,45 @@ int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, 
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
-static void d3_launch_plain(hipStream_t st, D3Args3& three, int n) {
-  auto blocks = [](const D3Plain& p) { return d3_blocks((p.M + 31) >> 5, (p.N + 31) >> 5) * std::max(1, p.batches); };
-  three.end0 = blocks(three.p0);
-  three.end1 = three.end0 + (n > 1 ? blocks(three.p1) : 0);
-  const int total = three.end1 + (n > 2 ? blocks(three.p2) : 0);
-  const int smax = std::max(three.p0.S, std::max(n > 1 ? three.p1.S : 0, n > 2 ? three.p2.S : 0));
-  if (smax > 16) hipLaunchKernelGGL(egx_dense3_kernel<3>, dim3(total), dim3(256), 0, st, three);
-  else hipLaunchKernelGGL(egx_dense3_kernel<2>, dim3(total), dim3(256), 0, st, three);
+void egx_launch_dense3_n(hipStream_t st, const D3Plain* ps, int n) {
+  D3Args4 f;
+  D3Plain* dst[4] = {&f.p0, &f.p1, &f.p2, &f.p3};
+  int ends[4] = {0, 0, 0, 0}, smax = 0, total = 0;
+  for (int i = 0; i < 4; ++i) {
+    *dst[i] = ps[i < n ? i : n - 1];
+    if (i < n) {
+      total += d3_blocks((ps[i].M + 31) >> 5, (ps[i].N + 31) >> 5) * std::max(1, ps[i].batches);
+      smax = std::max(smax, ps[i].S);
+    }
+    ends[i] = total;
+  }
+  f.end0 = ends[0]; f.end1 = ends[1]; f.end2 = ends[2];
+  if (smax > 16) hipLaunchKernelGGL(egx_dense3_kernel<3>, dim3(total), dim3(256), 0, st, f);
+  else hipLaunchKernelGGL(egx_dense3_kernel<2>, dim3(total), dim3(256), 0, st, f);
 }
-void egx_launch_dense3(hipStream_t st, const D3Plain& p) {
-  D3Args3 t;
-  t.p0 = p; t.p1 = p; t.p2 = p;
-  d3_launch_plain(st, t, 1);
-}
+void egx_launch_dense3(hipStream_t st, const D3Plain& p) { egx_launch_dense3_n(st, &p, 1); }
 void egx_launch_dense3_pair(hipStream_t st, const D3Plain& p, const D3Plain& q) {
-  D3Args3 t;
-  t.p0 = p; t.p1 = q; t.p2 = q;
-  d3_launch_plain(st, t, 2);
+  const D3Plain ps[2] = {p, q};
+  egx_launch_dense3_n(st, ps, 2);
 }
 void egx_launch_dense3_triple(hipStream_t st, const D3Plain& p, const D3Plain& q, const D3Plain& r) {
-  D3Args3 t;
-  t.p0 = p; t.p1 = q; t.p2 = r;
-  d3_launch_plain(st, t, 3);
+  const D3Plain ps[3] = {p, q, r};
+  egx_launch_dense3_n(st, ps, 3);
+}
+static void d3_launch_gru(hipStream_t st, const D3Gru& g0, const D3Gru* g1) {
+  constexpr size_t lds = (size_t)(4 * 48 * 64 + 32 * 20) * sizeof(float);   // 50.5 KiB: within the default dynamic-LDS cap
+  D3Gru2 two;
+  two.g0 = g0; two.g1 = g1 ? *g1 : g0;
+  two.blocks0 = d3_blocks((g0.M + 31) >> 5, g0.H >> 4);
+  const int total = two.blocks0 + (g1 ? d3_blocks((g1->M + 31) >> 5, g1->H >> 4) : 0);
+  hipLaunchKernelGGL(egx_gru3_kernel<2>, dim3(total), dim3(256), lds, st, two);
 }
 int egx_launch_gru3(hipStream_t st, const D3Gru& g) {
-  constexpr size_t lds = (size_t)(4 * 48 * 64 + 32 * 20) * sizeof(float);   // 50.5 KiB: within the default dynamic-LDS cap
-  const int blocks = d3_blocks((g.M + 31) >> 5, g.H >> 4);
-  hipLaunchKernelGGL(egx_gru3_kernel<2>, dim3(blocks), dim3(256), lds, st, g);
+  d3_launch_gru(st, g, nullptr);
+  return EGX_OK;
+}
+int egx_launch_gru3_pair(hipStream_t st, const D3Gru& g0, const D3Gru& g1) {
+  d3_launch_gru(st, g0, &g1);
   return EGX_OK;
 }
 

@@ -81,11 +81,23 @@ struct D3Plain {
   size_t batch_strideA = 0, batch_stride3 = 0;
   int batch_rows_out = 0;
   int prec = 0;   // 0: six partial products (fp32-equivalent); 1: leading product only (operands rounded to bf16)
+  // ---- training (update3.hip)
+  float* out_act = nullptr;       // fp32 [M, N] (ld ldact): the activation BEFORE the residual is added (saved for backward)
+  int ldact = 0;
+  const float* dact = nullptr;    // gradient launches: the packed outputs are v x act'(dact[m][n]) (fp32 `out` stays v)
+  int lddact = 0, dact_code = 0;
+  float dact_slope = 0.f;
+  bf16x8* out3T = nullptr;        // transposed packed output: image rows = this layer's columns, reduction index = its rows
+  int S3T = 0, s3T0 = 0;          //   (k-step s3T0 + row tile / 2 of a buffer with S3T k-steps per row tile)
+  float* bias_out = nullptr;      // n_split > 0: columns >= n_split are not stored to `out`; column n_split goes to bias_out[m]
+  int n_split = 0;
 };
+void egx_launch_dense3_n(hipStream_t st, const D3Plain* ps, int n);   // up to four independent layers, one launch
 void egx_launch_dense3(hipStream_t st, const D3Plain& p);
 void egx_launch_dense3_pair(hipStream_t st, const D3Plain& p, const D3Plain& q);  // two independent layers, one launch
 void egx_launch_dense3_triple(hipStream_t st, const D3Plain& p, const D3Plain& q, const D3Plain& r);
-void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, int n, float* out, int ld, void* out3, int S3, int s0);
+void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, int n, float* out, int ld, void* out3, int S3, int s0,
+                        void* out3T = nullptr, int S3T = 0, int col0T = 0);
 
 // One GRU cell step (gate order r, z, n; weights [3H, K] packed): see egx_gru3_kernel.
 struct D3Gru {
@@ -109,8 +121,13 @@ struct D3Gru {
   int S3 = 0, s30 = 0;
   int M = 0, H = 0;
   int prec = 0;   // as D3Plain::prec
+  // ---- training
+  float* gh_out = nullptr;        // [M, 3H]: the h-side pre-activations (saved for backward)
+  bf16x8* h_out3T = nullptr;      // transposed packed h: image rows col0T .. col0T + H, reduction index = batch rows
+  int S3T = 0, s3T0 = 0, col0T = 0;
 };
 int egx_launch_gru3(hipStream_t st, const D3Gru& g);
+int egx_launch_gru3_pair(hipStream_t st, const D3Gru& g0, const D3Gru& g1);   // two cells (same launch)
 
 // Fused regressor on packed weights (dense3.hip): in_fc split into its marker / xb / betas column blocks
 struct RegWeights3 {

@@ -557,6 +557,14 @@ class PolicyHipRunner:
         self._wstruct, self._wkey = w, key
         return w
 
+    def adopt_packed(self, packed3: "_lib.PolicyPacked3"):
+        """Use weight images somebody else keeps current (the update's `egx_policy_train` handle re-makes them after every
+        optimiser step): the runner stops packing its own."""
+        w = self._weights()
+        self._adopted = packed3            # keep the struct alive
+        w.packed3 = C.pointer(packed3)
+        self._p3 = None
+
     def mark_dirty(self):
         """The parameters changed through a path torch does not version (the flat AdamW kernel writes them by address):
         the packed images are re-made before the next forward."""

@@ -8,6 +8,7 @@ of one flat gradient buffer for data parallelism (one process per GPU).
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 import os
 from typing import Dict, List, Optional
@@ -88,6 +89,9 @@ class GAMMAPPOPolicy(nn.Module):
         self.use_update_graph = bool(_ignored.get("use_update_graph", False))
         self.use_fused_loss = bool(_ignored.get("use_fused_loss", True))
         self._scale_cache = {}
+        # the minibatch as a fixed chain of hand-written launches (csrc/update3.hip); EGX_TRAIN_STEP=0: the autograd nodes
+        self.use_train_step = bool(_ignored.get("use_train_step", os.environ.get("EGX_TRAIN_STEP", "1") != "0"))
+        self._train_handles: dict = {}
         # dense layers of the update as LinearFn nodes (library GEMMs + fused activation / bias-gradient / accumulation
         # kernels).  Their weight gradients are ACCUMULATED into the flat buffer: callers zero it once per minibatch.
         self.use_fused_linear = bool(_ignored.get("use_fused_linear", True))
@@ -230,7 +234,100 @@ class GAMMAPPOPolicy(nn.Module):
         return (obs, batch.act.reshape(N, 128).index_select(0, idx), batch.adv.reshape(N).index_select(0, idx),
                 batch.returns.reshape(N).index_select(0, idx), batch.logp_old.reshape(N).index_select(0, idx))
 
+    # ---- the minibatch as a fixed chain of hand-written launches (csrc/update3.hip) ---------------------------------
+    def _train_handle(self, n: int):
+        """`egx_policy_train` for minibatches of n rows, or None where the hand-written step does not apply (CPU tensors, a
+        minibatch that is not a multiple of 32 rows, an optimiser the flat AdamW kernel does not cover, ablation switches)."""
+        if not (self.use_train_step and self.use_fused_loss and self.use_fused_linear and n % 32 == 0 and self.actor.z_dim == 128
+                and self._flat_opt_state == "ready" and self._flat_grad is not None and self._flat_grad.is_cuda and self._norm_adv):
+            return None
+        hs = self._train_handles.get(n)
+        if hs is not None:
+            return hs
+        lib = _lib.load()
+        self._ensure_flat_grads()
+        w = self._runner._weights()
+        g = _lib.PolicyGrads()
+        s, a, c = self.shared_net, self.actor.pnet, self.critic.vnet
+        gp = lambda t: t.grad.data_ptr()
+        g.x_enc_w_ih, g.x_enc_w_hh, g.x_enc_b_ih, g.x_enc_b_hh = gp(s.x_enc.weight_ih_l0), gp(s.x_enc.weight_hh_l0), gp(s.x_enc.bias_ih_l0), gp(s.x_enc.bias_hh_l0)
+        g.ego_enc_w_ih, g.ego_enc_w_hh, g.ego_enc_b_ih, g.ego_enc_b_hh = (gp(s.ego_enc.weight_ih_l0), gp(s.ego_enc.weight_hh_l0),
+                                                                            gp(s.ego_enc.bias_ih_l0), gp(s.ego_enc.bias_hh_l0))
+        for b in range(2):
+            for k in range(2):
+                g.actor_w[2 * b + k], g.actor_b[2 * b + k] = gp(a.layers[b].layers[k].weight), gp(a.layers[b].layers[k].bias)
+                g.critic_w[2 * b + k], g.critic_b[2 * b + k] = gp(c.layers[b].layers[k].weight), gp(c.layers[b].layers[k].bias)
+        g.actor_out_w, g.actor_out_b = gp(a.out_fc.weight), gp(a.out_fc.bias)
+        g.critic_out_w, g.critic_out_b = gp(c.out_fc.weight), gp(c.out_fc.bias)
+        h = C.c_void_p()
+        _lib.check(lib.egx_policy_train_create(C.byref(w), C.byref(g), int(n), C.byref(h)), "egx_policy_train_create")
+        dev = self._flat_grad.device
+        f = dict(dtype=torch.float32, device=dev)
+        bufs = [torch.empty(n, 804, **f), torch.empty(n, 64, **f), torch.empty(n, 1, **f), torch.empty(n, 1, **f),
+                torch.empty(n, 128, **f), torch.empty(n, 1, **f), torch.empty(n, 1, **f), torch.empty(n, 1, **f)]
+        _lib.check(lib.egx_policy_train_bind(h, _lib.ptr(bufs[0]), _lib.ptr(bufs[1])), "egx_policy_train_bind")
+        packed = _lib.PolicyPacked3()
+        _lib.check(lib.egx_policy_train_packed(h, C.byref(packed)), "egx_policy_train_packed")
+        hs = {"h": h, "bufs": bufs, "stats": torch.zeros(2, **f), "key": (w.x_enc_w_ih, g.x_enc_w_ih), "packed": packed}
+        self._train_handles[n] = hs
+        if len(self._train_handles) == 1:   # the rollout forward reads the images this handle keeps current
+            self._runner.adopt_packed(packed)
+            self._images_owner = n
+        self._refresh_images()
+        return hs
+
+    def _drop_train_handles(self):
+        lib = _lib.load() if self._train_handles else None
+        for hs in self._train_handles.values():
+            lib.egx_policy_train_destroy(hs["h"])
+        self._train_handles = {}
+        self._runner._wstruct = None   # the rollout runner goes back to images of its own
+
+    def __del__(self):
+        try:
+            self._drop_train_handles()
+        except Exception:
+            pass
+
+    def _refresh_images(self):
+        """Re-make the packed weight images of every update handle (one launch each) - after anything that changed the
+        parameters."""
+        lib, st = _lib.load(), _lib.current_stream_ptr()
+        for hs in self._train_handles.values():
+            _lib.check(lib.egx_policy_train_refresh(hs["h"], st), "egx_policy_train_refresh")
+
+    def _fwd_bwd_train_step(self, hs, batch, idx, gstats, log_out):
+        """gather + forward + loss + backward of one minibatch: 2 + ~21 launches, gradients written into the flat buffer."""
+        from .fused_ops import gather_rows
+        lib, st = _lib.load(), _lib.current_stream_ptr()
+        N = batch.n * batch.A
+        obs_all = batch.obs_flat()
+        b = hs["bufs"]
+        gather_rows(idx, [obs_all["state"].reshape(N, 804), obs_all["egosensing"].reshape(N, 64), obs_all["dist"].reshape(N, 1),
+                          obs_all["time"].reshape(N, 1), batch.act.reshape(N, 128), batch.adv.reshape(N, 1), batch.returns.reshape(N, 1),
+                          batch.logp_old.reshape(N, 1)], out=b)
+        n = int(idx.shape[0])
+        dev = b[0].device
+        if gstats is None:
+            _lib.check(lib.egx_adv_stats(_lib.ptr(b[5]), n, _lib.ptr(hs["stats"]), st), "egx_adv_stats")
+            scale = self._scale_cache.get((n, dev))
+            if scale is None:
+                scale = torch.full((1,), 1.0 / n, dtype=torch.float32, device=dev)
+                self._scale_cache[(n, dev)] = scale
+        else:
+            hs["stats"].copy_(torch.stack([gstats[0], gstats[1]]).float())
+            scale = (1.0 / gstats[2]).reshape(1).float()
+        rc = lib.egx_policy_train_step(hs["h"], _lib.ptr(b[2]), _lib.ptr(b[3]), _lib.ptr(b[4]), _lib.ptr(b[5]), _lib.ptr(b[6]), _lib.ptr(b[7]),
+                                       _lib.ptr(hs["stats"]), _lib.ptr(scale), float(_EPS), float(self.actor.min_logvar),
+                                       float(self.actor.max_logvar), float(self._eps_clip), float(self._weight_vf), float(self._weight_ent),
+                                       _lib.ptr(log_out), st)
+        _lib.check(rc, "egx_policy_train_step")
+
     def _fwd_bwd(self, batch, idx, gstats, log_out):
+        hs = self._train_handle(int(idx.shape[0])) if idx.is_cuda else None
+        if hs is not None:
+            self._fwd_bwd_train_step(hs, batch, idx, gstats, log_out)
+            return
         obs, act, adv, ret, lpo = self._gather(batch, idx)
         loss, terms = self.minibatch_loss(obs, act, adv, ret, lpo, gstats)
         self._flat_grad.zero_()
@@ -258,10 +355,12 @@ class GAMMAPPOPolicy(nn.Module):
                                          _lib.ptr(self._adamw_ws), _lib.current_stream_ptr())
             _lib.check(rc, "egx_adamw_clip_step")
             self._runner.mark_dirty()   # parameters written by address: the rollout runner's packed images are stale
+            self._refresh_images()      # ... and so are the update's own (re-made by one launch, inside the captured graph too)
             return
         if self._grad_norm:
             nn.utils.clip_grad_norm_(self._actor_critic.parameters(), max_norm=self._grad_norm)
         self.optim.step()
+        self._refresh_images()
 
     def _flat_optimizer_ready(self) -> bool:
         """Flat-buffer AdamW (egx_adamw_clip_step): parameters, exp_avg and exp_avg_sq of the single AdamW group are
@@ -296,6 +395,7 @@ class GAMMAPPOPolicy(nn.Module):
                     p.data = self._flat_p[off:off + n].view_as(p)
             self._flat_opt_state = "ready"
             self._graph_cache.clear()  # parameter storage moved
+            self._drop_train_handles()
         # (re-)adopt the optimiser state: first use, or optim.load_state_dict() replaced the tensors
         st0 = opt.state.get(params[0], {})
         if st0.get("exp_avg") is None or st0["exp_avg"].data_ptr() != self._flat_m.data_ptr():
@@ -412,6 +512,7 @@ class GAMMAPPOPolicy(nn.Module):
                         old_v = osnap[id(p_)].get(k)
                         v.copy_(old_v) if old_v is not None else v.zero_()
             st["g1"], st["g2"] = g1, g2
+            self._refresh_images()   # the packed weight images followed the warm-up steps: back to the restored parameters
         except Exception as e:  # capture unsupported for some op on this stack: run the same ops eagerly
             import warnings
             warnings.warn(f"PPO update graph capture failed ({type(e).__name__}: {e}); running the update eagerly")
@@ -470,6 +571,7 @@ class GAMMAPPOPolicy(nn.Module):
         self._ensure_flat_grads()
         if self.use_flat_optimizer and batch.act.is_cuda:
             self._flat_optimizer_ready()  # (re-)points parameters / optimiser state BEFORE anything is captured
+        self._refresh_images()            # whatever changed the parameters since the last update (load_state_dict, ...)
         ws = self.world_size
         N = batch.n * batch.A
         dev = batch.act.device

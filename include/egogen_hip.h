@@ -320,6 +320,37 @@ typedef struct egx_policy_weights {
   const egx_policy_packed3* packed3;
 } egx_policy_weights;
 
+/* ---------------------------------------------------------------------------------------------
+ * One PPO minibatch of the policy networks without autograd and without library GEMMs (csrc/update3.hip):
+ * GAMMAPPOPolicy.learn's inner loop body (crowd_ppo/ppo_policy.py:189-241) - forward of shared_net / actor / critic
+ * (models/models_policy_ppo.py:287-350), the clipped-PPO loss (egx_ppo_loss_packed), and the backward pass - as a fixed chain
+ * of ~21 launches on the dense3 kernels.  Gradients are WRITTEN to the tensors of `egx_policy_grads` (the views of the flat
+ * gradient buffer): every parameter is used once per minibatch, nothing accumulates, the buffer needs no zero fill.
+ *   create   fixes the minibatch rows (a multiple of 32) and allocates every intermediate buffer;
+ *   refresh  re-makes the packed images (W and W^T) of the weights: after every optimiser step;
+ *   packed   hands the row-major weight images to egx_policy_forward (egx_policy_weights.packed3), so the rollout needs
+ *            no packing of its own;
+ *   bind     names the observation tensors of the minibatch, state [n,2,402] and egosensing [n,2,32] (fixed addresses:
+ *            the gather kernel's outputs);
+ *   step     runs the chain; out_terms[6] as egx_ppo_loss_packed.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct egx_policy_grads {
+  float *x_enc_w_ih, *x_enc_w_hh, *x_enc_b_ih, *x_enc_b_hh;
+  float *ego_enc_w_ih, *ego_enc_w_hh, *ego_enc_b_ih, *ego_enc_b_hh;
+  float *actor_w[4], *actor_b[4], *actor_out_w, *actor_out_b;
+  float *critic_w[4], *critic_b[4], *critic_out_w, *critic_out_b;
+} egx_policy_grads;
+typedef struct egx_policy_train egx_policy_train;
+int egx_policy_train_create(const egx_policy_weights* w, const egx_policy_grads* g, int num_rows, egx_policy_train** out);
+void egx_policy_train_destroy(egx_policy_train* h);
+int egx_policy_train_refresh(egx_policy_train* h, void* stream);
+int egx_policy_train_packed(const egx_policy_train* h, egx_policy_packed3* out);
+int egx_policy_train_bind(egx_policy_train* h, const float* state, const float* egosensing);
+int egx_policy_train_step(egx_policy_train* h, const float* dist, const float* time, const float* act, const float* adv,
+                          const float* ret, const float* logp_old, const float* adv_stats, const float* scale, float adv_eps,
+                          float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef, float* out_terms,
+                          void* stream);
+
 /* Arithmetic of the dense layers inside egx_policy_forward (process-wide): 0 = fp32 MFMA (default; 1e-4 parity with the
  * reference's fp32 policy), 1 = operands rounded to bf16, products on the bf16 MFMA, fp32 accumulation - BASELINE config 5
  * ("main_crowd_eval ... bf16 MFMA policy"), whose parity is statistical.  Gate math, biases, activations

@@ -358,3 +358,121 @@ def test_flat_adamw_clip_matches_torch():
     pol.optim.load_state_dict(copy.deepcopy(sr))
     assert pol._flat_optimizer_ready()
     assert float(pol._step_t) == 3.0 and pol.optim.state[next(iter(pol.optim.param_groups[0]["params"]))]["exp_avg"].data_ptr() == pol._flat_m.data_ptr()
+
+
+def _filled_batch(n_steps, A, seed, pol):
+    from egogen_amd.ppo_policy import RolloutBatch
+    g = torch.Generator().manual_seed(seed)
+    b = RolloutBatch(n_steps, A, "cuda")
+    b.state.copy_(torch.randn(b.state.shape, generator=g) * 0.3)
+    b.ego.copy_(torch.rand(b.ego.shape, generator=g) * 2 - 1)
+    b.dist.copy_(torch.rand(b.dist.shape, generator=g)); b.time.copy_(torch.rand(b.time.shape, generator=g))
+    b.act.copy_(torch.randn(b.act.shape, generator=g) * 2.5)   # some ratios leave the clip range
+    b.adv.copy_(torch.randn(b.adv.shape, generator=g)); b.returns.copy_(torch.randn(b.returns.shape, generator=g))
+    with torch.no_grad():
+        _, mu, sigma = pol._dist_params(b.obs_flat())
+        lp = pol.log_prob(mu, sigma, b.act.reshape(-1, 128)) + 0.2 * torch.randn(n_steps * A, generator=g).cuda()
+        b.logp_old.copy_(lp.reshape(n_steps, A))
+    return b
+
+
+def _assert_grads_close(name, got, ref):
+    """Two fp32 evaluations of a leaky-relu network disagree about the side of the kink for the odd pre-activation within
+    round-off of zero (about one element per ~1e6: expect one or two in a minibatch of this size).  One flipped mask bit changes
+    one row of one weight gradient by ~1e-2 of the tensor's scale and, diluted, everything upstream of it by ~1e-3 (measured:
+    every tensor not downstream of a flip agrees to 1e-7..3e-5 relative).  So the criterion is the error NORM - a wrong
+    product, transposition or missing term is O(1) in it - plus a cap on any single entry."""
+    scale = float(ref.abs().max()) + 1e-12
+    d = got - ref
+    rel_l2 = float(d.norm()) / (float(ref.norm()) + 1e-12)
+    assert rel_l2 <= 1e-2 and float(d.abs().max()) <= 5e-2 * scale, (name, rel_l2, float(d.abs().max()) / scale)
+
+
+def test_train_step_matches_torch_autograd():
+    """csrc/update3.hip: the minibatch as a chain of hand-written launches (forward, clipped-PPO loss, backward: packed bf16x3
+    products, fused epilogues, bias gradients through a row of ones) gives the loss terms and EVERY parameter gradient of the
+    plain torch expression of ppo_policy.py:189-241."""
+    from egogen_amd import models, setup_world as sw
+    pol = sw.build_policy(_Args())
+    with torch.no_grad():   # non-trivial biases; some raw logvars outside [-2.5, 2.5] so that the clamp mask is exercised
+        for p_ in pol.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.05 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(p_.numel())).cuda())
+        pol.actor.pnet.out_fc.bias[128:160] += 4.0
+        pol.actor.pnet.out_fc.bias[160:192] -= 4.0
+    N = 96
+    b = _filled_batch(1, N, 0, pol)
+    pol._ensure_flat_grads()
+    assert pol._flat_optimizer_ready()
+    args = (b.obs_flat(), b.act.reshape(N, 128), b.adv.reshape(N), b.returns.reshape(N), b.logp_old.reshape(N))
+    try:
+        models.FUSED_UPDATE_OPS = False
+        pol.use_fused_loss = False
+        pol.zero_grad(set_to_none=True)
+        loss, terms = pol.minibatch_loss(*args)
+        loss.backward()
+        ref = {n_: p_.grad.detach().clone() for n_, p_ in pol.named_parameters()}
+        ref_terms = {k: float(v) for k, v in terms.items()}
+    finally:
+        models.FUSED_UPDATE_OPS = True
+        pol.use_fused_loss = True
+    pol._ensure_flat_grads()
+    pol._flat_grad.fill_(7.0)   # the step WRITES every gradient: whatever was there must be gone
+    idx = torch.arange(N, device="cuda")
+    log = torch.zeros(6, device="cuda")
+    hs = pol._train_handle(N)
+    assert hs is not None, "the hand-written update step was not selected"
+    pol._fwd_bwd(b, idx, None, log)
+    torch.cuda.synchronize()
+    log = log.cpu().tolist()
+    for i, k in enumerate(("loss", "loss/clip", "loss/vf", "loss/ent", "loss/kld", "approx_kl")):
+        assert abs(log[i] - ref_terms[k]) <= 2e-4 * max(1.0, abs(ref_terms[k])), (k, log[i], ref_terms[k])
+    for n_, p_ in pol.named_parameters():
+        if n_.startswith("_actor_critic."):
+            continue
+        _assert_grads_close(n_, p_.grad, ref[n_])
+    # a second minibatch through the same handle (all buffers reused), other rows
+    b2 = _filled_batch(1, N, 1, pol)
+    args2 = (b2.obs_flat(), b2.act.reshape(N, 128), b2.adv.reshape(N), b2.returns.reshape(N), b2.logp_old.reshape(N))
+    snap = pol._flat_grad.clone()
+    pol._fwd_bwd(b2, idx, None, torch.zeros(6, device="cuda"))
+    assert float((pol._flat_grad - snap).abs().max()) > 0
+
+
+def test_learn_with_train_step_equals_autograd_nodes():
+    """GAMMAPPOPolicy.learn over a whole collect: the hand-written step (eager and as replayed HIP graphs) performs the same
+    optimiser steps as the autograd-node path - losses of every minibatch and the parameters afterwards."""
+    from egogen_amd import setup_world as sw
+
+    def make(train_step, graph):
+        a = _Args()
+        a.update_graph = graph
+        p = sw.build_policy(a)
+        p.use_train_step = train_step
+        return p
+
+    ref, eager, graph = make(False, False), make(True, False), make(True, True)
+    for p in (eager, graph):
+        p.load_state_dict(ref.state_dict())
+    b = _filled_batch(4, 64, 3, ref)
+    out = []
+    for p in (ref, eager, graph):
+        p._perm_gen.manual_seed(11)
+        l1 = p.learn(b, 64, 1)
+        l2 = p.learn(b, 64, 1)   # second pass: replayed graphs, refreshed weight images
+        out.append((l1["loss"] + l2["loss"], torch.cat([q.detach().flatten() for q in p.parameters()]).clone()))
+    assert eager._train_handles and graph._train_handles and not ref._train_handles
+    assert not any(v.get("failed") for v in graph._graph_cache.values()), "graph capture fell back to eager"
+    for name, (losses, params) in zip(("eager", "graph"), out[1:]):
+        np.testing.assert_allclose(losses, out[0][0], rtol=1e-3, atol=5e-5, err_msg=name)
+        # AdamW's first steps move every parameter by ~lr whatever the size of its gradient, so round-off-level differences
+        # of near-zero gradients show up as differences of up to 2 lr per step: bound by that, and require that nearly
+        # all parameters agree far more closely
+        d = (params - out[0][1]).abs()
+        assert float(d.max()) <= 8 * 2 * 3e-4 and float((d > 2e-5).float().mean()) <= 0.02, (name, float(d.max()))
+    # the rollout forward reads the images the update keeps current: same action means as a fresh runner on the same weights
+    from egogen_amd.models import PolicyHipRunner
+    obs = {k: v[:64] for k, v in b.obs_flat().items()}
+    o1 = eager._runner.forward(obs)
+    o2 = PolicyHipRunner(eager.shared_net, eager.actor, eager.critic).forward(obs)
+    assert max_abs(o1["mu"].cpu(), o2["mu"].cpu()) <= 1e-6 and max_abs(o1["value"].cpu(), o2["value"].cpu()) <= 1e-6
