@@ -388,11 +388,6 @@ def _lbs_in_scene_ms(env, lib, reps=8):
             "fraction_of_agents_with_zero_penetration": inside}
 
 
-def _tuned_gemm_active():
-    from egogen_amd import tuned_gemm
-    return bool(tuned_gemm.enable())
-
-
 def main():
     import faulthandler
     faulthandler.enable()
@@ -505,7 +500,7 @@ def main():
                    "agents_total": total_agents, "agents_per_gpu": A, "scene": args.scene, "vec_steps_per_collect": args.vec_steps,
                    "minibatch_global": bs_local * world, "minibatch_per_gpu": bs_local,
                    "parallelism": f"dp{world}" if world > 1 else "single", "hip_graph_env": bool(args.graph),
-                   "hip_graph_update": m["graphs_ok"], "library_gemm_table": _tuned_gemm_active()},
+                   "hip_graph_update": m["graphs_ok"], "update": "hand-written launch chain (csrc/update3.hip)" if m["policy"]._train_handles else "autograd nodes + library GEMMs"},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,

@@ -38,17 +38,28 @@ __device__ __forceinline__ void d3_split(const float (&x)[8], bf16x8 (&pl)[3]) {
   }
 }
 
-// acc += a . b with the six significant partial products, small ones first; `one`: the leading product only (operands
-// rounded to bf16, fp32 accumulation - the "bf16 MFMA policy" of BASELINE config 5, egx_policy_set_precision)
-__device__ __forceinline__ f32x4 d3_mma(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc, bool one) {
-  if (one) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-  return acc;
+// acc += a . b with the six significant partial products (mid.mid, hi.lo, lo.hi, hi.mid, mid.hi, hi.hi: small ones first);
+// `one`: the leading product only (operands rounded to bf16, fp32 accumulation - the "bf16 MFMA policy" of BASELINE config 5,
+// egx_policy_set_precision).  For a block of MI x NI output tiles, product-major: consecutive MFMAs go to different
+// accumulators, so none waits for the previous one's result.
+template <int MI, int NI>
+__device__ __forceinline__ void d3_mma_tiles(const bf16x8 (&fa)[MI][3], const bf16x8 (&fb)[NI][3], f32x4 (&acc)[MI][NI], bool one) {
+  if (one) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
+    return;
+  }
+#pragma unroll
+  for (int pr = 0; pr < 6; ++pr) {
+    const int pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
+    const int pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi][pa], fb[ni][pb], acc[mi][ni], 0, 0, 0);
+  }
 }
 
 __device__ __forceinline__ float d3_act(float v, int act, float slope) {
@@ -150,49 +161,53 @@ struct D3Args4 {
   int end0, end1, end2;   // blocks [0, end0) work on p0, [end0, end1) on p1, [end1, end2) on p2, the rest on p3
 };
 
-template <int TRIP>
-__global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args4 four) {
+// MI x NI MFMA tiles of 16 x 16 per workgroup of NW waves (instantiated: 2 x 2 tiles, four waves).
+template <int TRIP, int MI, int NI, int NW>
+__global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
+  constexpr int TM = 16 * MI, TN = 16 * NI, NACC = MI * NI * 4, PITCH = TN + 4;
   const int bx = (int)blockIdx.x;
   const int which = bx < four.end0 ? 0 : (bx < four.end1 ? 1 : (bx < four.end2 ? 2 : 3));
   const D3Plain& a = which == 0 ? four.p0 : (which == 1 ? four.p1 : (which == 2 ? four.p2 : four.p3));
   const int bid = bx - (which == 0 ? 0 : (which == 1 ? four.end0 : (which == 2 ? four.end1 : four.end2)));
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  __shared__ __attribute__((aligned(16))) float tile[32 * 36];
+  extern __shared__ __attribute__((aligned(16))) float d3_smem[];
+  float* red = d3_smem;                      // [NW waves][NACC][64]
+  float* tile = d3_smem + NW * NACC * 64;    // [TM][PITCH]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int MT = (a.M + 31) >> 5, NT = (a.N + 31) >> 5;
+  const int MT = (a.M + TM - 1) / TM, NT = (a.N + TN - 1) / TN;
   const int per_batch = d3_blocks(MT, NT);
   const int batch = bid / per_batch;
   int mt, nt;
   if (!d3_tile(bid - batch * per_batch, MT, NT, mt, nt)) return;
   const bf16x8* Ab = a.A + (size_t)batch * a.batch_strideA;
-  const int per = (a.S + 3) >> 2;
+  const int per = (a.S + NW - 1) / NW;
   const int s_lo = wave * per, s_hi = min(a.S, s_lo + per);
-  f32x4 acc[2][2];
+  const bool one = a.prec != 0;
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // fragment streams of this tile: A row tiles 2 mt, 2 mt + 1 (k-steps sa0 + s of a buffer with SA per row tile);
-  // B column tiles 2 nt, 2 nt + 1 (a column tile past N is all zeros in the packed weights: B is padded to 32 columns)
-  const bf16x8* pa[2];
-  const bf16x8* pb[2];
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment streams of this tile: A row tiles MI mt + i (k-steps sa0 + s of a buffer with SA per row tile); B column tiles
+  // NI nt + j, clamped to the image (packed images hold an even number of 16-row tiles; columns past N are never stored)
+  const int a_tiles = 2 * ((a.M + 31) >> 5), b_tiles = 2 * ((a.N + 31) >> 5);
+  const bf16x8* pa[MI];
+  const bf16x8* pb[NI];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    pa[h] = Ab + ((size_t)(2 * mt + h) * a.SA + a.sa0) * 3 * 64 + lane;
-    pb[h] = a.B + (size_t)(2 * nt + h) * a.S * 3 * 64 + lane;
-  }
+  for (int i = 0; i < MI; ++i) pa[i] = Ab + ((size_t)min(MI * mt + i, a_tiles - 1) * a.SA + a.sa0) * 3 * 64 + lane;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) pb[j] = a.B + (size_t)min(NI * nt + j, b_tiles - 1) * a.S * 3 * 64 + lane;
   for (int s = s_lo; s < s_hi; s += TRIP) {
-    bf16x8 fa[TRIP][2][3], fb[TRIP][2][3];
+    bf16x8 fa[TRIP][MI][3], fb[TRIP][NI][3];
 #pragma unroll
     for (int u = 0; u < TRIP; ++u) {
       const int su = min(s + u, s_hi - 1);
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int p = 0; p < 3; ++p) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          fa[u][h][p] = pa[h][(size_t)(su * 3 + p) * 64];
-          fb[u][h][p] = pb[h][(size_t)(su * 3 + p) * 64];
-        }
+        for (int i = 0; i < MI; ++i) fa[u][i][p] = pa[i][(size_t)(su * 3 + p) * 64];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[u][j][p] = pb[j][(size_t)(su * 3 + p) * 64];
+      }
     }
     // burst, wait, then only MFMAs: a wave that issues MFMAs with its own loads in flight runs the matrix pipe at about
     // half rate on this part (scripts/ubench/mfma_bf16.hip)
@@ -202,33 +217,35 @@ __global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args4 four) {
 #pragma unroll
     for (int u = 0; u < TRIP; ++u) {
       if (s + u >= s_hi) break;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d3_mma(fa[u][mi], fb[u][ni], acc[mi][ni], a.prec != 0);
+      d3_mma_tiles<MI, NI>(fa[u], fb[u], acc, one);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // split-K reduction through LDS; wave w then finishes MFMA tile (w >> 1, w & 1): bias, activation, residual
+  // split-K reduction through LDS; wave w then finishes MFMA tiles w, w + NW, ...: bias, activation, residual
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(wave * 16 + (mi * 2 + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
+      for (int r = 0; r < 4; ++r) red[(wave * NACC + (mi * NI + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
   __syncthreads();
-  {
-    const int mi = wave >> 1, ni = wave & 1;
-    const int col = 16 * ni + (lane & 15), n = nt * 32 + col;
+  const int row_base = batch * a.batch_rows_out;
+#pragma unroll
+  for (int t0 = 0; t0 < MI * NI; t0 += NW) {
+    const int t = t0 + wave;
+    if (t >= MI * NI) break;
+    const int mi = t / NI, ni = t % NI;
+    const int col = 16 * ni + (lane & 15), n = nt * TN + col;
     const float bsv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
-    const int row_base = batch * a.batch_rows_out;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int q = (mi * 2 + ni) * 4 + r;
-      float v = ((red[(0 * 16 + q) * 64 + lane] + red[(1 * 16 + q) * 64 + lane]) + red[(2 * 16 + q) * 64 + lane]) +
-                red[(3 * 16 + q) * 64 + lane] + bsv;
+      const int q = t * 4 + r;
+      float v = (red[(0 * NACC + q) * 64 + lane] + red[(1 * NACC + q) * 64 + lane]) + red[(2 * NACC + q) * 64 + lane];
+#pragma unroll
+      for (int w2 = 3; w2 < NW; ++w2) v += red[(w2 * NACC + q) * 64 + lane];
+      v += bsv;
       v = d3_act(v, a.act, a.slope);
-      const int row = 16 * mi + 4 * (lane >> 4) + r, m = mt * 32 + row;
+      const int row = 16 * mi + 4 * (lane >> 4) + r, m = mt * TM + row;
       const bool live = m < a.M && n < a.N;
       if (live && a.out_act) a.out_act[(size_t)m * a.ldact + n] = v;   // activation before the skip connection (saved for backward)
       if (live && a.res) v += a.res[(size_t)(row_base + m) * a.ldr + n];
@@ -240,35 +257,40 @@ __global__ __launch_bounds__(256) void egx_dense3_kernel(D3Args4 four) {
       }
       // gradient launches: what goes on to the next products is v x act'(saved activation of the layer below)
       if (live && a.dact) v *= d3_act_grad(a.dact[(size_t)m * a.lddact + n], a.dact_code, a.dact_slope);
-      tile[row * 36 + col] = live ? v : 0.f;
+      tile[row * PITCH + col] = live ? v : 0.f;
     }
   }
-  if (a.out3 || a.out3T) __syncthreads();
-  if (a.out3T && wave >= 2) {
-    // transposed image (rows = this layer's columns, reduction index = its rows): the tile is k-step (s3T0 + mt) of row tiles
-    // 2 nt, 2 nt + 1 - what a weight-gradient product reads as its A (gradients) or B (activations) operand
-    const int half = wave - 2, c = 16 * half + (lane & 15), kg = lane >> 4;
+  if (!a.out3 && !a.out3T) return;
+  __syncthreads();
+  // packed images of the tile.  Row-major image (the consumer's A operand): 16-row tiles MI mt + i, k-steps s30 + nt NI/2 + j.
+  // Transposed image (rows = this layer's columns, reduction index = its rows - what a weight-gradient product reads):
+  // row tiles NI nt + j, k-steps s3T0 + mt MI/2 + i.  One wave per fragment.
+  constexpr int NR = MI * (NI / 2), NTT = NI * (MI / 2);
+  const int ntask = (a.out3 ? NR : 0) + (a.out3T ? NTT : 0);
+  const int m_ksteps = (a.M + 31) >> 5, n_ksteps = (a.N + 31) >> 5;   // extents of the images (even tile counts)
+  for (int task = wave; task < ntask; task += NW) {
     float x[8];
+    bf16x8* o;
+    if (a.out3 && task < NR) {
+      const int i = task / (NI / 2), j = task % (NI / 2);
+      if (MI * mt + i >= 2 * m_ksteps || nt * (NI / 2) + j >= n_ksteps) continue;   // past the image (ragged last tile)
+      const int row = 16 * i + (lane & 15), g = lane >> 4;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&tile[row * PITCH + 32 * j + 8 * g]), x1 = *reinterpret_cast<const f32x4*>(&tile[row * PITCH + 32 * j + 8 * g + 4]);
+      x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2]; x[3] = x0[3]; x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3];
+      o = a.out3 + (size_t)batch * a.batch_stride3 + ((size_t)(MI * mt + i) * a.S3 + a.s30 + nt * (NI / 2) + j) * 3 * 64 + lane;
+    } else {
+      const int tt = task - (a.out3 ? NR : 0);
+      const int j = tt / (MI / 2), i = tt % (MI / 2);
+      if (NI * nt + j >= 2 * n_ksteps || mt * (MI / 2) + i >= m_ksteps) continue;
+      const int c = 16 * j + (lane & 15), kg = lane >> 4;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = tile[(8 * kg + e) * 36 + c];
+      for (int e = 0; e < 8; ++e) x[e] = tile[(32 * i + 8 * kg + e) * PITCH + c];
+      o = a.out3T + ((size_t)(NI * nt + j) * a.S3T + a.s3T0 + mt * (MI / 2) + i) * 3 * 64 + lane;
+    }
     bf16x8 pl[3];
     d3_split(x, pl);
-    bf16x8* o = a.out3T + ((size_t)(2 * nt + half) * a.S3T + a.s3T0 + mt) * 3 * 64 + lane;
 #pragma unroll
     for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
-  }
-  if (a.out3) {
-    // the tile is k-step (s30 + nt) of the consumer's A operand: two 16-row fragments x three planes
-    if (wave < 2) {
-      const int row = 16 * wave + (lane & 15), g = lane >> 4;
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&tile[row * 36 + 8 * g]), x1 = *reinterpret_cast<const f32x4*>(&tile[row * 36 + 8 * g + 4]);
-      const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      bf16x8 pl[3];
-      d3_split(x, pl);
-      bf16x8* o = a.out3 + (size_t)batch * a.batch_stride3 + ((size_t)(2 * mt + wave) * a.S3 + a.s30 + nt) * 3 * 64 + lane;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
-    }
   }
 }
 
@@ -296,13 +318,13 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
   const int MT = (a.M + 31) >> 5, CT = a.H >> 4;
   int mt, ct;
   if (!d3_tile(gru_bid, MT, CT, mt, ct)) return;
-  f32x4 acc[2][3][2];   // [side][gate][row half]
+  f32x4 acc[2][2][3];   // [side][row half][gate]
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd)
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) acc[sd][g][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 3; ++g) acc[sd][mi][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd) {
     const bf16x8* A = sd ? a.Ah : a.Ai;
@@ -336,10 +358,7 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
 #pragma unroll
       for (int u = 0; u < TRIP; ++u) {
         if (s + u >= s_hi) break;
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) acc[sd][g][mi] = d3_mma(fa[u][mi], fb[u][g], acc[sd][g][mi], a.prec != 0);
+        d3_mma_tiles<2, 3>(fa[u], fb[u], acc[sd], a.prec != 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -351,7 +370,7 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(wave * 48 + ((sd * 3 + g) * 2 + mi) * 4 + r) * 64 + lane] = acc[sd][g][mi][r];
+        for (int r = 0; r < 4; ++r) red[(wave * 48 + ((sd * 3 + g) * 2 + mi) * 4 + r) * 64 + lane] = acc[sd][mi][g][r];
   __syncthreads();
   // wave w finishes positions (mi, r) = (w >> 1, 2 (w & 1) + {0, 1}) of every lane: all six gate values of an element in
   // one thread
@@ -493,7 +512,7 @@ void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, in
 //   * weights are read from packed images (one contiguous KiB per fragment), the next layer's prefetched under the epilogue.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int R3_ROWS = 48, R3_XB = 159, R3_XBP = 164, R3_NOUT = 159;
+constexpr int R3_ROWS = 48, R3_XBP = 164, R3_NOUT = 159;
 constexpr int R3_ACT_FRAGS = 3 * 4 * 3 * 64;            // one 48 x 128 activation buffer, in bf16x8 fragments-lanes
 constexpr int R3_STRIP = R3_ROWS * 20;                  // floats per wave: 48 rows x 16 columns, pitch 20
 constexpr size_t R3_LDS = (size_t)R3_ROWS * R3_XBP * 4 + 2 * (size_t)R3_ACT_FRAGS * 16 + 8 * (size_t)R3_STRIP * 4;
@@ -506,17 +525,27 @@ __device__ __forceinline__ void r3_load_w(const bf16x8* P, int tile, int S, int 
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) wf[s][pl] = p[(s * 3 + pl) * 64];
 }
+// acc[rt] += a[rt] . w for the three row tiles, product-major (no MFMA waits for the previous one's result)
+__device__ __forceinline__ void r3_mma3(const bf16x8 (&a)[3][3], const bf16x8 (&wf)[3], f32x4 (&acc)[3]) {
+#pragma unroll
+  for (int pr = 0; pr < 6; ++pr) {
+    const int pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
+    const int pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][pa], wf[pb], acc[rt], 0, 0, 0);
+  }
+}
 // acc[rt] += act(48 x 128, packed in LDS) . w^T for the wave's 16 columns
 __device__ __forceinline__ void r3_mma128(const bf16x8* act, int lane, const bf16x8 (&wf)[4][3], f32x4 (&acc)[3]) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int s = 0; s < 4; ++s) {
+    bf16x8 a[3][3];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) {
-      bf16x8 a[3];
+    for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[pl] = act[((rt * 4 + s) * 3 + pl) * 64 + lane];
-      acc[rt] = d3_mma(a, wf[s], acc[rt], false);
-    }
+      for (int pl = 0; pl < 3; ++pl) a[rt][pl] = act[((rt * 4 + s) * 3 + pl) * 64 + lane];
+    r3_mma3(a, wf[s], acc);
+  }
 }
 // v[rt][r] (C layout: column lane & 15 of the wave's tile, rows 16 rt + 4 (lane >> 4) + r) -> packed planes of k-group pair
 // (wave & 1) of k-step wave >> 1 of `dst`, through the wave's transposition strip
@@ -584,13 +613,12 @@ __global__ __launch_bounds__(512, 2) void egx_regressor3_kernel(RegWeights3 w, c
       const bf16x8* pw = (s < 7) ? w.in_m + ((size_t)(wave * 7 + s) * 3) * 64 + lane : w.in_b3 + ((size_t)wave * 3) * 64 + lane;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) wf[pl] = pw[pl * 64];
+      bf16x8 a[3][3];
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt) {
-        bf16x8 a[3];
+      for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[pl] = in3[((rt * 8 + s) * 3 + pl) * 64 + lane];
-        base[rt] = d3_mma(a, wf, base[rt], false);
-      }
+        for (int pl = 0; pl < 3; ++pl) a[rt][pl] = in3[((rt * 8 + s) * 3 + pl) * 64 + lane];
+      r3_mma3(a, wf, base);
     }
   }
   __syncthreads();
@@ -619,13 +647,12 @@ __global__ __launch_bounds__(512, 2) void egx_regressor3_kernel(RegWeights3 w, c
         bf16x8 wf[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) wf[pl] = w.in_xb[((size_t)(wave * 5 + s) * 3 + pl) * 64 + lane];
+        bf16x8 a[3][3];
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt) {
-          bf16x8 a[3];
+        for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) a[pl] = xb3[((rt * 5 + s) * 3 + pl) * 64 + lane];
-          acc[rt] = d3_mma(a, wf, acc[rt], false);
-        }
+          for (int pl = 0; pl < 3; ++pl) a[rt][pl] = xb3[((rt * 5 + s) * 3 + pl) * 64 + lane];
+        r3_mma3(a, wf, acc);
       }
       __syncthreads();   // everyone is done reading xb3 before h overwrites the region
     }
@@ -712,21 +739,46 @@ int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, 
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
-void egx_launch_dense3_n(hipStream_t st, const D3Plain* ps, int n) {
+namespace {
+template <int TRIP, int MI, int NI, int NW>
+void d3_launch_cfg(hipStream_t st, const D3Plain* ps, int n) {
+  constexpr int TM = 16 * MI, TN = 16 * NI;
+  constexpr size_t lds = (size_t)(NW * MI * NI * 4 * 64 + TM * (TN + 4)) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS");
+  if (lds > 64 * 1024) {   // above the default dynamic-LDS cap: raised once per device
+    static std::mutex mu;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_dense3_kernel<TRIP, MI, NI, NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev] = true;
+      }
+    }
+  }
   D3Args4 f;
   D3Plain* dst[4] = {&f.p0, &f.p1, &f.p2, &f.p3};
-  int ends[4] = {0, 0, 0, 0}, smax = 0, total = 0;
+  int ends[4] = {0, 0, 0, 0}, total = 0;
   for (int i = 0; i < 4; ++i) {
     *dst[i] = ps[i < n ? i : n - 1];
-    if (i < n) {
-      total += d3_blocks((ps[i].M + 31) >> 5, (ps[i].N + 31) >> 5) * std::max(1, ps[i].batches);
-      smax = std::max(smax, ps[i].S);
-    }
+    if (i < n) total += d3_blocks(egx_ceil_div(ps[i].M, TM), egx_ceil_div(ps[i].N, TN)) * std::max(1, ps[i].batches);
     ends[i] = total;
   }
   f.end0 = ends[0]; f.end1 = ends[1]; f.end2 = ends[2];
-  if (smax > 16) hipLaunchKernelGGL(egx_dense3_kernel<3>, dim3(total), dim3(256), 0, st, f);
-  else hipLaunchKernelGGL(egx_dense3_kernel<2>, dim3(total), dim3(256), 0, st, f);
+  hipLaunchKernelGGL((egx_dense3_kernel<TRIP, MI, NI, NW>), dim3(total), dim3(64 * NW), lds, st, f);
+}
+}  // namespace
+
+// 32 x 32 tile per 4-wave workgroup, the reduction split over the waves; three k-steps per round trip for deep reductions.
+// (Measured for the update's 1152-deep layers, profiles/r03_update_experiments.md: 64 x 64 and 64 x 32 tiles, eight-wave
+// split-K, a software-pipelined loop and two k-steps per trip all land within a few per cent of this form or behind it.)
+void egx_launch_dense3_n(hipStream_t st, const D3Plain* ps, int n) {
+  int smax = 0;
+  for (int i = 0; i < n; ++i) smax = std::max(smax, ps[i].S);
+  if (smax > 16) d3_launch_cfg<3, 2, 2, 4>(st, ps, n);
+  else d3_launch_cfg<2, 2, 2, 4>(st, ps, n);
 }
 void egx_launch_dense3(hipStream_t st, const D3Plain& p) { egx_launch_dense3_n(st, &p, 1); }
 void egx_launch_dense3_pair(hipStream_t st, const D3Plain& p, const D3Plain& q) {

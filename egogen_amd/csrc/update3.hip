@@ -9,7 +9,7 @@
 //             gradient one more output column; input- and weight-gradient products of the actor AND the critic share a launch;
 //   GRU       cell forward = one launch per time step for both encoders (dense3 gru kernel), cell backward = one launch per
 //             step producing the gate gradients directly as packed images.
-// ~21 launches per minibatch instead of ~85.  Gradients are WRITTEN (not accumulated) into the flat gradient buffer - every
+// ~27 launches per minibatch instead of ~85.  Gradients are WRITTEN (not accumulated) into the flat gradient buffer - every
 // parameter is used exactly once per minibatch - so the buffer needs no zero fill.
 #include <cstring>
 #include <vector>
@@ -195,7 +195,7 @@ struct Branch {   // actor or critic MLP block
   bf16x8 *W_r[4], *W_t[4], *Wout_r, *Wout_t;   // weight images
   float *a[4], *u1f, *du2, *du1, *dhx;         // saved activations (fp32), unit-1 output, fp32 gradients of u2 / u1 / hx
   bf16x8 *a1_r, *u1_r, *a3_r, *u2_r, *a1T, *u1T, *a3T, *u2T;
-  bf16x8 *gA_r, *gAT, *gB_r, *gBT;             // gradient images: gA = g4 then g2, gB = g3 then g1
+  bf16x8 *g_r[4], *gT[4];                      // images of the gradient w.r.t. the pre-activation of layer l (and their transposes)
   float* head;                                 // zp [n,256] / value [n]
   float* ghead;                                // loss gradient w.r.t. the head's output
   bf16x8 *ghead_r, *gheadT;
@@ -271,7 +271,7 @@ void layout(egx_policy_train* h) {
     B.u1f = f32((size_t)n * CAT); B.du2 = f32((size_t)n * CAT); B.du1 = f32((size_t)n * CAT); B.dhx = f32((size_t)n * CAT);
     B.a1_r = img(n, CAT); B.u1_r = img(n, CAT); B.a3_r = img(n, CAT); B.u2_r = img(n, CAT);
     B.a1T = img(CAT + 1, n); B.u1T = img(CAT + 1, n); B.a3T = img(CAT + 1, n); B.u2T = img(CAT + 1, n);
-    B.gA_r = img(n, CAT); B.gAT = img(CAT, n); B.gB_r = img(n, CAT); B.gBT = img(CAT, n);
+    for (int l = 0; l < 4; ++l) { B.g_r[l] = img(n, CAT); B.gT[l] = img(CAT, n); }
     B.head = f32((size_t)n * B.nout); B.ghead = f32((size_t)n * B.nout);
     B.ghead_r = img(n, B.nout); B.gheadT = img(B.nout, n);
   }
@@ -423,6 +423,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
   const int n = h->n, Sn = h->Sn;
   constexpr int S_HD = HD / 32, S_CAT = CAT / 32, S_G = 3 * HD / 32;
   const float slope = 0.01f;   // torch.nn.LeakyReLU() default (baseops.py:627-628)
+
   // ================= forward =================
   run_table(st, h->tab_inputs, h->n_inputs, h->frags_inputs);
   egx_launch_posenc3(st, dist, time, n, h->catf + 2 * HD, CAT, h->cat_r, S_CAT, 2 * S_HD, h->catT, Sn, 2 * HD);
@@ -488,67 +489,66 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
                                eps_clip, vf_coef, ent_coef, n, h->br[0].ghead, h->br[1].ghead, out_terms, st);
   if (rc) return rc;
   run_table(st, h->tab_loss, h->n_loss, h->frags_loss);
-  // ================= backward: the two MLP blocks =================
-  {
-    D3Plain P[4];
-    auto wgrad = [&](D3Plain& q, const bf16x8* gT, const bf16x8* xT, int rows, float* gW, float* gb) {
-      q = D3Plain();
-      q.M = rows; q.N = CAT + 1; q.A = gT; q.SA = Sn; q.S = Sn; q.B = xT; q.out = gW; q.ldo = CAT; q.n_split = CAT; q.bias_out = gb;
-    };
-    for (int b = 0; b < 2; ++b) {   // out_fc: dW = g^T u2, du2 = g W_out -> g4 = du2 x lrelu'(a4)
+  // ================= backward =================
+  // Input-gradient products form the dependent chain (out_fc -> unit 2 -> unit 1 -> GRU cells); each layer's weight-gradient
+  // product follows the launch that left its gradient image behind.  (Weight gradients on a second stream beside the chain,
+  // and fused into the input-gradient launches, were both measured and are not faster: profiles/r03_update_experiments.md.)
+  hipStream_t sw = st;
+  auto wgrad = [&](D3Plain& q, const bf16x8* gT, const bf16x8* xT, int rows, float* gW, float* gb) {
+    q = D3Plain();
+    q.M = rows; q.N = CAT + 1; q.A = gT; q.SA = Sn; q.S = Sn; q.B = xT; q.out = gW; q.ldo = CAT; q.n_split = CAT; q.bias_out = gb;
+  };
+  Branch &Ba = h->br[0], &Bc = h->br[1];
+  D3Plain W[4], D[2];
+  for (int b = 0; b < 2; ++b) wgrad(W[b], h->br[b].gheadT, h->br[b].u2T, h->br[b].nout, h->br[b].gWout, h->br[b].gbout);
+  egx_launch_dense3_n(sw, W, 2);
+  // input gradient of one layer for both blocks: d = g_in W^T-image (+ skip) -> fp32 `out` raw, images gated by act'(a[gate])
+  auto dgrad = [&](const bf16x8* const (&gin)[2], const int (&S_in)[2], const bf16x8* const (&Wt)[2], float* const (&res)[2],
+                   float* const (&outf)[2], int gate, int lout) {
+    for (int b = 0; b < 2; ++b) {
       Branch& B = h->br[b];
-      wgrad(P[2 * b], B.gheadT, B.u2T, B.nout, B.gWout, B.gbout);
-      D3Plain& d = P[2 * b + 1];
+      D3Plain& d = D[b];
       d = D3Plain();
-      d.M = n; d.N = CAT; d.A = B.ghead_r; d.SA = egx_ceil_div(B.nout, 32); d.S = d.SA; d.B = B.Wout_t; d.out = B.du2; d.ldo = CAT;
-      d.dact = B.a[3]; d.lddact = CAT; d.dact_code = 3; d.dact_slope = slope;
-      d.out3 = B.gA_r; d.S3 = S_CAT; d.out3T = B.gAT; d.S3T = Sn;
-    }
-    egx_launch_dense3_n(st, P, 4);
-    // one residual unit: W_hi its second layer (input x_hi), W_lo its first (input x_lo); dout = gradient of the unit's output
-    auto unit = [&](int hi, int lo, bf16x8* const (&x_hiT)[2], bf16x8* const (&x_loT)[2], float* const (&dout)[2], float* const (&dx)[2],
-                    int below /* saved activation the next gradient is gated by, -1: none */) {
-      for (int b = 0; b < 2; ++b) {   // launch A: dW_hi = gA^T x_hi, d(a_lo) = gA W_hi -> gB = . x lrelu'(a_lo)
-        Branch& B = h->br[b];
-        wgrad(P[2 * b], B.gAT, x_hiT[b], CAT, B.gW[hi], B.gb[hi]);
-        D3Plain& d = P[2 * b + 1];
-        d = D3Plain();
-        d.M = n; d.N = CAT; d.A = B.gA_r; d.SA = S_CAT; d.S = S_CAT; d.B = B.W_t[hi];
-        d.dact = B.a[lo]; d.lddact = CAT; d.dact_code = 3; d.dact_slope = slope;
-        d.out3 = B.gB_r; d.S3 = S_CAT; d.out3T = B.gBT; d.S3T = Sn;
+      d.M = n; d.N = CAT; d.A = gin[b]; d.SA = S_in[b]; d.S = S_in[b]; d.B = Wt[b];
+      d.res = res[b]; d.ldr = CAT; d.out = outf[b]; d.ldo = CAT;
+      if (gate >= 0) {
+        d.dact = B.a[gate]; d.lddact = CAT; d.dact_code = 3; d.dact_slope = slope;
+        d.out3 = B.g_r[lout]; d.S3 = S_CAT; d.out3T = B.gT[lout]; d.S3T = Sn;
       }
-      egx_launch_dense3_n(st, P, 4);
-      for (int b = 0; b < 2; ++b) {   // launch B: dW_lo = gB^T x_lo, dx = gB W_lo + dout -> gA = dx x lrelu'(a_below)
-        Branch& B = h->br[b];
-        wgrad(P[2 * b], B.gBT, x_loT[b], CAT, B.gW[lo], B.gb[lo]);
-        D3Plain& d = P[2 * b + 1];
-        d = D3Plain();
-        d.M = n; d.N = CAT; d.A = B.gB_r; d.SA = S_CAT; d.S = S_CAT; d.B = B.W_t[lo];
-        d.res = dout[b]; d.ldr = CAT; d.out = dx[b]; d.ldo = CAT;
-        if (below >= 0) {
-          d.dact = B.a[below]; d.lddact = CAT; d.dact_code = 3; d.dact_slope = slope;
-          d.out3 = B.gA_r; d.S3 = S_CAT; d.out3T = B.gAT; d.S3T = Sn;
-        }
-      }
-      egx_launch_dense3_n(st, P, 4);
-    };
-    Branch &Ba = h->br[0], &Bc = h->br[1];
-    {
-      bf16x8* const xh[2] = {Ba.a3T, Bc.a3T};
-      bf16x8* const xl[2] = {Ba.u1T, Bc.u1T};
-      float* const dout[2] = {Ba.du2, Bc.du2};
-      float* const dx[2] = {Ba.du1, Bc.du1};
-      unit(3, 2, xh, xl, dout, dx, 1);
     }
-    {
-      bf16x8* const xh[2] = {Ba.a1T, Bc.a1T};
-      bf16x8* const xl[2] = {h->catT, h->catT};
-      float* const dout[2] = {Ba.du1, Bc.du1};
-      float* const dx[2] = {Ba.dhx, Bc.dhx};
-      unit(1, 0, xh, xl, dout, dx, -1);
-    }
+    egx_launch_dense3_n(st, D, 2);
+  };
+  const int S_head[2] = {egx_ceil_div(Ba.nout, 32), egx_ceil_div(Bc.nout, 32)}, S_full[2] = {S_CAT, S_CAT};
+  float* const none[2] = {nullptr, nullptr};
+  {   // out_fc: du2 = g W_out -> g4 = du2 x lrelu'(a4)
+    const bf16x8* const gin[2] = {Ba.ghead_r, Bc.ghead_r};
+    const bf16x8* const Wt[2] = {Ba.Wout_t, Bc.Wout_t};
+    float* const outf[2] = {Ba.du2, Bc.du2};
+    dgrad(gin, S_head, Wt, none, outf, 3, 3);
   }
-  // ================= backward: the two GRU encoders (dhx = actor's + critic's) =================
+  // layer l of both blocks: dW_l = g_l^T x_l on the side stream; then the input gradient of layer l on `st`
+  auto layer_bwd = [&](int l, bf16x8* const (&xT)[2], float* const (&res)[2], float* const (&outf)[2], int gate) {
+    for (int b = 0; b < 2; ++b) wgrad(W[b], h->br[b].gT[l], xT[b], CAT, h->br[b].gW[l], h->br[b].gb[l]);
+    egx_launch_dense3_n(sw, W, 2);
+    const bf16x8* const gin[2] = {Ba.g_r[l], Bc.g_r[l]};
+    const bf16x8* const Wt[2] = {Ba.W_t[l], Bc.W_t[l]};
+    dgrad(gin, S_full, Wt, res, outf, gate, gate);
+    return EGX_OK;
+  };
+  {
+    bf16x8* const x3[2] = {Ba.a3T, Bc.a3T};
+    if ((rc = layer_bwd(3, x3, none, none, 2))) return rc;                    // d(a3) = g4 W4 -> g3
+    bf16x8* const x2[2] = {Ba.u1T, Bc.u1T};
+    float* const du2[2] = {Ba.du2, Bc.du2};
+    float* const du1[2] = {Ba.du1, Bc.du1};
+    if ((rc = layer_bwd(2, x2, du2, du1, 1))) return rc;                      // du1 = g3 W3 + du2 -> g2
+    bf16x8* const x1[2] = {Ba.a1T, Bc.a1T};
+    if ((rc = layer_bwd(1, x1, none, none, 0))) return rc;                    // d(a1) = g2 W2 -> g1
+    bf16x8* const x0[2] = {h->catT, h->catT};
+    float* const dhx[2] = {Ba.dhx, Bc.dhx};
+    if ((rc = layer_bwd(0, x0, du1, dhx, -1))) return rc;                     // dhx = g1 W1 + du1
+  }
+  // ---- the two GRU encoders (dhx = actor's + critic's)
   {
     GruBwd2 two;
     const int blocks = (n / 32) * (HD / 32);
@@ -577,7 +577,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
       q.s0T = 0; q.dgh_r = nullptr; q.dhp = nullptr;
     }
     hipLaunchKernelGGL(egx_gru_bwd3_kernel, dim3(2 * blocks), dim3(256), 0, st, two);
-    for (int e = 0; e < 2; ++e) {   // dW_ih = [dgi1; dgi2]^T [x0; x1], dW_hh = [dgh1; dgh2]^T [0; h1]; the ones rows give the biases
+      for (int e = 0; e < 2; ++e) {   // dW_ih = [dgi1; dgi2]^T [x0; x1], dW_hh = [dgh1; dgh2]^T [0; h1]; the ones rows give the biases
       Encoder& E = h->enc[e];
       D3Plain& a = P[2 * e];
       a = D3Plain();
@@ -588,7 +588,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
       c.M = 3 * HD; c.N = HD + 1; c.A = E.dghT; c.SA = 2 * Sn; c.S = 2 * Sn; c.B = E.hprevT; c.out = E.gWhh; c.ldo = HD;
       c.n_split = HD; c.bias_out = E.gbhh;
     }
-    egx_launch_dense3_n(st, P, 4);
+    egx_launch_dense3_n(sw, P, 4);
   }
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;

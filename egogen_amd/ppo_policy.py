@@ -565,9 +565,6 @@ class GAMMAPPOPolicy(nn.Module):
     def learn(self, batch: RolloutBatch, batch_size: int, repeat: int) -> Dict[str, List[float]]:
         """ppo_policy.py:182-265.  `batch_size` is the GLOBAL minibatch size; each rank contributes batch_size/world."""
         self.train()
-        if batch.act.is_cuda:
-            from . import tuned_gemm
-            tuned_gemm.enable()   # read-only solution table for the update's library GEMMs (no tuning at run time)
         self._ensure_flat_grads()
         if self.use_flat_optimizer and batch.act.is_cuda:
             self._flat_optimizer_ready()  # (re-)points parameters / optimiser state BEFORE anything is captured

@@ -58,20 +58,3 @@ def test_missing_config_raises(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     with pytest.raises(FileNotFoundError):
         sw.load_model(cfg_dir=str(tmp_path / "nowhere"))
-
-
-def test_tuned_gemm_table_is_well_formed_and_inert_without_a_gpu():
-    """egogen_amd/data/tunableop_gfx950.csv (scripts/tune_gemms.sh): validator header for the stack it was tuned on, one solution
-    per GEMM shape of the update at 256 / 128 / 64 / 32 local minibatch rows; enable() is a no-op without a HIP device."""
-    import torch
-    from egogen_amd import tuned_gemm
-    lines = [ln.strip().split(",") for ln in open(tuned_gemm.TABLE) if ln.strip()]
-    val = {ln[1]: ln[2] for ln in lines if ln[0] == "Validator"}
-    assert {"PT_VERSION", "HIP_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"} <= set(val) and val["GCN_ARCH_NAME"].startswith("gfx950")
-    sols = [ln for ln in lines if ln[0] != "Validator"]
-    assert len(sols) >= 60 and all(len(ln) == 4 and float(ln[3]) > 0 for ln in sols)
-    shapes = {ln[1] for ln in sols}
-    for rows in (256, 128, 64, 32):   # forward of the 1152-wide residual layers and its two gradients at every local minibatch size
-        assert f"tn_1152_{rows}_1152_ld_1152_1152_1152" in shapes and f"nt_1152_1152_{rows}_ld_1152_1152_1152" in shapes
-    if not torch.cuda.is_available():
-        assert tuned_gemm.enable() is False
