@@ -813,11 +813,22 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
   w.lds = nullptr;
   w.qn = 0;
   w.s_cnt[lane] = 0;
-  int bg_lo, nper, n_streams, stream;
-  if (p.nbg >= 8 && (gridDim.x & 7) == 0) {
+  // Work partition over the XCDs (blocks are dealt to them round-robin).  With >= 8 body groups every XCD owns a chunk of
+  // body groups and all vertex tiles: its bodies' features / transforms stay in its L2 and the bases stream through once per
+  // block of groups.  With fewer groups (an 8-way agent split leaves 64 agents = 5 groups per GPU) every XCD owns a chunk of
+  // VERTEX TILES and all groups instead: it streams an eighth of the bases once, and the few bodies' features fit any L2.
+  int bg_lo, nper, n_streams, stream, vt_lo = 0, nvt = p.n_tiles;
+  if ((gridDim.x & 7) == 0 && p.nbg >= 8) {
     const int per = (p.nbg + 7) / 8, xcd = blockIdx.x & 7;
     bg_lo = xcd * per;
     nper = max(0, min(per, p.nbg - bg_lo));
+    n_streams = gridDim.x >> 3;
+    stream = blockIdx.x >> 3;
+  } else if ((gridDim.x & 7) == 0 && p.n_tiles >= 8) {
+    const int per = (p.n_tiles + 7) / 8, xcd = blockIdx.x & 7;
+    vt_lo = xcd * per;
+    nvt = max(0, min(per, p.n_tiles - vt_lo));
+    bg_lo = 0; nper = p.nbg;
     n_streams = gridDim.x >> 3;
     stream = blockIdx.x >> 3;
   } else {
@@ -825,17 +836,17 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
     n_streams = gridDim.x;
     stream = blockIdx.x;
   }
-  const int n_items = p.n_tiles * nper;
+  const int n_items = nvt * nper;
   // item order: blocks of bg_block body groups, vertex-tile-major inside a block - the features / joint transforms of
   // a block (1.4 MB per group) stay in the XCD's 4 MiB L2 while the bases stream through once per block
   const int PB = max(1, min(p.bg_block, max(nper, 1)));
   unsigned long long tacc[4] = {0, 0, 0, 0};
   (void)tacc;
   for (int item = stream; item < n_items; item += n_streams) {
-    const int blk = item / (p.n_tiles * PB);
+    const int blk = item / (nvt * PB);
     const int pb = min(PB, nper - blk * PB);
-    const int r = item - blk * p.n_tiles * PB;
-    const int vti = r / pb, bg = bg_lo + blk * PB + r % pb;
+    const int r = item - blk * nvt * PB;
+    const int vti = vt_lo + r / pb, bg = bg_lo + blk * PB + r % pb;
     const int vt = p.tiles ? p.tiles[vti] : vti;
     const int bt0 = bg * 8 + wave * NB;
     __syncthreads();  // previous item: every wave is done with the metadata and with the stage ring
@@ -1338,7 +1349,8 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     if (split3) {
       // two persistent 4-wave workgroups per CU: one's VALU epilogue runs under the other's MFMA stages
       constexpr size_t lds3 = (size_t)LBS3_SHARED_BYTES + 4 * LBS3_WAVE_BYTES;
-      const int grid3 = std::max(1, std::min(2 * num_cu, n_items));
+      int grid3 = std::max(1, std::min(2 * num_cu, n_items));
+      if (grid3 >= 8) grid3 &= ~7;   // a multiple of 8: the kernel's XCD partition (body groups, or vertex tiles when groups are few)
       if (mode == 2) {
         if (sdf) hipLaunchKernelGGL((egx_lbs_fused3_kernel<2, true>), dim3(grid3), dim3(256), lds3, stream, p);
         else hipLaunchKernelGGL((egx_lbs_fused3_kernel<2, false>), dim3(grid3), dim3(256), lds3, stream, p);
