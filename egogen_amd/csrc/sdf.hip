@@ -39,39 +39,10 @@ __global__ void egx_sdf_build_coarse_kernel(const float* __restrict__ grid, int 
   out[idx] = make_float2(mn, mx);
 }
 
-// Second level, appended to the first in the same buffer: the same brackets for blocks of 32 voxels (8 first-level blocks),
-// [(C0+2)][(C1+2)][(C2+2)] with C = ceil(d / 32) and the same meaning of the two padding layers.  A whole BODY is classified
-// against it (egx_pose_chain_kernel: every vertex of a body lies within a computable margin of the box of its joints):
-// bodies that are entirely inside an obstacle / outside the room, or entirely in free space, need no per-vertex lookups.
-__global__ void egx_sdf_build_coarse2_kernel(const float2* __restrict__ l1, int c0, int c1, int c2, int C0, int C1, int C2,
-                                             float2* __restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int E1 = C1 + 2, E2 = C2 + 2;
-  if (idx >= (C0 + 2) * E1 * E2) return;
-  const int jz = idx % E2, jy = (idx / E2) % E1, jx = idx / (E1 * E2);
-  auto range = [](int j, int C, int c, int& lo, int& hi) {
-    if (j == 0) { lo = hi = 0; }
-    else if (j == C + 1) { lo = hi = c + 1; }
-    else { lo = 8 * (j - 1) + 1; hi = min(8 * j, c); }
-  };
-  int x0, x1, y0, y1, z0, z1;
-  range(jx, C0, c0, x0, x1); range(jy, C1, c1, y0, y1); range(jz, C2, c2, z0, z1);
-  float mn = 3.4e38f, mx = -3.4e38f;
-  for (int x = x0; x <= x1; ++x)
-    for (int y = y0; y <= y1; ++y)
-      for (int z = z0; z <= z1; ++z) {
-        const float2 v = l1[((size_t)x * (c1 + 2) + y) * (c2 + 2) + z];
-        mn = fminf(mn, v.x);
-        mx = fmaxf(mx, v.y);
-      }
-  out[idx] = make_float2(mn, mx);
-}
-
 extern "C" size_t egx_sdf_coarse_bytes(int d0, int d1, int d2) {
   if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
   const size_t c0 = egx_ceil_div(d0, 4), c1 = egx_ceil_div(d1, 4), c2 = egx_ceil_div(d2, 4);
-  const size_t C0 = egx_ceil_div(d0, 32), C1 = egx_ceil_div(d1, 32), C2 = egx_ceil_div(d2, 32);
-  return ((c0 + 2) * (c1 + 2) * (c2 + 2) + (C0 + 2) * (C1 + 2) * (C2 + 2)) * sizeof(float2);
+  return (c0 + 2) * (c1 + 2) * (c2 + 2) * sizeof(float2);
 }
 
 extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream_) {
@@ -80,10 +51,6 @@ extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, v
   const int n = (c0 + 2) * (c1 + 2) * (c2 + 2);
   hipLaunchKernelGGL(egx_sdf_build_coarse_kernel, dim3(egx_ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      sdf->grid, sdf->d0, sdf->d1, sdf->d2, c0, c1, c2, static_cast<float2*>(coarse_out));
-  const int C0 = egx_ceil_div(sdf->d0, 32), C1 = egx_ceil_div(sdf->d1, 32), C2 = egx_ceil_div(sdf->d2, 32);
-  const int n2 = (C0 + 2) * (C1 + 2) * (C2 + 2);
-  hipLaunchKernelGGL(egx_sdf_build_coarse2_kernel, dim3(egx_ceil_div(n2, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                     static_cast<const float2*>(coarse_out), c0, c1, c2, C0, C1, C2, static_cast<float2*>(coarse_out) + n);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
