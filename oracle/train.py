@@ -96,3 +96,24 @@ def predictor_loss_rollout(sd, ref_markers, ref_jts, eps_list, t_his=2, max_roll
             break
     loss = torch.stack(losses).mean()
     return loss, torch.stack(infos).mean(0)
+
+
+# ---- body-regressor training loss (models/models_GAMMA_primitive.py:617-633, GAMMARegressorTrainOP.calc_loss) -------------
+# Pinned by tests/golden/regressor_train_ref.npz (scripts/gen_goldens.py regressor_train runs the reference class with its
+# body model replaced by the adapter around smplx_lbs.py and torchgeometry by rot.py: the class's own arithmetic is pinned,
+# the two third-party packages stay restated).
+
+def regressor_marker_loss(bm, marker_ids, x_ref, xb, betas, weight_reg_hpose=0.01):
+    """x_ref[n,67,3], xb[n,93] (axis-angle), betas[n,10] -> loss, (marker L1, hand-pose mean square)."""
+    from .smplx_lbs import smplx_forward
+    x_pred = smplx_forward(bm, xb, betas)[0][:, marker_ids]
+    loss_marker = (x_ref.to(x_pred.dtype) - x_pred).abs().mean()
+    loss_hpose = (xb[:, 69:] ** 2).mean()
+    return loss_marker + weight_reg_hpose * loss_hpose, (loss_marker, loss_hpose)
+
+
+def regressor_loss(sd, bm, marker_ids, marker_ref, betas, weight_reg_hpose=0.01, prefix=""):
+    """One loop body of GAMMARegressorTrainOP.train (:670-678): MoshRegressor.forward on the reference markers, then calc_loss."""
+    xb = nets.regressor_forward(sd, marker_ref.reshape(marker_ref.shape[0], -1), betas, prefix=prefix)
+    loss, items = regressor_marker_loss(bm, marker_ids, marker_ref, xb, betas, weight_reg_hpose)
+    return loss, items, xb

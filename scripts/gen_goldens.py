@@ -429,7 +429,118 @@ def gen_canonicalize():
     print("canonicalize_ref", {k: (np.asarray(v).shape, np.asarray(v).dtype) for k, v in outs[0].items()})
 
 
+def gen_regressor_train():
+    """GAMMARegressorTrainOP.calc_loss (+ MoshRegressor.forward and backward) and the batcher methods
+    next_sequence / next_batch_genderselection of the reference -> regressor_train_ref.npz.
+
+    Absent third-party pieces, substituted as in gen_canonicalize: `self.bm` is the adapter around oracle/smplx_lbs.py on
+    the synthetic full-size model, `torchgeometry.rotation_matrix_to_angle_axis` is oracle/rot.py's restatement.  The fixture
+    therefore pins the CLASS's arithmetic (recurrence, 6D tail, which vertices, L1 + hand regulariser, the batcher's slicing
+    and stacking), not smplx / torchgeometry."""
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from egogen_amd import synth
+    from egogen_amd.train_predictor import write_canonicalized_primitive
+    from oracle.rot import tgm_rotation_matrix_to_angle_axis
+    from oracle.smplx_lbs import BodyModel, smplx_forward
+    install_stubs()
+    install_env_stubs()
+    sys.modules["torchgeometry"].rotation_matrix_to_angle_axis = lambda m: tgm_rotation_matrix_to_angle_axis(m[:, :3, :3])
+    sys.path.insert(0, REF)
+    from models import models_GAMMA_primitive as mgp
+    bm = BodyModel(synth.make_body_model(0))
+    marker_ids = [int(v) for v in synth.marker_ids()]
+
+    class _Out:
+        pass
+
+    def fake_bm(return_verts=True, transl=None, global_orient=None, body_pose=None, left_hand_pose=None, right_hand_pose=None,
+                betas=None, **kw):
+        xb = torch.cat([transl, global_orient, body_pose, left_hand_pose, right_hand_pose], -1)
+        o = _Out()
+        o.vertices, o.joints = smplx_forward(bm, xb, betas)
+        return o
+    mcfg = {"body_repr": "ssm2_67", "h_dim": 128, "n_blocks": 10, "n_recur": 3, "actfun": "relu", "use_cont": True, "gender": "male",
+            "seq_len": 10}
+    g = torch.Generator().manual_seed(410)
+    n = 24
+    with tempfile.TemporaryDirectory() as td:
+        op = mgp.GAMMARegressorTrainOP(mcfg, {"weight_reg_hpose": 0.01}, {"log_dir": td, "save_dir": td, "batch_size": 4})
+        op.model = mgp.MoshRegressor(mcfg)
+        op.model.markers = op.markers = marker_ids
+        op.bm = fake_bm
+        shapes = fill_module(op.model, seed=411, gain=0.6)
+        # reference markers: bodies posed by random parameters, plus a little noise
+        xb_gt = torch.zeros(n, 93)
+        xb_gt[:, :3] = torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0.0, 0.0, 0.9])
+        xb_gt[:, 3:69] = torch.randn(n, 66, generator=g) * 0.25
+        xb_gt[:, 69:] = torch.randn(n, 24, generator=g) * 0.3
+        betas = torch.randn(n, 10, generator=g) * 0.7
+        with torch.no_grad():
+            marker_ref = smplx_forward(bm, xb_gt, betas)[0][:, marker_ids] + torch.randn(n, 67, 3, generator=g) * 0.01
+        op.model.zero_grad()
+        xb_new = op.model(marker_ref.detach(), betas)
+        loss, items = op.calc_loss(marker_ref, xb_new, betas)
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in op.model.named_parameters()}
+        # calc_loss alone, with the gradient with respect to the body parameters
+        xb_in = (xb_gt + torch.randn(n, 93, generator=g) * 0.05).requires_grad_(True)
+        loss_b, items_b = op.calc_loss(marker_ref, xb_in, betas)
+        loss_b.backward()
+    out = {"fill_seed": np.int64(411), "fill_gain": np.float64(0.6), "state_dict_keys": np.array(list(shapes.keys())),
+           "state_dict_shapes": np.array([str(v) for v in shapes.values()]), "body_model_seed": np.int64(0),
+           "marker_ref": marker_ref.numpy(), "betas": betas.numpy(), "xb_new": xb_new.detach().numpy(),
+           "loss": np.float64(loss.item()), "loss_items": np.asarray(items, np.float64),
+           "grad_keys": np.array(list(grads.keys())), "grad_norm": np.array([float(v.norm()) for v in grads.values()]),
+           "grad_head": np.stack([np.resize(v.flatten()[:8].numpy(), 8) for v in grads.values()]),
+           "xb_in": xb_in.detach().numpy(), "loss_b": np.float64(loss_b.item()), "loss_b_items": np.asarray(items_b, np.float64),
+           "dloss_dxb": xb_in.grad.numpy()}
+    # ---- batcher: five primitive files (mixed gender), read by the reference's two per-file methods
+    cwd = os.getcwd()
+    os.chdir(REF)                                   # the module opens data/CMU.json and data/SSM2.json relative to motion/
+    try:
+        from exp_GAMMAPrimitive.utils import batch_gen_amass as bga
+    finally:
+        os.chdir(cwd)
+    rng = np.random.default_rng(412)
+    T = 12
+    recs = []
+    for i, gender in enumerate(["male", "female", "male", "male", "female"]):
+        recs.append(dict(trans=rng.normal(0, 0.3, (T, 3)), poses=rng.normal(0, 0.2, (T, 156)), betas=rng.normal(0, 0.5, 16), gender=gender,
+                         marker_ssm2_67=rng.normal(0, 0.4, (T, 67, 3)), marker_cmu_41=rng.normal(0, 0.4, (T, 41, 3)),
+                         joints=np.cumsum(rng.normal(0, 0.05, (T, 22, 3)), 0), transf_rotmat=np.linalg.qr(rng.normal(size=(3, 3)))[0],
+                         transf_transl=rng.normal(0, 1, (1, 3))))
+    for k in ("trans", "poses", "betas", "marker_ssm2_67", "marker_cmu_41", "joints", "transf_rotmat", "transf_transl"):
+        out["rec_" + k] = np.stack([r[k] for r in recs])
+    out["rec_gender"] = np.array([r["gender"] for r in recs])
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "set"))
+        files = []
+        for i, r in enumerate(recs):
+            f = os.path.join(td, "set", f"subseq_{i:05d}.npz")
+            write_canonicalized_primitive(f, **r)
+            files.append(f)
+        for repr_ in ("ssm2_67", "ssm2_67_marker2tarloc", "smpl_params", "bone_transform"):
+            b = object.__new__(bga.BatchGeneratorAMASSCanonicalized)   # the constructor builds two CUDA body models
+            b.rec_list, b.index_rec, b.sample_rate, b.body_repr, b.read_to_ram, b.data_list = list(files), 0, 3, repr_, False, []
+            seq = b.next_sequence()
+            for k, v in seq.items():
+                out[f"seq_{repr_}_{k}"] = np.asarray(v)
+            b.index_rec = 0
+            with cuda_to_cpu():
+                batch = b.next_batch_genderselection(2, "male")
+                again = b.next_batch_genderselection(2, "male")          # only one male record left
+            assert again is None
+            for name, v in zip(("betas", "feature", "transl", "glorot", "thetas", "jts"), batch):
+                out[f"batch_{repr_}_{name}"] = v.numpy()
+            out[f"batch_{repr_}_index_after"] = np.int64(b.index_rec)
+    np.savez_compressed(os.path.join(OUT, "regressor_train_ref.npz"), **out)
+    print("regressor_train_ref", items, items_b, os.path.getsize(os.path.join(OUT, "regressor_train_ref.npz")))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["canonicalize"]:
         sys.exit(gen_canonicalize())
+    if sys.argv[1:] == ["regressor_train"]:
+        sys.exit(gen_regressor_train())
     main()

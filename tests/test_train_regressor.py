@@ -1,0 +1,201 @@
+"""Body-regressor training: `GAMMARegressorTrainOP` and the per-file batcher methods against the golden the
+reference's own classes produced (scripts/gen_goldens.py regressor_train) and against the oracle's autograd.
+
+CPU part: the oracle restatement and the host-side pieces that are plain torch / numpy (marker-restricted body model, the 6D
+tail, the batcher).  GPU part: the train operator itself (network through the HIP-backed autograd nodes)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_golden, max_abs, rebuild_state_dict
+
+MCFG = {"body_repr": "ssm2_67", "h_dim": 128, "n_blocks": 10, "n_recur": 3, "actfun": "relu", "use_cont": True, "gender": "male",
+        "seq_len": 10}
+REPRS = ("ssm2_67", "ssm2_67_marker2tarloc", "smpl_params", "bone_transform")
+
+
+def _body(g):
+    from egogen_amd import synth
+    return synth.make_body_model(int(g["body_model_seed"])), [int(v) for v in synth.marker_ids()]
+
+
+def test_oracle_regressor_loss_matches_reference_class():
+    from oracle import train as otrain
+    from oracle.smplx_lbs import BodyModel
+    g = load_golden("regressor_train_ref.npz")
+    bmd, mids = _body(g)
+    bm = BodyModel(bmd)
+    sd = rebuild_state_dict(g, [int(g["fill_seed"])], [""], gains=[float(g["fill_gain"])])
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    keys = [str(k) for k in g["grad_keys"]]
+    loss, items, xb = otrain.regressor_loss(sd, bm, mids, torch.from_numpy(g["marker_ref"]), torch.from_numpy(g["betas"]))
+    assert max_abs(xb.detach(), g["xb_new"]) < 2e-5
+    np.testing.assert_allclose([float(v) for v in items], g["loss_items"], rtol=2e-6)
+    grads = torch.autograd.grad(loss, [sd[k] for k in keys])
+    for k, gr, n, hd in zip(keys, grads, g["grad_norm"], g["grad_head"]):
+        assert abs(float(gr.norm()) - n) <= 5e-5 * max(n, 1e-6) + 1e-9, k
+        assert max_abs(np.resize(gr.flatten()[:8].numpy(), 8), hd) <= 5e-5 * max(float(np.abs(hd).max()), 1e-4), k
+    xb_in = torch.from_numpy(g["xb_in"]).requires_grad_(True)
+    loss_b, items_b = otrain.regressor_marker_loss(bm, mids, torch.from_numpy(g["marker_ref"]), xb_in, torch.from_numpy(g["betas"]))
+    np.testing.assert_allclose([float(v) for v in items_b], g["loss_b_items"], rtol=2e-6)
+    assert max_abs(torch.autograd.grad(loss_b, xb_in)[0], g["dloss_dxb"]) < 1e-7
+
+
+def test_marker_body_model_loss_and_pose_gradient_match_reference_class():
+    """calc_loss arithmetic of the product (SMPL-X on the 67 marker rows only) on the CPU: value and d loss / d xb."""
+    from egogen_amd.train_regressor import MarkerBodyModel
+    g = load_golden("regressor_train_ref.npz")
+    bmd, mids = _body(g)
+    mbm = MarkerBodyModel(bmd, mids)
+    xb = torch.from_numpy(g["xb_in"]).requires_grad_(True)
+    x_ref, betas = torch.from_numpy(g["marker_ref"]), torch.from_numpy(g["betas"])
+    x_pred = mbm(xb, betas)
+    lm = torch.nn.functional.l1_loss(x_ref, x_pred)
+    lh = torch.mean(xb[:, 69:] ** 2)
+    np.testing.assert_allclose([float(lm), float(lh)], g["loss_b_items"], rtol=5e-6)
+    (lm + 0.01 * lh).backward()
+    assert max_abs(xb.grad, g["dloss_dxb"]) < 2e-7
+    # and in float64 the restricted model IS the full model's rows
+    from oracle.smplx_lbs import BodyModel, smplx_forward
+    full = smplx_forward(BodyModel(bmd, torch.float64), xb.detach().double(), betas.double())[0][:, mids]
+    assert max_abs(mbm.double()(xb.detach().double(), betas.double()), full) < 1e-6   # model buffers are fp32-rounded folds
+
+
+def test_cont6d_tail_matches_oracle_and_is_differentiable():
+    from egogen_amd.train_regressor import cont6d_params_to_aa
+    from oracle.nets import cont2aa
+    g = torch.Generator().manual_seed(3)
+    xb6 = torch.randn(40, 159, generator=g, dtype=torch.float64)
+    xb6[0, 3:9] = torch.tensor([1.0, 0, 0, 1.0, 0, 0], dtype=torch.float64)                    # identity
+    xb6[1, 3:9] = torch.tensor([-1.0, 0, 0, -1.0, 0, 0], dtype=torch.float64) + 1e-3          # near a half turn: w < 0 branches
+    got = cont6d_params_to_aa(xb6)
+    ref = torch.cat([xb6[:, :3], cont2aa(xb6[:, 3:135].reshape(40, 22, 6)).reshape(40, 66), xb6[:, 135:]], -1)
+    assert max_abs(got, ref) < 1e-12
+    x = xb6[2:].clone().requires_grad_(True)
+    torch.autograd.gradcheck(lambda t: cont6d_params_to_aa(t)[:, :12], (x[:3],), eps=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("body_repr", REPRS)
+def test_per_file_batcher_methods_match_reference(tmp_path, body_repr):
+    from egogen_amd.train_predictor import write_canonicalized_primitive
+    from egogen_amd.train_regressor import BatchGeneratorAMASSCanonicalized
+    g = load_golden("regressor_train_ref.npz")
+    root = tmp_path / "set"
+    os.makedirs(root)
+    files = []
+    for i in range(len(g["rec_gender"])):
+        f = str(root / f"subseq_{i:05d}.npz")
+        write_canonicalized_primitive(f, **{k: g["rec_" + k][i] for k in ("trans", "poses", "betas", "marker_ssm2_67", "marker_cmu_41",
+                                                                        "joints", "transf_rotmat", "transf_transl")},
+                                      gender=str(g["rec_gender"][i]))
+        files.append(f)
+    b = BatchGeneratorAMASSCanonicalized(str(tmp_path), ["set"], sample_rate=3, body_repr=body_repr, device="cpu")
+    b.get_rec_list(shuffle_seed=0)
+    assert sorted(b.rec_list) == files
+    b.rec_list = list(files)
+    seq = b.next_sequence()
+    assert b.index_rec == 1
+    for k, v in seq.items():
+        ref = g[f"seq_{body_repr}_{k}"]
+        assert np.array_equal(np.asarray(v), ref), k
+    b.index_rec = 0
+    batch = b.next_batch_genderselection(2, "male")
+    for name, v in zip(("betas", "feature", "transl", "glorot", "thetas", "jts"), batch):
+        ref = g[f"batch_{body_repr}_{name}"]
+        assert v.dtype == torch.float32 and tuple(v.shape) == ref.shape and np.array_equal(v.numpy(), ref), name
+    assert b.index_rec == 3                                          # male, (female skipped), male
+    assert b.next_batch_genderselection(2, "male") is None          # one male record left: the list is consumed
+    assert b.index_rec == int(g[f"batch_{body_repr}_index_after"])
+    b.reset()
+    assert b.index_rec == 0 and b.has_next_rec()
+    t_first = b.next_batch_genderselection(1, "female", batch_first=False)
+    assert t_first[1].shape[1] == 1
+
+
+def test_batcher_rejects_unknown_representation(tmp_path):
+    from egogen_amd.train_regressor import BatchGeneratorAMASSCanonicalized
+    with pytest.raises(NameError):
+        BatchGeneratorAMASSCanonicalized(str(tmp_path), body_repr="keypoints")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_train_op_loss_and_gradients_match_reference_golden_and_oracle(tmp_path):
+    from egogen_amd.train_regressor import GAMMARegressorTrainOP
+    from oracle import train as otrain
+    from oracle.smplx_lbs import BodyModel
+    g = load_golden("regressor_train_ref.npz")
+    bmd, mids = _body(g)
+    op = GAMMARegressorTrainOP(MCFG, {"weight_reg_hpose": 0.01}, {"log_dir": str(tmp_path / "logs"), "save_dir": str(tmp_path / "ckpt"),
+                                                                  "batch_size": 4})
+    op.build_model(bmd, mids)
+    sd = rebuild_state_dict(g, [int(g["fill_seed"])], [""], gains=[float(g["fill_gain"])])
+    op.model.load_state_dict(sd)
+    op.grads.attach()
+    x_ref, betas = torch.from_numpy(g["marker_ref"]).cuda(), torch.from_numpy(g["betas"]).cuda()
+    xb = op.model(x_ref, betas)
+    assert max_abs(xb.detach().cpu(), g["xb_new"]) < 2e-4                                   # fp32 device GEMMs vs the reference on the CPU
+    op.grads.zero()
+    loss, items = op.calc_loss(x_ref, xb, betas)
+    np.testing.assert_allclose(items, g["loss_items"], rtol=5e-5)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=5e-5)
+    loss.backward()
+    keys = [str(k) for k in g["grad_keys"]]
+    params = dict(op.model.named_parameters())
+    osd = {k: v.clone().double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    oloss, _, _ = otrain.regressor_loss(osd, BodyModel(bmd, torch.float64), mids, torch.from_numpy(g["marker_ref"]).double(),
+                                        torch.from_numpy(g["betas"]).double())
+    ograds = torch.autograd.grad(oloss, [osd[k] for k in keys])
+    gmax = max(float(o.abs().max()) for o in ograds)
+    for k, og, n in zip(keys, ograds, g["grad_norm"]):
+        got = params[k].grad.detach().cpu().double()
+        rel = float((got - og).norm() / og.norm().clamp_min(1e-3 * gmax))
+        assert rel <= 2e-3, (k, rel)                                   # ReLU kinks may flip for single rows between two fp32 evaluations
+        assert abs(float(got.norm()) - n) <= 2e-3 * max(n, 1e-6) + 1e-8, k                   # vs the reference's own backward
+    # calc_loss alone with the gradient in the body parameters
+    xb_in = torch.from_numpy(g["xb_in"]).cuda().requires_grad_(True)
+    loss_b, items_b = op.calc_loss(x_ref, xb_in, betas)
+    np.testing.assert_allclose(items_b, g["loss_b_items"], rtol=2e-5)
+    loss_b.backward()
+    assert max_abs(xb_in.grad.cpu(), g["dloss_dxb"]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_training_loop_fits_markers_and_writes_reference_checkpoint(tmp_path):
+    """A few epochs on primitives whose markers come from the body model itself: the marker loss goes down and epoch-N.ckp
+    loads into the rollout's regressor (the key set GAMMAPrimitiveComboGenOP.build_model reads)."""
+    from egogen_amd import synth
+    from egogen_amd.models import MoshRegressor
+    from egogen_amd.train_predictor import write_canonicalized_primitive
+    from egogen_amd.train_regressor import BatchGeneratorAMASSCanonicalized, GAMMARegressorTrainOP, MarkerBodyModel
+    bmd, mids = synth.make_body_model(0), [int(v) for v in synth.marker_ids()]
+    mbm = MarkerBodyModel(bmd, mids)
+    rng = np.random.default_rng(1)
+    root = tmp_path / "data" / "locomotion"
+    os.makedirs(root)
+    T = 10
+    for i in range(16):
+        xb = np.zeros((T, 93), np.float32)
+        xb[:, :3] = rng.normal(0, 0.05, (1, 3)) + np.cumsum(rng.normal(0, 0.01, (T, 3)), 0)
+        xb[:, 3:69] = rng.normal(0, 0.1, (1, 66)) + np.cumsum(rng.normal(0, 0.01, (T, 66)), 0)
+        betas = rng.normal(0, 0.5, 16)
+        with torch.no_grad():
+            mk = mbm(torch.from_numpy(xb), torch.from_numpy(np.tile(betas[:10], (T, 1)).astype(np.float32))).numpy()
+        poses = np.zeros((T, 156))
+        poses[:, :66] = xb[:, 3:69]
+        write_canonicalized_primitive(str(root / f"subseq_{i:05d}.npz"), trans=xb[:, :3], poses=poses, betas=betas,
+                                      gender="male" if i % 4 else "female", marker_ssm2_67=mk, joints=rng.normal(0, 0.3, (T, 22, 3)))
+    gen = BatchGeneratorAMASSCanonicalized(str(tmp_path / "data"), ["locomotion"], sample_rate=1, body_repr="ssm2_67")
+    gen.get_rec_list(shuffle_seed=0)
+    torch.manual_seed(0)
+    op = GAMMARegressorTrainOP(MCFG, {"weight_reg_hpose": 0.01},
+                               {"log_dir": str(tmp_path / "logs"), "save_dir": str(tmp_path / "ckpt"), "batch_size": 4, "num_epochs": 12,
+                                "num_epochs_fix": 6, "learning_rate": 1e-3, "saving_per_X_ep": 6, "resume_training": False})
+    op.build_model(bmd, mids)
+    hist = op.train(gen)
+    assert len(hist) == 12 and hist[-1][0] < 0.6 * hist[0][0], [h[0] for h in hist]
+    ck = torch.load(str(tmp_path / "ckpt" / "epoch-12.ckp"), map_location="cpu")
+    assert set(ck.keys()) == {"epoch", "model_state_dict", "optimizer_state_dict"} and ck["epoch"] == 12
+    MoshRegressor(MCFG).load_state_dict(ck["model_state_dict"])             # strict: the reference's key set
