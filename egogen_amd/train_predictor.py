@@ -94,43 +94,36 @@ class GAMMAPrimitiveVAETrainOP:
         return loss, torch.stack([loss.detach(), loss_rec.detach(), loss_kld.detach()]).cpu().numpy()
 
     def calc_loss_rollout(self, data, epoch, eps_list: Optional[List[torch.Tensor]] = None):
+        """Loss over consecutive 20-frame primitives of one long sequence (:435-505).  Primitive k covers frames
+        [k t_pred, k t_pred + 20) and lives in the frame of its own first body; from the second primitive on, the motion seed
+        is the model's reconstruction of the previous one, carried over between the two frames.  All canonical frames come from
+        one kernel launch on the stacked first-frame joints; the loss is the mean over primitives."""
         ref_markers, ref_jts = data
         n_t, n_b = ref_markers.shape[:2]
-        ref_jts = ref_jts.contiguous().view(n_t, n_b, -1, 3)
-        t, loss, loss_info = 0, [], []
-        Y_rec = R_prev = T_prev = None
-        while t < n_t:
-            t_lb, t_ub = t, t + 20
-            if t_ub >= n_t:
-                break
-            t_his = self.t_his
-            t_pred = 20 - t_his
-            ref_markers_, ref_jts_ = ref_markers[t_lb:t_ub], ref_jts[t_lb:t_ub]
-            if t == 0:  # only the first primitive starts from ground-truth markers
-                X = ref_markers_[:t_his].detach()
-                Y = ref_markers_[t_his:, :, :self.model.in_dim].detach()
-                R_prev, T_prev = canonical_frame(ref_jts_[0])
+        t_his = self.t_his
+        t_pred = 20 - t_his
+        starts = [s for s in range(0, n_t, t_pred) if s + 20 < n_t][:self.max_rollout]
+        joints0 = ref_jts.reshape(n_t, n_b, -1, 3)[starts]                                   # [K,b,J,3]
+        R_all, T_all = canonical_frame(joints0.reshape(len(starts) * n_b, -1, 3))
+        R_all, T_all = R_all.view(len(starts), n_b, 3, 3), T_all.view(len(starts), n_b, 1, 3)
+        into = lambda x, R, T: torch.einsum("bji,tbpj->tbpi", R, x - T.unsqueeze(0))           # world -> frame (R^T (x - T))
+        out_of = lambda x, R, T: torch.einsum("bij,tbpj->tbpi", R, x) + T.unsqueeze(0)          # frame -> world
+        losses, infos, Y_rec = [], [], None
+        for k, s in enumerate(starts):
+            window = ref_markers[s:s + 20, :, :self.model.in_dim]
+            if k == 0:                                                    # the data is already in the frame of frame 0
+                X, Y = window[:t_his], window[t_his:]
             else:
-                R_curr, T_curr = canonical_frame(ref_jts_[0])
-                Yg = ref_markers_[t_his:, :, :self.model.in_dim].reshape(t_pred, n_b, -1, 3)
-                Y = torch.einsum("bij,tbpj->tbpi", R_curr.permute(0, 2, 1), Yg - T_curr.unsqueeze(0))
-                X_prev = Y_rec[-t_his:].reshape(t_his, n_b, -1, 3)
-                Xg = torch.einsum("bij,tbpj->tbpi", R_prev, X_prev) + T_prev.unsqueeze(0)
-                X = torch.einsum("bij,tbpj->tbpi", R_curr.permute(0, 2, 1), Xg - T_curr.unsqueeze(0))
-                Y = Y.contiguous().view(t_pred, n_b, -1).detach()
-                X = X.contiguous().view(t_his, n_b, -1).detach()
-                R_prev, T_prev = R_curr, T_curr
-            Y_rec, mu, logvar = self.model.forward_train(X, Y, None if eps_list is None else eps_list[len(loss)])
-            loss_rec = self._calc_loss_rec(Y, Y_rec)
-            loss_kld, weight_kld = self._kld(mu, logvar, epoch)
-            loss_ = loss_rec + weight_kld * loss_kld
-            loss.append(loss_)
-            loss_info.append(torch.stack([loss_.detach(), loss_rec.detach(), loss_kld.detach()]))
-            t += t_pred
-            if len(loss) >= self.max_rollout:
-                break
-        loss = torch.stack(loss).mean()
-        return loss, torch.stack(loss_info).mean(0).cpu().numpy()
+                Y = into(window[t_his:].reshape(t_pred, n_b, -1, 3), R_all[k], T_all[k]).reshape(t_pred, n_b, -1)
+                seed_world = out_of(Y_rec[-t_his:].reshape(t_his, n_b, -1, 3), R_all[k - 1], T_all[k - 1])
+                X = into(seed_world, R_all[k], T_all[k]).reshape(t_his, n_b, -1)
+            X, Y = X.detach().contiguous(), Y.detach().contiguous()
+            Y_rec, mu, logvar = self.model.forward_train(X, Y, None if eps_list is None else eps_list[k])
+            rec = self._calc_loss_rec(Y, Y_rec)
+            kld, w_kld = self._kld(mu, logvar, epoch)
+            losses.append(rec + w_kld * kld)
+            infos.append(torch.stack([losses[-1].detach(), rec.detach(), kld.detach()]))
+        return torch.stack(losses).mean(), torch.stack(infos).mean(0).cpu().numpy()
 
     def step(self, optimizer, loss):
         """loss.backward() + optimizer.step() around the flat gradient buffer (:541-553)."""

@@ -4,7 +4,7 @@
 #   gpurun --timeout 4500 -- 'bash scripts/run_final_checks.sh'
 set -u
 mkdir -p gpurun_out/final
-timeout 2400 python -m pytest tests -x -q -m gpu < /dev/null > gpurun_out/final/gpu_tests.log 2>&1
+EGX_DRIFT_TABLE=gpurun_out/final/drift_table.txt timeout 2400 python -m pytest tests -x -q -m gpu < /dev/null > gpurun_out/final/gpu_tests.log 2>&1
 echo "gpu tests rc=$?"; tail -4 gpurun_out/final/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" < /dev/null > gpurun_out/final/smoke.log 2>&1
 echo "smoke rc=$?"; tail -2 gpurun_out/final/smoke.log

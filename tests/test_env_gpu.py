@@ -1,5 +1,7 @@
 """GPU parity of the batched CrowdEnv (reset + step, SDF and box scenes) against the CPU oracle,
 through the C ABI.  Tolerance: north_star's 1e-4 relative fp32 (absolute floor stated per quantity)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -355,13 +357,16 @@ def test_episode_without_resync_reports_drift():
         scale = max(1.0, float(L["joints"].abs().max()))
         if it < 3:
             assert gpu_mk <= 1e-4 * scale and gpu_jt <= 1e-4 * scale, (it, gpu_mk, gpu_jt)
-        assert gpu_mk <= 8 * ref_mk + 1e-5 * scale, (it, gpu_mk, ref_mk)
-        assert gpu_jt <= 8 * ref_jt + 1e-5 * scale, (it, gpu_jt, ref_jt)
+        assert gpu_mk <= 3 * ref_mk + 1e-5 * scale, (it, gpu_mk, ref_mk)
+        assert gpu_jt <= 3 * ref_jt + 1e-5 * scale, (it, gpu_jt, ref_jt)
         if gpu_jt < 1e-3:   # while the trajectories still coincide, the discrete outcomes do as well
             assert term.cpu().bool().tolist() == oterm.tolist(), f"termination differs at step {it}"
-    print("\nstep  |dY| gpu-o32  o32-o64   |dJ| gpu-o32  o32-o64   |dreward|  max|dcount|  near-zero")
-    for r in rows:
-        print("%4d  %.2e     %.2e  %.2e     %.2e  %.2e  %6d  %6d" % r)
+    lines = ["step  |dY| gpu-o32  o32-o64   |dJ| gpu-o32  o32-o64   |dreward|  max|dcount|  near-zero"]
+    lines += ["%4d  %.2e     %.2e  %.2e     %.2e  %.2e  %6d  %6d" % r for r in rows]
+    print("\n" + "\n".join(lines))
+    if os.environ.get("EGX_DRIFT_TABLE"):     # kept under profiles/ (scripts/run_final_checks.sh)
+        with open(os.environ["EGX_DRIFT_TABLE"], "w") as fh:
+            fh.write("\n".join(lines) + "\n")
 
 
 @pytest.mark.parametrize("static_scene", [True, False])
