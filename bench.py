@@ -452,7 +452,7 @@ def main():
     # applies only to the configuration that pass was taken on
     traffic = None
     try:
-        for name in (f"r02_lbs_pmc_mode{blend}.json",):
+        for name in (f"r03_lbs_pmc_mode{blend}.json", f"r02_lbs_pmc_mode{blend}.json"):   # newest round first
             f = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(f):
                 continue

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/${1:-pmc_lbs}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
-SETS=${PMC_SETS:-"FETCH_SIZE,WRITE_SIZE TCC_HIT_sum,TCC_MISS_sum GRBM_GUI_ACTIVE,SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES,SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VMEM_RD,SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES,SQ_WAIT_INST_ANY"}
+SETS=${PMC_SETS:-"FETCH_SIZE WRITE_SIZE TCC_HIT_sum,TCC_MISS_sum GRBM_GUI_ACTIVE,SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES,SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VMEM_RD,SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES,SQ_WAIT_INST_ANY"}
 for cs in $SETS; do
   set=${cs//,/ }
   i=$((i+1))
