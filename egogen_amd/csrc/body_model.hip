@@ -813,24 +813,27 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
   w.lds = nullptr;
   w.qn = 0;
   w.s_cnt[lane] = 0;
-  // Work partition over the XCDs (blocks are dealt to them round-robin).  With >= 8 body groups every XCD owns a chunk of
-  // body groups and all vertex tiles: its bodies' features / transforms stay in its L2 and the bases stream through once per
-  // block of groups.  With fewer groups (an 8-way agent split leaves 64 agents = 5 groups per GPU) every XCD owns a chunk of
-  // VERTEX TILES and all groups instead: it streams an eighth of the bases once, and the few bodies' features fit any L2.
+  // Work partition over the XCDs (blocks are dealt to them round-robin).  Either every XCD owns a chunk of BODY GROUPS and
+  // all vertex tiles (its bodies' features / transforms stay in its L2 and the bases stream through once per block of groups)
+  // or a chunk of VERTEX TILES and all groups (it streams an eighth of the bases once per block; every XCD reads all
+  // features).  The bases traffic is the same either way; what differs is the balance: 20 groups (256 agents) deal 3 / 2 over
+  // the XCDs, 10 groups (128) deal 2 / 1, 5 groups (64 agents, the 8-way split) leave three XCDs idle - so the partition with
+  // the shorter per-workgroup item count is taken, body groups on a tie (less feature traffic).
   int bg_lo, nper, n_streams, stream, vt_lo = 0, nvt = p.n_tiles;
-  if ((gridDim.x & 7) == 0 && p.nbg >= 8) {
-    const int per = (p.nbg + 7) / 8, xcd = blockIdx.x & 7;
-    bg_lo = xcd * per;
-    nper = max(0, min(per, p.nbg - bg_lo));
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7;
     n_streams = gridDim.x >> 3;
     stream = blockIdx.x >> 3;
-  } else if ((gridDim.x & 7) == 0 && p.n_tiles >= 8) {
-    const int per = (p.n_tiles + 7) / 8, xcd = blockIdx.x & 7;
-    vt_lo = xcd * per;
-    nvt = max(0, min(per, p.n_tiles - vt_lo));
-    bg_lo = 0; nper = p.nbg;
-    n_streams = gridDim.x >> 3;
-    stream = blockIdx.x >> 3;
+    const int per_g = (p.nbg + 7) / 8, per_t = (p.n_tiles + 7) / 8;
+    const int span_g = (per_g * p.n_tiles + n_streams - 1) / n_streams, span_t = (per_t * p.nbg + n_streams - 1) / n_streams;
+    if (span_g <= span_t) {
+      bg_lo = xcd * per_g;
+      nper = max(0, min(per_g, p.nbg - bg_lo));
+    } else {
+      vt_lo = xcd * per_t;
+      nvt = max(0, min(per_t, p.n_tiles - vt_lo));
+      bg_lo = 0; nper = p.nbg;
+    }
   } else {
     bg_lo = 0; nper = p.nbg;
     n_streams = gridDim.x;

@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(os.path.join(R, f"{RND}_final_bench_kernel_stats
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 cat, calls = collections.Counter(), collections.Counter()
 for r in rows:
-    n = r["Name"]
+    n = r["Name"].replace("(anonymous namespace)::", "")
     if n.startswith("Cijk"): k = "library GEMMs (Cijk_*: hipBLASLt / rocBLAS Tensile kernels)"
     elif "egx_" in n: k = n.split("(")[0].replace("void ", "")[:48]
     elif "at::native" in n: k = "torch " + n.split("at::native::")[1].split("<")[0][:40]
@@ -34,12 +34,16 @@ def avg_us(sub):
 n_flat = 13_168_001 + 28 * 32          # parameters + alignment padding of the flat buffers (upper bound of the padding)
 adam_bytes = 7 * 4 * n_flat            # read p, g, m, v; write p, m, v
 reg_flop = 2.0 * 9216 * 3 * (370 * 128 + 20 * 128 * 128 + 128 * 159)
+reg3 = any("egx_regressor3" in x["Name"] for x in rows)
+reg_name = "egx_regressor3" if reg3 else "egx_regressor_fused"
+reg_bound = ("bf16 MFMA, six partial products per fp32 product: 416.7 TFLOP/s fp32-equivalent ceiling / LDS + L2 weight stream" if reg3
+             else "fp32 MFMA 157.3 / L2 weight stream (64 KB per layer and workgroup)")
 extra = ["", "| kernel | work per launch | avg us | rate | bound |", "|---|---|---|---|---|",
          f"| `egx_adamw_flat_kernel` | {adam_bytes/1e6:.0f} MB (p, g, m, v in; p, m, v out) | {avg_us('egx_adamw_flat'):.1f} | {adam_bytes/avg_us('egx_adamw_flat')/1e6:.2f} TB/s | HBM (8 TB/s peak, ~6.3 achievable) |",
-         f"| `egx_regressor_fused_kernel` | {reg_flop/1e9:.1f} GFLOP (9216 rows x 66 layers) | {avg_us('egx_regressor_fused'):.1f} | {reg_flop/avg_us('egx_regressor_fused')/1e6:.1f} TFLOP/s | fp32 MFMA 157.3 / L2 weight stream (64 KB per layer and workgroup) |"]
+         f"| `{reg_name}_kernel` | {reg_flop/1e9:.1f} GFLOP fp32-equivalent (9216 rows x 66 layers) | {avg_us(reg_name):.1f} | {reg_flop/avg_us(reg_name)/1e6:.1f} TFLOP/s | {reg_bound} |"]
 egx = sum(v for k, v in cat.items() if "egx_" in k)
 L += extra
-L += ["", f"hand-written kernels (`egx_*`): {egx/tot*100:.1f} % of GPU time; summed kernel time {tot/ncyc/1e6:.2f} ms per cycle (the update's actor / critic and encoder branches run concurrently, so the sum exceeds the wall time).",
-      f"PMC passes of the LBS kernel: `{RND}_lbs_pmc_mode*.json`; experiments of the round: `{RND}_lbs_experiments.md`; micro-benchmarks: `r01_ubench.md`."]
+L += ["", f"hand-written kernels (`egx_*`): {egx/tot*100:.1f} % of GPU time; summed kernel time {tot/ncyc/1e6:.2f} ms per cycle (one stream: the sum is the GPU-busy part of the wall time).",
+      f"PMC passes of the LBS kernel: `{RND}_lbs_pmc_mode*.json`; experiments of the round: " + ", ".join(f"`{f}`" for f in sorted(os.listdir(R)) if f.startswith(RND) and f.endswith(".md") and "final" not in f) + "; micro-benchmarks: `r01_ubench.md`."]
 open(os.path.join(R, f"{RND}_final_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L[5:9]))
