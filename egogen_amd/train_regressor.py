@@ -168,7 +168,10 @@ class MoshRegressorTrain(MoshRegressor):
             h = linear_act(torch.cat([xr, xb, betas], dim=-1), net.in_fc)
             for blk in net.layers:
                 h = res_mlp(h, blk.layers[0], blk.layers[1], act="relu")
-            xb = linear_act(h, net.out_fc, res=xb)
+            if (n * self.body_dim) % 4 == 0:      # the fused residual pass works on float4s
+                xb = linear_act(h, net.out_fc, res=xb)
+            else:
+                xb = linear_act(h, net.out_fc) + xb
         return cont6d_params_to_aa(xb)
 
 

@@ -199,3 +199,32 @@ def test_training_loop_fits_markers_and_writes_reference_checkpoint(tmp_path):
     ck = torch.load(str(tmp_path / "ckpt" / "epoch-12.ckp"), map_location="cpu")
     assert set(ck.keys()) == {"epoch", "model_state_dict", "optimizer_state_dict"} and ck["epoch"] == 12
     MoshRegressor(MCFG).load_state_dict(ck["model_state_dict"])             # strict: the reference's key set
+
+
+@pytest.mark.gpu
+def test_regressor_training_driver_runs_from_a_yaml(tmp_path):
+    """exp_GAMMAPrimitive/train_GAMMARegressor.py on a config in the reference's yaml layout (crowd_ppo/cfg_samp20/MoshRegressor_v3_male.yml)."""
+    import subprocess
+    import sys
+    import yaml
+    from egogen_amd.train_predictor import write_canonicalized_primitive
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(5)
+    data = tmp_path / "data" / "CMU"
+    os.makedirs(data)
+    for i in range(6):
+        write_canonicalized_primitive(str(data / f"subseq_{i:05d}.npz"), trans=rng.normal(0, 0.1, (9, 3)), poses=rng.normal(0, 0.1, (9, 156)),
+                                      betas=rng.normal(0, 0.5, 16), gender="male", marker_ssm2_67=rng.normal(0, 0.4, (9, 67, 3)),
+                                      joints=rng.normal(0, 0.3, (9, 22, 3)))
+    os.makedirs(tmp_path / "crowd_ppo" / "cfg_samp20")
+    cfg = {"modelconfig": dict(MCFG, seq_len=3), "lossconfig": {"weight_rec": 1.0, "weight_reg_hpose": 0.01},
+           "trainconfig": {"learning_rate": 3e-4, "batch_size": 2, "num_epochs": 2, "num_epochs_fix": 1, "saving_per_X_ep": 2,
+                           "dataset_path": str(tmp_path / "data"), "subsets": ["CMU"]}}
+    with open(tmp_path / "crowd_ppo" / "cfg_samp20" / "MoshRegressor_v3_male.yml", "w") as fh:
+        yaml.safe_dump(cfg, fh)
+    r = subprocess.run([sys.executable, os.path.join(root, "exp_GAMMAPrimitive", "train_GAMMARegressor.py"), "--cfg", "MoshRegressor_v3_male"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "[epoch 2]" in r.stdout
+    ck = torch.load(str(tmp_path / "results" / "exp_GAMMAPrimitive" / "MoshRegressor_v3_male" / "checkpoints" / "epoch-2.ckp"), map_location="cpu")
+    assert ck["epoch"] == 2 and "pnet.in_fc.weight" in ck["model_state_dict"]
