@@ -191,6 +191,9 @@ SIGNATURES = {
     "egx_policy_train_step": (C.c_int, [C.c_void_p] * 9 + [C.c_float] * 6 + [C.c_void_p, C.c_void_p]),
     "egx_pack3_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "egx_pack3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "egx_gemm3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "egx_gemm3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                            C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egx_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
     "egx_stream_destroy": (C.c_int, [C.c_void_p]),
     "egx_vposer_workspace_bytes": (C.c_size_t, [C.c_int]),

@@ -105,6 +105,7 @@ struct D3PackJob {
   int R, K, ld, col0;
   bf16x8* dst;
   int S_total, s0;
+  int transpose;   // 1: the source block is [K rows (the reduction index), R columns]: image rows = source columns
 };
 struct D3PackJobs {
   D3PackJob j0, j1, j2, j3;
@@ -122,8 +123,13 @@ __global__ __launch_bounds__(256) void egx_pack3_kernel(D3PackJobs jobs) {
   const int rt = frag / S, s = frag % S;
   const int row = rt * 16 + (lane & 15), k0 = s * 32 + 8 * (lane >> 4);
   float x[8];
+  if (!j.transpose) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) x[e] = (row < j.R && k0 + e < j.K) ? j.src[(size_t)row * j.ld + j.col0 + k0 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) x[e] = (row < j.R && k0 + e < j.K) ? j.src[(size_t)row * j.ld + j.col0 + k0 + e] : 0.f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (row < j.R && k0 + e < j.K) ? j.src[(size_t)(k0 + e) * j.ld + j.col0 + row] : 0.f;
+  }
   bf16x8 pl[3];
   d3_split(x, pl);
   bf16x8* o = j.dst + ((size_t)rt * j.S_total + j.s0 + s) * 3 * 64 + lane;
@@ -142,9 +148,10 @@ void egx_launch_pack3(hipStream_t st, const D3Pack* jobs, int njobs) {
     if (i < njobs) {
       d.src = jobs[i].src; d.R = jobs[i].R; d.K = jobs[i].K; d.ld = jobs[i].ld; d.col0 = jobs[i].col0;
       d.dst = static_cast<bf16x8*>(jobs[i].dst); d.S_total = jobs[i].S_total; d.s0 = jobs[i].s0;
+      d.transpose = jobs[i].transpose;
       frags[i] = d3_pack_frags(d.R, d.K);
     } else {
-      d.src = nullptr; d.R = d.K = d.ld = d.col0 = d.S_total = d.s0 = 0; d.dst = nullptr;
+      d.src = nullptr; d.R = d.K = d.ld = d.col0 = d.S_total = d.s0 = d.transpose = 0; d.dst = nullptr;
     }
   }
   J.end0 = frags[0]; J.end1 = J.end0 + frags[1]; J.end2 = J.end1 + frags[2];
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
       const int row = 16 * mi + 4 * (lane >> 4) + r, m = mt * TM + row;
       const bool live = m < a.M && n < a.N;
       if (live && a.out_act) a.out_act[(size_t)m * a.ldact + n] = v;   // activation before the skip connection (saved for backward)
-      if (live && a.res) v += a.res[(size_t)(row_base + m) * a.ldr + n];
+      if (live && a.res && !(a.n_split > 0 && n >= a.n_split)) v += a.res[(size_t)(row_base + m) * a.ldr + n];
       if (live && a.n_split > 0 && n >= a.n_split) {
         // weight-gradient launch: the B operand's extra row of ones makes column n_split the bias gradient
         if (n == a.n_split && a.bias_out) a.bias_out[m] = v;
@@ -818,6 +825,37 @@ extern "C" int egx_pack3(const float* src, int num_rows, int num_cols, int src_l
   EGX_REQUIRE(dst_kstep0 >= 0 && dst_ksteps >= dst_kstep0 + S, "destination k-step range too small");
   D3Pack job{src, num_rows, num_cols, src_ld, src_col0, dst, dst_ksteps, dst_kstep0};
   egx_launch_pack3(static_cast<hipStream_t>(stream), &job, 1);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+// ---- one product on fp32 row-major operands (training-side autograd nodes: fused_ops.py) ---------------------------------
+extern "C" size_t egx_gemm3_workspace_bytes(int M, int N, int K) { return egx_pack3_bytes(M, K) + egx_pack3_bytes(N, K); }
+
+extern "C" int egx_gemm3(const float* A, int lda, int trans_a, const float* B, int ldb, int trans_b, int M, int N, int K,
+                         const float* bias, int act, float slope, const float* res, int ldr, float* out, int ldo, float* out_act,
+                         int ldact, void* workspace, size_t workspace_bytes, void* stream) {
+  EGX_REQUIRE(A && B && out && M > 0 && N > 0 && K > 0 && workspace, "bad arguments");
+  EGX_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? N : K) && ldo >= N && (!res || ldr >= N) && (!out_act || ldact >= N),
+              "leading dimension smaller than the row");
+  EGX_REQUIRE(workspace_bytes >= egx_gemm3_workspace_bytes(M, N, K), "workspace too small (egx_gemm3_workspace_bytes)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int S = egx_ceil_div(K, 32);
+  char* ws = static_cast<char*>(workspace);
+  void* img_a = ws;
+  void* img_b = ws + egx_pack3_bytes(M, K);
+  D3Pack jobs[2];
+  jobs[0].src = A; jobs[0].R = M; jobs[0].K = K; jobs[0].ld = lda; jobs[0].col0 = 0; jobs[0].dst = img_a; jobs[0].S_total = S; jobs[0].s0 = 0;
+  jobs[0].transpose = trans_a ? 1 : 0;
+  jobs[1].src = B; jobs[1].R = N; jobs[1].K = K; jobs[1].ld = ldb; jobs[1].col0 = 0; jobs[1].dst = img_b; jobs[1].S_total = S; jobs[1].s0 = 0;
+  jobs[1].transpose = trans_b ? 1 : 0;
+  egx_launch_pack3(st, jobs, 2);
+  D3Plain p;
+  p.A = static_cast<const bf16x8*>(img_a); p.SA = S; p.sa0 = 0;
+  p.B = static_cast<const bf16x8*>(img_b); p.S = S;
+  p.bias = bias; p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo; p.M = M; p.N = N; p.act = act; p.slope = slope;
+  p.out_act = out_act; p.ldact = ldact;
+  egx_launch_dense3(st, p);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

@@ -55,6 +55,7 @@ struct D3Pack {
   int R, K, ld, col0;   // rows, columns taken, leading dimension, first column
   void* dst;
   int S_total, s0;      // k-steps per row tile of the destination buffer, k-step this image starts at
+  int transpose = 0;    // 1: src is [K rows (reduction index), R columns] - the image is that of the transposed block
 };
 void egx_launch_pack3(hipStream_t st, const D3Pack* jobs, int njobs);  // njobs <= 4, one launch
 

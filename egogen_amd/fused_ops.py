@@ -1,12 +1,58 @@
-"""Custom autograd nodes backed by libegogen_hip.so for the PPO update: GRU gate math (forward + backward), the
-fused clipped-PPO loss with its gradients, and the dense layer `LinearFn` whose matrix products are library GEMMs
-(hipBLASLt through torch.addmm / mm) while activation, residual, activation gradient, bias gradient and the
-accumulation of weight gradients into the flat gradient buffer are fused (no per-parameter AccumulateGrad kernels)."""
+"""Custom autograd nodes backed by libegogen_hip.so: GRU gate math (forward + backward), the fused clipped-PPO loss with
+its gradients, and the dense layer `LinearFn` / `ResMLPFn` / `GRUSeqFn` nodes of the training operators (marker predictor,
+body regressor, and the checker path of the PPO update).  Every matrix product of these nodes - x W^T + b forward, g^T x
+and g W backward - is `egx_gemm3`: operands packed as bf16 triples, six partial products on the bf16 matrix pipe, fp32
+accumulation (fp32-equivalent; the dense kernel of the rollout and of the update chain).  Bias, activation and residual run
+in that kernel's epilogue, weight gradients accumulate straight into the flat gradient buffer (`res` aliasing `out`): no
+library GEMM and no per-parameter AccumulateGrad kernels."""
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 
 from . import _lib
+
+_GEMM_WS = {}
+
+
+def _workspace(dev, nbytes):
+    """Operand images of one product; one buffer per (device, stream), since products on different streams may overlap."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)   # owned by the graph's pool
+    key = (str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
+    ws = _GEMM_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=dev)
+        _GEMM_WS[key] = ws
+    return ws
+
+
+def gemm3(A, trans_a, B, trans_b, bias=None, act=0, slope=0.0, res=None, out=None, out_act=None):
+    """out[M,N] = act(op(A) op(B)^T + bias) + res on 2-D fp32 tensors with unit inner stride (`egx_gemm3`).  op(A) is [M,K]:
+    A itself, or A^T when trans_a (A stored [K,M]); op(B) is [N,K] likewise.  `res` may be `out` (accumulate in place)."""
+    lib = _lib.load()
+    for t in (A, B):
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+            raise _lib.EgxError("gemm3 operands must be 2-D fp32 device tensors with unit inner stride")
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    N, K2 = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if K != K2:
+        raise ValueError(f"gemm3: reduction lengths differ ({K} vs {K2})")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    nbytes = int(lib.egx_gemm3_workspace_bytes(M, N, K))
+    ws = _workspace(A.device, nbytes)
+    for t in (res, out, out_act):
+        if t is not None and (t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or tuple(t.shape) != (M, N)):
+            raise _lib.EgxError("gemm3: res / out / out_act must be [M,N] fp32 with unit inner stride")
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())     # row strides are passed explicitly
+    _lib.check(lib.egx_gemm3(p(A), A.stride(0), int(bool(trans_a)), p(B), B.stride(0), int(bool(trans_b)), M, N, K,
+                             _lib.ptr(bias) if bias is not None else None, int(act), float(slope),
+                             p(res), res.stride(0) if res is not None else 0, p(out), out.stride(0), p(out_act),
+                             out_act.stride(0) if out_act is not None else 0, _lib.ptr(ws), nbytes, _lib.current_stream_ptr()),
+               "egx_gemm3")
+    return out
 
 
 class GRUPointwiseFn(torch.autograd.Function):
@@ -111,19 +157,14 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b, wg, bg, act, slope, res):
-        lib = _lib.load()
         x = x.contiguous()
-        z = torch.addmm(b, x, W.t())
-        M, N = z.shape
-        out = z
-        if act != 0 or res is not None:
-            if res is not None:
-                res = res.contiguous()
-                out = torch.empty_like(z)
-            _lib.check(lib.egx_act_fwd(_lib.ptr(z), _lib.ptr(res) if res is not None else None,
-                                       _lib.ptr(out) if res is not None else None, M, N, int(act), float(slope),
-                                       _lib.current_stream_ptr()), "egx_act_fwd")
-        ctx.save_for_backward(x, W, z if act != 0 else None)
+        if res is not None:
+            res = res.contiguous()
+        M, N = x.shape[0], W.shape[0]
+        # the activation BEFORE the residual is what backward needs; without a residual it is the output itself
+        a = torch.empty(M, N, dtype=torch.float32, device=x.device) if (act != 0 and res is not None) else None
+        out = gemm3(x, False, W, False, bias=b, act=act, slope=slope, res=res, out_act=a)
+        ctx.save_for_backward(x, W, (a if a is not None else out) if act != 0 else None)
         ctx.wg, ctx.bg, ctx.act, ctx.slope, ctx.has_res = wg, bg, int(act), float(slope), res is not None
         return out
 
@@ -137,27 +178,23 @@ class LinearFn(torch.autograd.Function):
         _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(dout), _lib.ptr(a) if a is not None else None,
                                           _lib.ptr(g) if ctx.act != 0 else None, _lib.ptr(ctx.bg), M, N, ctx.act, ctx.slope,
                                           _lib.current_stream_ptr()), "egx_act_bwd_colsum")
-        ctx.wg.addmm_(g.t(), x)
-        dx = torch.mm(g, W) if ctx.needs_input_grad[0] else None
+        gemm3(g, True, x, True, res=ctx.wg, out=ctx.wg)                       # wg += g^T x
+        dx = gemm3(g, False, W, True) if ctx.needs_input_grad[0] else None    # g W
         return dx, None, None, None, None, None, None, (dout if ctx.has_res else None)
 
 
 class ResMLPFn(torch.autograd.Function):
     """out = act(act(x W1^T + b1) W2^T + b2) + x: one residual unit of MLPBlock (models_policy_ppo.py:233-274) as ONE node.
     The same kernels and products as two LinearFn nodes, but the two gradient paths into x (through W1 and through the
-    skip connection) are summed by the last GEMM (`addmm` with the incoming gradient as its addend) instead of by an extra
+    skip connection) are summed by the last product (the incoming gradient as its residual operand) instead of by an extra
     element-wise kernel of the autograd engine."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, wg1, bg1, W2, b2, wg2, bg2, act, slope):
-        lib, st = _lib.load(), _lib.current_stream_ptr()
         x = x.contiguous()
-        a1 = torch.addmm(b1, x, W1.t())
-        M, N1 = a1.shape
-        _lib.check(lib.egx_act_fwd(_lib.ptr(a1), None, None, M, N1, int(act), float(slope), st), "egx_act_fwd")
-        a2 = torch.addmm(b2, a1, W2.t())
-        out = torch.empty_like(a2)
-        _lib.check(lib.egx_act_fwd(_lib.ptr(a2), _lib.ptr(x), _lib.ptr(out), M, a2.shape[1], int(act), float(slope), st), "egx_act_fwd")
+        a1 = gemm3(x, False, W1, False, bias=b1, act=act, slope=slope)
+        a2 = torch.empty(x.shape[0], W2.shape[0], dtype=torch.float32, device=x.device)
+        out = gemm3(a1, False, W2, False, bias=b2, act=act, slope=slope, res=x, out_act=a2)
         ctx.save_for_backward(x, W1, a1, W2, a2)
         ctx.g = (wg1, bg1, wg2, bg2)
         ctx.act, ctx.slope = int(act), float(slope)
@@ -173,13 +210,13 @@ class ResMLPFn(torch.autograd.Function):
         g2 = torch.empty_like(dout)
         _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(dout), _lib.ptr(a2), _lib.ptr(g2), _lib.ptr(bg2), M, g2.shape[1], ctx.act, ctx.slope, st),
                    "egx_act_bwd_colsum")
-        wg2.addmm_(g2.t(), a1)
-        d1 = torch.mm(g2, W2)
+        gemm3(g2, True, a1, True, res=wg2, out=wg2)
+        d1 = gemm3(g2, False, W2, True)
         g1 = torch.empty_like(d1)
         _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(d1), _lib.ptr(a1), _lib.ptr(g1), _lib.ptr(bg1), M, g1.shape[1], ctx.act, ctx.slope, st),
                    "egx_act_bwd_colsum")
-        wg1.addmm_(g1.t(), x)
-        dx = torch.addmm(dout, g1, W1) if ctx.needs_input_grad[0] else None
+        gemm3(g1, True, x, True, res=wg1, out=wg1)
+        dx = gemm3(g1, False, W1, True, res=dout) if ctx.needs_input_grad[0] else None
         return (dx,) + (None,) * 10
 
 
@@ -234,7 +271,7 @@ def adv_stats(adv: torch.Tensor) -> torch.Tensor:
 
 class GRUSeqFn(torch.autograd.Function):
     """Last hidden state of a one-layer nn.GRU over x[T*nb, in] (time-major, zero initial state) as ONE autograd node:
-    the input products of all steps are one GEMM, each step is a recurrent GEMM + the fused gate kernel, and backward
+    the input products of all steps are one product, each step is a recurrent product + the fused gate kernel, and backward
     writes the gate gradients of every step straight into one [T*nb, 3H] buffer (no slicing / expand / accumulate nodes).
     Parameter gradients are accumulated into the flat-buffer views like LinearFn; x gets no gradient (observations)."""
 
@@ -245,13 +282,13 @@ class GRUSeqFn(torch.autograd.Function):
         nb = x2.shape[0] // T
         H = w_hh.shape[1]
         st = _lib.current_stream_ptr()
-        gi = torch.addmm(b_ih, x2, w_ih.t())
+        gi = gemm3(x2, False, w_ih, False, bias=b_ih)
         gh = torch.empty(T, nb, 3 * H, dtype=torch.float32, device=x2.device)
         hs = torch.zeros(T + 1, nb, H, dtype=torch.float32, device=x2.device)  # hs[0] = initial state
         gh[0].copy_(b_hh.unsqueeze(0).expand(nb, 3 * H))
         for t in range(T):
             if t > 0:
-                torch.addmm(b_hh, hs[t], w_hh.t(), out=gh[t])
+                gemm3(hs[t], False, w_hh, False, bias=b_hh, out=gh[t])
             _lib.check(lib.egx_gru_pointwise(_lib.ptr(gi[t * nb:(t + 1) * nb]), _lib.ptr(gh[t]), _lib.ptr(hs[t]), H, _lib.ptr(hs[t + 1]), H,
                                              nb, H, st), "egx_gru_pointwise")
         ctx.save_for_backward(x2, w_hh, gi, gh, hs)
@@ -276,14 +313,14 @@ class GRUSeqFn(torch.autograd.Function):
                                                  _lib.ptr(dgi[t * nb:(t + 1) * nb]), _lib.ptr(dgh[t]), _lib.ptr(dhp), st),
                        "egx_gru_pointwise_bwd")
             if t > 0:  # through gh_t = h_t W_hh^T + b_hh
-                dh = torch.addmm(dhp, dgh[t], w_hh)
+                dh = gemm3(dgh[t], False, w_hh, True, res=dhp)
                 dhp = torch.empty_like(dhp)
         dgh2 = dgh.reshape(T * nb, 3 * H)
         _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(dgh2), None, None, _lib.ptr(g_b_hh), T * nb, 3 * H, 0, 0.0, st), "egx_act_bwd_colsum")
         _lib.check(lib.egx_act_bwd_colsum(_lib.ptr(dgi), None, None, _lib.ptr(g_b_ih), T * nb, 3 * H, 0, 0.0, st), "egx_act_bwd_colsum")
         if T > 1:
-            g_w_hh.addmm_(dgh2[nb:].t(), hs[1:T].reshape((T - 1) * nb, H))
-        g_w_ih.addmm_(dgi.t(), x2)
+            gemm3(dgh2[nb:], True, hs[1:T].reshape((T - 1) * nb, H), True, res=g_w_hh, out=g_w_hh)
+        gemm3(dgi, True, x2, True, res=g_w_ih, out=g_w_ih)
         return (None,) * 10
 
 

@@ -237,6 +237,19 @@ size_t egx_pack3_bytes(int num_rows, int num_cols);
 int egx_pack3(const float* src, int num_rows, int num_cols, int src_ld, int src_col0, void* dst, int dst_ksteps,
               int dst_kstep0, void* stream);
 
+/* One dense product on fp32 row-major operands with fp32-equivalent arithmetic on the bf16 matrix pipe:
+ *   out[M,N] = act(op(A) op(B)^T + bias) + res,   op(A) = A[M,K] (trans_a = 0) or A[K,M]^T (trans_a = 1),
+ *                                                 op(B) = B[N,K] (trans_b = 0) or B[K,N]^T (trans_b = 1).
+ * Both operands are packed into `workspace` (egx_gemm3_workspace_bytes) and multiplied by the dense kernel of the rollout
+ * / update chain: two launches.  `res` may alias `out` (accumulation); `out_act` (optional) receives the activation before
+ * the residual is added.  This is what the training-side autograd nodes (egogen_amd/fused_ops.py: predictor / regressor
+ * training, the checker path of the PPO update) call where the reference's `loss.backward()` reaches an `nn.Linear` /
+ * `nn.GRU` product: x W^T + b forward (models/baseops.py:638-641), g^T x and g W backward. */
+size_t egx_gemm3_workspace_bytes(int M, int N, int K);
+int egx_gemm3(const float* A, int lda, int trans_a, const float* B, int ldb, int trans_b, int M, int N, int K,
+              const float* bias, int act, float slope, const float* res, int ldr, float* out, int ldo, float* out_act,
+              int ldact, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Packed images of the C-VAE decoder's dense weights (all of them or none). */
 typedef struct egx_prior_packed3 {
   const void *x_enc_w_ih, *x_enc_w_hh; /* [768,201], [768,256]                                  */

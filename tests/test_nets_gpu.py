@@ -161,3 +161,32 @@ def test_policy_bf16_mode_is_close_to_fp32_and_restorable():
         scale = float(ref[k].abs().mean()) + 1e-6
         err = float((low[k] - ref[k]).abs().mean()) / scale
         assert 1e-6 < err < 3e-2, (k, err)   # different from fp32, but by bf16 round-off only
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1152, 1152), (37, 201, 585), (512, 159, 128), (1152, 403, 96), (5, 7, 3)])
+@pytest.mark.parametrize("trans_a,trans_b", [(False, False), (True, True), (False, True), (True, False)])
+def test_gemm3_product_is_fp32_equivalent(M, N, K, trans_a, trans_b):
+    """egx_gemm3 (the product behind every training-side autograd node): all operand layouts, ragged shapes, bias /
+    activation / residual / saved activation, and in-place accumulation, against float64.  The six-product bf16 split must sit
+    at fp32 round-off of the exact result (the bound is that of an fp32 dot product of length K), not at bf16's."""
+    from egogen_amd.fused_ops import gemm3
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + 2 * trans_a + trans_b)
+    A = torch.randn((K, M) if trans_a else (M, K), generator=g)
+    B = torch.randn((K, N) if trans_b else (N, K), generator=g)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    opA, opB = (A.t() if trans_a else A).double(), (B.t() if trans_b else B).double()
+    ref = opA @ opB.t()
+    bound = 4e-7 * float((opA.abs() @ opB.abs().t()).max()) + 1e-6
+    Ad, Bd = A.cuda(), B.cuda()
+    assert max_abs(gemm3(Ad, trans_a, Bd, trans_b).cpu(), ref) <= bound
+    act_ref = torch.tanh(ref + bias.double())
+    saved = torch.empty(M, N, device="cuda")
+    out = gemm3(Ad, trans_a, Bd, trans_b, bias=bias.cuda(), act=1, res=res.cuda(), out_act=saved)
+    assert max_abs(saved.cpu(), act_ref) <= bound and max_abs(out.cpu(), act_ref + res.double()) <= bound
+    acc = res.cuda().clone()
+    gemm3(Ad, trans_a, Bd, trans_b, res=acc, out=acc)                  # accumulate in place (weight gradients)
+    assert max_abs(acc.cpu(), ref + res.double()) <= bound
+    # operands that are row slices of larger tensors (leading dimension > width)
+    if not trans_a and not trans_b and M > 8:
+        wide = torch.randn(M, K + 5, generator=g).cuda()
+        assert max_abs(gemm3(wide[:, :K], False, Bd, False).cpu(), wide[:, :K].cpu().double() @ opB.t()) <= bound
