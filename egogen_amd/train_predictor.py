@@ -106,8 +106,10 @@ class GAMMAPrimitiveVAETrainOP:
         joints0 = ref_jts.reshape(n_t, n_b, -1, 3)[starts]                                   # [K,b,J,3]
         R_all, T_all = canonical_frame(joints0.reshape(len(starts) * n_b, -1, 3))
         R_all, T_all = R_all.view(len(starts), n_b, 3, 3), T_all.view(len(starts), n_b, 1, 3)
-        into = lambda x, R, T: torch.einsum("bji,tbpj->tbpi", R, x - T.unsqueeze(0))           # world -> frame (R^T (x - T))
-        out_of = lambda x, R, T: torch.einsum("bij,tbpj->tbpi", R, x) + T.unsqueeze(0)          # frame -> world
+        # rigid frame changes of [t,b,p,3] point sets, written as broadcast multiply + sum (3-term dot products, no batched GEMM)
+        rot = lambda M, x: (M[None, :, None] * x.unsqueeze(-2)).sum(-1)                        # y_i = sum_j M[b,i,j] x_j
+        into = lambda x, R, T: rot(R.transpose(1, 2), x - T.unsqueeze(0))                      # world -> frame: R^T (x - T)
+        out_of = lambda x, R, T: rot(R, x) + T.unsqueeze(0)                                    # frame -> world
         losses, infos, Y_rec = [], [], None
         for k, s in enumerate(starts):
             window = ref_markers[s:s + 20, :, :self.model.in_dim]

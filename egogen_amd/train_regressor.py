@@ -83,29 +83,65 @@ def cont6d_params_to_aa(xb6: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------------------
 # SMPL-X on the marker rows only
 # ---------------------------------------------------------------------------------------------------------------------
+class _ConstMatmulFn(torch.autograd.Function):
+    """y = x P for a constant P[K,N] (a model buffer): forward and the input gradient g P^T are `egx_gemm3` products."""
+
+    @staticmethod
+    def forward(ctx, x, P):
+        from .fused_ops import gemm3
+        ctx.save_for_backward(P)
+        return gemm3(x.contiguous(), False, P, True)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .fused_ops import gemm3
+        (P,) = ctx.saved_tensors
+        return (gemm3(g.contiguous(), False, P, False) if ctx.needs_input_grad[0] else None), None
+
+
+def _cmm(x, P):
+    if x.is_cuda and x.dtype == torch.float32:
+        return _ConstMatmulFn.apply(x, P)
+    return x @ P          # host / float64 evaluation (tests compare the two)
+
+
+def _mm3(a, b):
+    """[...,3,3] x [...,3,3] written out (9 dot products of length 3: element-wise kernels, not a batched GEMM)."""
+    return (a.unsqueeze(-1) * b.unsqueeze(-3)).sum(-2)
+
+
+def _mv3(a, v):
+    return (a * v.unsqueeze(-2)).sum(-1)
+
+
 class MarkerBodyModel(torch.nn.Module):
     """`bm(return_verts=True, **body_param).vertices[:, markers]` (models_GAMMA_primitive.py:629) without the other 10 408
     vertices.  Arithmetic of smplx.SMPLX.forward / lbs.lbs [upstream smplx 0.1.28] restricted to the rows in `marker_vids`:
     the rest joints are an affine function of betas (J_regressor folded into the template and the shape directions once, in
-    float64), the pose chain is the full 55-joint one, blend shapes and skinning weights are gathered at the markers."""
+    float64), the pose chain is the full 55-joint one, blend shapes and skinning weights are gathered at the markers.  The
+    four matrix products (hand PCA, shape and pose blend shapes, skinning-weight blend of the joint transforms) have a constant
+    right-hand side and run as `egx_gemm3` products; the 3x3 chain is element-wise."""
 
     def __init__(self, bm: Dict[str, np.ndarray], marker_vids):
         super().__init__()
         vids = np.asarray(marker_vids, np.int64)
+        m = len(vids)
         V = bm["v_template"].shape[0]
         Jr = np.asarray(bm["J_regressor"], np.float64)
         buf = lambda name, a: self.register_buffer(name, torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32), persistent=False)
-        buf("J_template", Jr @ np.asarray(bm["v_template"], np.float64))                                  # [55,3]
-        buf("J_shapedirs", np.einsum("jv,vkl->jkl", Jr, np.asarray(bm["shapedirs"], np.float64)))          # [55,3,10]
-        buf("v_template", np.asarray(bm["v_template"])[vids])                                              # [m,3]
-        buf("shapedirs", np.asarray(bm["shapedirs"])[vids])                                                # [m,3,10]
-        buf("posedirs", np.asarray(bm["posedirs"]).reshape(-1, V, 3)[:, vids].reshape(-1, 3 * len(vids)))   # [486,3m]
-        buf("lbs_weights", np.asarray(bm["lbs_weights"])[vids])                                            # [m,55]
-        buf("hand_comps", np.concatenate([np.asarray(bm["hand_comps_l"]), np.asarray(bm["hand_comps_r"])], 0))   # [24,45]
+        buf("J_template", Jr @ np.asarray(bm["v_template"], np.float64))                                              # [55,3]
+        buf("J_shapedirs", np.einsum("jv,vkl->jkl", Jr, np.asarray(bm["shapedirs"], np.float64)).reshape(-1, 10).T)  # [10,165]
+        buf("v_template", np.asarray(bm["v_template"])[vids])                                                          # [m,3]
+        buf("shapedirs", np.asarray(bm["shapedirs"])[vids].reshape(3 * m, 10).T)                                       # [10,3m]
+        buf("posedirs", np.asarray(bm["posedirs"]).reshape(-1, V, 3)[:, vids].reshape(-1, 3 * m))                     # [486,3m]
+        buf("lbs_weights_t", np.asarray(bm["lbs_weights"])[vids].T)                                                    # [55,m]
+        hand = np.zeros((24, 90), np.float64)                                                                           # block diagonal
+        hand[:12, :45], hand[12:, 45:] = np.asarray(bm["hand_comps_l"]), np.asarray(bm["hand_comps_r"])
+        buf("hand_comps", hand)
         buf("hand_mean", np.concatenate([np.asarray(bm["hand_mean_l"]), np.asarray(bm["hand_mean_r"])]))
         parents = [int(p) for p in bm["parents"]]
         self.parents = parents
-        # joints grouped by depth so that the chain is one batched product per level, not one per joint
+        # joints grouped by depth so that the chain is one batched step per level, not one per joint
         depth = [0] * len(parents)
         for j in range(1, len(parents)):
             depth[j] = depth[parents[j]] + 1
@@ -113,43 +149,45 @@ class MarkerBodyModel(torch.nn.Module):
 
     @staticmethod
     def rodrigues(r: torch.Tensor) -> torch.Tensor:
-        """smplx lbs.batch_rodrigues: angle = |r + 1e-8|, R = I + sin K + (1 - cos) K^2."""
+        """smplx lbs.batch_rodrigues: angle = |r + 1e-8|, d = r / angle, R = I + sin K + (1 - cos) K^2 with K the cross-product
+        matrix of d; K^2 = d d^T - |d|^2 I for any d, so no matrix product is needed."""
         angle = torch.linalg.vector_norm(r + 1e-8, dim=1, keepdim=True)
         d = r / angle
         zero = torch.zeros_like(angle[:, 0])
         K = torch.stack([zero, -d[:, 2], d[:, 1], d[:, 2], zero, -d[:, 0], -d[:, 1], d[:, 0], zero], 1).view(-1, 3, 3)
+        eye = torch.eye(3, dtype=r.dtype, device=r.device)
+        K2 = d.unsqueeze(-1) * d.unsqueeze(-2) - (d * d).sum(-1).view(-1, 1, 1) * eye
         s, c = torch.sin(angle).unsqueeze(-1), torch.cos(angle).unsqueeze(-1)
-        return torch.eye(3, dtype=r.dtype, device=r.device) + s * K + (1 - c) * (K @ K)
+        return eye + s * K + (1 - c) * K2
 
     def forward(self, xb: torch.Tensor, betas: torch.Tensor) -> torch.Tensor:
         """xb[B,93] (transl | global_orient | body_pose 63 | hand PCA 12 + 12), betas[B,10] -> markers[B,m,3]."""
         B = xb.shape[0]
-        lh = xb[:, 69:81] @ self.hand_comps[:12]
-        rh = xb[:, 81:93] @ self.hand_comps[12:]
-        hands = torch.cat([lh, rh], 1) + self.hand_mean
+        hands = _cmm(xb[:, 69:93], self.hand_comps) + self.hand_mean
         full_pose = torch.cat([xb[:, 3:69], xb.new_zeros(B, 9), hands], 1)                 # jaw and eyes stay at rest
         rot = self.rodrigues(full_pose.reshape(-1, 3)).view(B, 55, 3, 3)
-        J = self.J_template + torch.einsum("bl,jkl->bjk", betas, self.J_shapedirs)           # [B,55,3]
-        v_shaped = self.v_template + torch.einsum("bl,mkl->bmk", betas, self.shapedirs)
+        J = self.J_template + _cmm(betas, self.J_shapedirs).view(B, 55, 3)
+        v_shaped = self.v_template + _cmm(betas, self.shapedirs).view(B, -1, 3)
         pose_feature = (rot[:, 1:] - torch.eye(3, dtype=xb.dtype, device=xb.device)).reshape(B, -1)
-        v_posed = v_shaped + (pose_feature @ self.posedirs).view(B, -1, 3)
+        v_posed = v_shaped + _cmm(pose_feature, self.posedirs).view(B, -1, 3)
         # world transform of every joint: G_j = G_parent(j) [R_j | J_j - J_parent(j)]
-        rel = J.clone()
-        rel[:, 1:] = J[:, 1:] - J[:, self.parents[1:]]
+        rel = torch.cat([J[:, :1], J[:, 1:] - J[:, self.parents[1:]]], 1)
         G_R, G_t = [None] * 55, [None] * 55
         G_R[0], G_t[0] = rot[:, 0], rel[:, 0]
         for lv in self.levels:
             pr = torch.stack([G_R[self.parents[j]] for j in lv], 1)                          # [B,n,3,3]
             pt = torch.stack([G_t[self.parents[j]] for j in lv], 1)
-            r = pr @ rot[:, lv]
-            t = (pr @ rel[:, lv].unsqueeze(-1)).squeeze(-1) + pt
+            r = _mm3(pr, rot[:, lv])
+            t = _mv3(pr, rel[:, lv]) + pt
             for i, j in enumerate(lv):
                 G_R[j], G_t[j] = r[:, i], t[:, i]
         GR, Gt = torch.stack(G_R, 1), torch.stack(G_t, 1)                                    # [B,55,3,3], [B,55,3]
-        At = Gt - (GR @ J.unsqueeze(-1)).squeeze(-1)                                         # rest joint removed
-        TR = torch.einsum("mj,bjik->bmik", self.lbs_weights, GR)
-        Tt = torch.einsum("mj,bji->bmi", self.lbs_weights, At)
-        return (TR @ v_posed.unsqueeze(-1)).squeeze(-1) + Tt + xb[:, None, :3]
+        At = Gt - _mv3(GR, J)                                                                # rest joint removed
+        # skinning transforms of the markers: T_m = sum_j w[m,j] [GR_j | At_j], one product with the 12 entries as rows
+        X = torch.cat([GR.reshape(B, 55, 9), At], -1).permute(0, 2, 1).reshape(B * 12, 55)
+        T = _cmm(X, self.lbs_weights_t).view(B, 12, -1).permute(0, 2, 1)                     # [B,m,12]
+        TR, Tt = T[..., :9].reshape(B, -1, 3, 3), T[..., 9:]
+        return _mv3(TR, v_posed) + Tt + xb[:, None, :3]
 
 
 # ---------------------------------------------------------------------------------------------------------------------

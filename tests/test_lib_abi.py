@@ -39,6 +39,19 @@ def test_product_does_not_import_oracle():
     assert not bad, bad
 
 
+def test_training_nodes_call_no_library_gemm():
+    """The autograd nodes and training operators run their matrix products through egx_gemm3 / the update chain: no
+    torch GEMM entry point (hipBLASLt / rocBLAS behind it) is spelled in those sources."""
+    pat = re.compile(r"torch\.(addmm|mm|bmm|baddbmm|matmul|einsum|tensordot)\(|\.addmm_\(|F\.linear\(")
+    bad = []
+    for fn in ("fused_ops.py", "ppo_policy.py", "train_predictor.py", "trainer.py"):
+        src = open(os.path.join(ROOT, "egogen_amd", fn)).read()
+        bad += [(fn, m.group(0)) for m in pat.finditer(src)]
+    src = open(os.path.join(ROOT, "egogen_amd", "train_regressor.py")).read()
+    bad += [("train_regressor.py", m.group(0)) for m in pat.finditer(src)]
+    assert not bad, bad
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from egogen_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
