@@ -292,6 +292,8 @@ class GAMMAPPOPolicy(nn.Module):
     def _refresh_images(self):
         """Re-make the packed weight images of every update handle (one launch each) - after anything that changed the
         parameters."""
+        if not self._train_handles:
+            return
         lib, st = _lib.load(), _lib.current_stream_ptr()
         for hs in self._train_handles.values():
             _lib.check(lib.egx_policy_train_refresh(hs["h"], st), "egx_policy_train_refresh")
