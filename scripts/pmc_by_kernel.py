@@ -1,3 +1,5 @@
+"""Development aid: per-kernel averages of a rocprofv3 `--pmc` counter_collection CSV for the dense / GRU / packing kernels.
+    python scripts/pmc_by_kernel.py <counter_collection.csv>"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(list)

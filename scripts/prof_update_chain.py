@@ -1,3 +1,5 @@
+"""Development aid: three `learn()` passes over a filled 4 x 512 rollout without graph replay - the workload behind
+profiles/r03_update_experiments.md (run under `rocprofv3 --kernel-trace`, then scripts/trace_sequence.py on the CSV)."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch

@@ -1,5 +1,5 @@
 """Development aid: the kernel sequence (durations, idle gap before each) between the last two launches of a marker kernel.
-    python scripts/_seq.py <kernel_trace.csv> [marker substring, default gather_rows]"""
+    python scripts/trace_sequence.py <kernel_trace.csv> [marker substring, default gather_rows]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 marker = sys.argv[2] if len(sys.argv) > 2 else "gather_rows"
