@@ -14,6 +14,7 @@
 //   * the GRU cell is ONE launch: a workgroup owns 32 rows x 16 hidden columns of all three gates on both sides
 //     (x W_ih^T and h W_hh^T), so the gate math runs in its epilogue (was: paired GEMM launch + pointwise launch).
 // Weights are packed once (motion prior: at load; policy: once per collect).
+#include <cstddef>
 #include <mutex>
 #include "egx_nets.h"
 
@@ -159,6 +160,59 @@ void egx_launch_pack3(hipStream_t st, const D3Pack* jobs, int njobs) {
   hipLaunchKernelGGL(egx_pack3_kernel, dim3(egx_ceil_div(total, 4)), dim3(256), 0, st, J);
 }
 
+// One output element after the reduction (bias already added): activation, saved activation, residual, fp32 stores, and the
+// value that goes into the packed images (0 outside the matrix).
+__device__ __forceinline__ float d3_finish(const D3Plain& a, float v, int m, int n, int row_base) {
+  v = d3_act(v, a.act, a.slope);
+  const bool live = m < a.M && n < a.N;
+  if (live && a.out_act) a.out_act[(size_t)m * a.ldact + n] = v;   // activation before the skip connection (saved for backward)
+  if (live && a.res && !(a.n_split > 0 && n >= a.n_split)) v += a.res[(size_t)(row_base + m) * a.ldr + n];
+  if (live && a.n_split > 0 && n >= a.n_split) {
+    // weight-gradient launch: the B operand's extra row of ones makes column n_split the bias gradient
+    if (n == a.n_split && a.bias_out) a.bias_out[m] = v;
+  } else if (live && a.out) {
+    a.out[(size_t)(row_base + m) * a.ldo + n] = v;
+  }
+  // gradient launches: what goes on to the next products is v x act'(saved activation of the layer below)
+  if (live && a.dact) v *= d3_act_grad(a.dact[(size_t)m * a.lddact + n], a.dact_code, a.dact_slope);
+  return live ? v : 0.f;
+}
+
+// Packed images of a finished tile (values in `tile`, pitch TN + 4).  Row-major image (the consumer's A operand): 16-row tiles
+// MI mt + i, k-steps s30 + nt NI/2 + j.  Transposed image (rows = this layer's columns, reduction index = its rows - what a
+// weight-gradient product reads): row tiles NI nt + j, k-steps s3T0 + mt MI/2 + i.  One wave per fragment.
+template <int MI, int NI, int NW>
+__device__ __forceinline__ void d3_write_packed(const D3Plain& a, const float* tile, int mt, int nt, int batch, int wave, int lane) {
+  constexpr int PITCH = 16 * NI + 4;
+  constexpr int NR = MI * (NI / 2), NTT = NI * (MI / 2);
+  const int ntask = (a.out3 ? NR : 0) + (a.out3T ? NTT : 0);
+  const int m_ksteps = (a.M + 31) >> 5, n_ksteps = (a.N + 31) >> 5;   // extents of the images (even tile counts)
+  for (int task = wave; task < ntask; task += NW) {
+    float x[8];
+    bf16x8* o;
+    if (a.out3 && task < NR) {
+      const int i = task / (NI / 2), j = task % (NI / 2);
+      if (MI * mt + i >= 2 * m_ksteps || nt * (NI / 2) + j >= n_ksteps) continue;   // past the image (ragged last tile)
+      const int row = 16 * i + (lane & 15), g = lane >> 4;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&tile[row * PITCH + 32 * j + 8 * g]), x1 = *reinterpret_cast<const f32x4*>(&tile[row * PITCH + 32 * j + 8 * g + 4]);
+      x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2]; x[3] = x0[3]; x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3];
+      o = a.out3 + (size_t)batch * a.batch_stride3 + ((size_t)(MI * mt + i) * a.S3 + a.s30 + nt * (NI / 2) + j) * 3 * 64 + lane;
+    } else {
+      const int tt = task - (a.out3 ? NR : 0);
+      const int j = tt / (MI / 2), i = tt % (MI / 2);
+      if (NI * nt + j >= 2 * n_ksteps || mt * (MI / 2) + i >= m_ksteps) continue;
+      const int c = 16 * j + (lane & 15), kg = lane >> 4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = tile[(32 * i + 8 * kg + e) * PITCH + c];
+      o = a.out3T + ((size_t)(NI * nt + j) * a.S3T + a.s3T0 + mt * (MI / 2) + i) * 3 * 64 + lane;
+    }
+    bf16x8 pl[3];
+    d3_split(x, pl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // plain layer: out = act(A B^T + bias) + res for a 32 x 32 output tile per workgroup, the reduction split over the four
 // waves; up to three independent layers may share a launch.
@@ -168,13 +222,34 @@ struct D3Args4 {
   int end0, end1, end2;   // blocks [0, end0) work on p0, [end0, end1) on p1, [end1, end2) on p2, the rest on p3
 };
 
+// The layer a block works on.  Picking one of the four structs by reference (`which == 0 ? four.p0 : ...`) makes the
+// compiler copy all of the kernel arguments to scratch in every wave and read the fields back with vector loads; selecting
+// field by field keeps them in SGPRs but loads all four structs.  Reading the one struct straight from the kernel-argument
+// segment (constant address space, uniform offset: scalar loads) touches only what is used.  D3Args4 is the kernels' only
+// argument, so p0 sits at offset 0 of the segment.
+__device__ __forceinline__ D3Plain d3_pick(int which) {
+  D3Plain a;
+  static_assert(offsetof(D3Args4, p0) == 0 && offsetof(D3Args4, p1) == sizeof(D3Plain) && sizeof(D3Plain) % 4 == 0, "layout");
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) char* kptr;
+  typedef const __attribute__((address_space(4))) int* iptr;
+  iptr src = (iptr)((kptr)__builtin_amdgcn_kernarg_segment_ptr() + (size_t)which * sizeof(D3Plain));
+  int* dst = reinterpret_cast<int*>(&a);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(D3Plain) / 4); ++i) dst[i] = src[i];
+#else
+  (void)which;
+#endif
+  return a;
+}
+
 // MI x NI MFMA tiles of 16 x 16 per workgroup of NW waves (instantiated: 2 x 2 tiles, four waves).
 template <int TRIP, int MI, int NI, int NW>
 __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
   constexpr int TM = 16 * MI, TN = 16 * NI, NACC = MI * NI * 4, PITCH = TN + 4;
   const int bx = (int)blockIdx.x;
   const int which = bx < four.end0 ? 0 : (bx < four.end1 ? 1 : (bx < four.end2 ? 2 : 3));
-  const D3Plain& a = which == 0 ? four.p0 : (which == 1 ? four.p1 : (which == 2 ? four.p2 : four.p3));
+  const D3Plain a = d3_pick(which);
   const int bid = bx - (which == 0 ? 0 : (which == 1 ? four.end0 : (which == 2 ? four.end1 : four.end2)));
   extern __shared__ __attribute__((aligned(16))) float d3_smem[];
   float* red = d3_smem;                      // [NW waves][NACC][64]
@@ -250,55 +325,13 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
       float v = (red[(0 * NACC + q) * 64 + lane] + red[(1 * NACC + q) * 64 + lane]) + red[(2 * NACC + q) * 64 + lane];
 #pragma unroll
       for (int w2 = 3; w2 < NW; ++w2) v += red[(w2 * NACC + q) * 64 + lane];
-      v += bsv;
-      v = d3_act(v, a.act, a.slope);
       const int row = 16 * mi + 4 * (lane >> 4) + r, m = mt * TM + row;
-      const bool live = m < a.M && n < a.N;
-      if (live && a.out_act) a.out_act[(size_t)m * a.ldact + n] = v;   // activation before the skip connection (saved for backward)
-      if (live && a.res && !(a.n_split > 0 && n >= a.n_split)) v += a.res[(size_t)(row_base + m) * a.ldr + n];
-      if (live && a.n_split > 0 && n >= a.n_split) {
-        // weight-gradient launch: the B operand's extra row of ones makes column n_split the bias gradient
-        if (n == a.n_split && a.bias_out) a.bias_out[m] = v;
-      } else if (live && a.out) {
-        a.out[(size_t)(row_base + m) * a.ldo + n] = v;
-      }
-      // gradient launches: what goes on to the next products is v x act'(saved activation of the layer below)
-      if (live && a.dact) v *= d3_act_grad(a.dact[(size_t)m * a.lddact + n], a.dact_code, a.dact_slope);
-      tile[row * PITCH + col] = live ? v : 0.f;
+      tile[row * PITCH + col] = d3_finish(a, v + bsv, m, n, row_base);
     }
   }
   if (!a.out3 && !a.out3T) return;
   __syncthreads();
-  // packed images of the tile.  Row-major image (the consumer's A operand): 16-row tiles MI mt + i, k-steps s30 + nt NI/2 + j.
-  // Transposed image (rows = this layer's columns, reduction index = its rows - what a weight-gradient product reads):
-  // row tiles NI nt + j, k-steps s3T0 + mt MI/2 + i.  One wave per fragment.
-  constexpr int NR = MI * (NI / 2), NTT = NI * (MI / 2);
-  const int ntask = (a.out3 ? NR : 0) + (a.out3T ? NTT : 0);
-  const int m_ksteps = (a.M + 31) >> 5, n_ksteps = (a.N + 31) >> 5;   // extents of the images (even tile counts)
-  for (int task = wave; task < ntask; task += NW) {
-    float x[8];
-    bf16x8* o;
-    if (a.out3 && task < NR) {
-      const int i = task / (NI / 2), j = task % (NI / 2);
-      if (MI * mt + i >= 2 * m_ksteps || nt * (NI / 2) + j >= n_ksteps) continue;   // past the image (ragged last tile)
-      const int row = 16 * i + (lane & 15), g = lane >> 4;
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&tile[row * PITCH + 32 * j + 8 * g]), x1 = *reinterpret_cast<const f32x4*>(&tile[row * PITCH + 32 * j + 8 * g + 4]);
-      x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2]; x[3] = x0[3]; x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3];
-      o = a.out3 + (size_t)batch * a.batch_stride3 + ((size_t)(MI * mt + i) * a.S3 + a.s30 + nt * (NI / 2) + j) * 3 * 64 + lane;
-    } else {
-      const int tt = task - (a.out3 ? NR : 0);
-      const int j = tt / (MI / 2), i = tt % (MI / 2);
-      if (NI * nt + j >= 2 * n_ksteps || mt * (MI / 2) + i >= m_ksteps) continue;
-      const int c = 16 * j + (lane & 15), kg = lane >> 4;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = tile[(32 * i + 8 * kg + e) * PITCH + c];
-      o = a.out3T + ((size_t)(NI * nt + j) * a.S3T + a.s3T0 + mt * (MI / 2) + i) * 3 * 64 + lane;
-    }
-    bf16x8 pl[3];
-    d3_split(x, pl);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
-  }
+  d3_write_packed<MI, NI, NW>(a, tile, mt, nt, batch, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
