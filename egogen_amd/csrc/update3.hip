@@ -526,10 +526,12 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
     float* const outf[2] = {Ba.du2, Bc.du2};
     dgrad(gin, S_head, Wt, none, outf, 3, 3);
   }
-  // layer l of both blocks: dW_l = g_l^T x_l on the side stream; then the input gradient of layer l on `st`
+  // layer l of both blocks: the input gradient now (the dependent chain); its weight gradient dW_l = g_l^T x_l only needs the
+  // images this launch leaves behind, so the eight weight-gradient products of the four layers go out afterwards as two
+  // four-product launches (fewer, fuller launches: ~10 us of every launch is fixed cost, profiles/r03_update_experiments.md)
+  D3Plain WL[8];
   auto layer_bwd = [&](int l, bf16x8* const (&xT)[2], float* const (&res)[2], float* const (&outf)[2], int gate) {
-    for (int b = 0; b < 2; ++b) wgrad(W[b], h->br[b].gT[l], xT[b], CAT, h->br[b].gW[l], h->br[b].gb[l]);
-    egx_launch_dense3_n(sw, W, 2);
+    for (int b = 0; b < 2; ++b) wgrad(WL[2 * l + b], h->br[b].gT[l], xT[b], CAT, h->br[b].gW[l], h->br[b].gb[l]);
     const bf16x8* const gin[2] = {Ba.g_r[l], Bc.g_r[l]};
     const bf16x8* const Wt[2] = {Ba.W_t[l], Bc.W_t[l]};
     dgrad(gin, S_full, Wt, res, outf, gate, gate);
@@ -547,6 +549,8 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
     bf16x8* const x0[2] = {h->catT, h->catT};
     float* const dhx[2] = {Ba.dhx, Bc.dhx};
     if ((rc = layer_bwd(0, x0, du1, dhx, -1))) return rc;                     // dhx = g1 W1 + du1
+    egx_launch_dense3_n(sw, WL, 4);
+    egx_launch_dense3_n(sw, WL + 4, 4);
   }
   // ---- the two GRU encoders (dhx = actor's + critic's)
   {
