@@ -319,20 +319,26 @@ static int policy_forward_packed(const egx_policy_weights* w, const float* state
     egx_launch_pack3(st, jobs, 4);
   }
   egx_launch_posenc3(st, dist, time, n, catf + 2 * HD, 1152, cat3, PS_CAT, 2 * PS_HD);
-  auto gru2 = [&](const bf16x8* x0, const bf16x8* x1, int Sx, const void* w_ih, const void* w_hh, const float* b_ih,
-                  const float* b_hh, bf16x8* h1, float* h1f, int col0, int s30) {
-    D3Gru g;
-    g.M = n; g.H = HD; g.prec = prec;
-    g.Ai = x0; g.SAi = Sx; g.Bi = B3(w_ih); g.Si = Sx; g.bias_i = b_ih; g.bias_h = b_hh;
-    g.h_out = h1f; g.ldo = HD; g.h_out3 = h1; g.S3 = PS_HD;
-    egx_launch_gru3(st, g);
-    g.Ai = x1;
-    g.Ah = h1; g.SAh = PS_HD; g.Bh = B3(w_hh); g.Sh = PS_HD; g.h_prev = h1f; g.ldh = HD;
-    g.h_out = catf + col0; g.ldo = 1152; g.h_out3 = cat3; g.S3 = PS_CAT; g.s30 = s30;
-    egx_launch_gru3(st, g);
-  };
-  gru2(s0p, s1p, PS_ST, P.x_enc_w_ih, P.x_enc_w_hh, w->x_enc_b_ih, w->x_enc_b_hh, hx1, hx1f, 0, 0);
-  gru2(e0p, e1p, PS_EGO, P.ego_enc_w_ih, P.ego_enc_w_hh, w->ego_enc_b_ih, w->ego_enc_b_hh, he1, he1f, HD, PS_HD);
+  {   // the two 2-step GRU encoders, both cells of a step in one launch
+    struct Enc { const bf16x8 *x0, *x1; int Sx; const void *w_ih, *w_hh; const float *b_ih, *b_hh; bf16x8* h1; float* h1f; int col0, s30; };
+    const Enc enc[2] = {{s0p, s1p, PS_ST, P.x_enc_w_ih, P.x_enc_w_hh, w->x_enc_b_ih, w->x_enc_b_hh, hx1, hx1f, 0, 0},
+                        {e0p, e1p, PS_EGO, P.ego_enc_w_ih, P.ego_enc_w_hh, w->ego_enc_b_ih, w->ego_enc_b_hh, he1, he1f, HD, PS_HD}};
+    D3Gru g[2];
+    for (int e = 0; e < 2; ++e) {
+      const Enc& E = enc[e];
+      g[e].M = n; g[e].H = HD; g[e].prec = prec;
+      g[e].Ai = E.x0; g[e].SAi = E.Sx; g[e].Bi = B3(E.w_ih); g[e].Si = E.Sx; g[e].bias_i = E.b_ih; g[e].bias_h = E.b_hh;
+      g[e].h_out = E.h1f; g[e].ldo = HD; g[e].h_out3 = E.h1; g[e].S3 = PS_HD;
+    }
+    egx_launch_gru3_pair(st, g[0], g[1]);
+    for (int e = 0; e < 2; ++e) {
+      const Enc& E = enc[e];
+      g[e].Ai = E.x1;
+      g[e].Ah = E.h1; g[e].SAh = PS_HD; g[e].Bh = B3(E.w_hh); g[e].Sh = PS_HD; g[e].h_prev = E.h1f; g[e].ldh = HD;
+      g[e].h_out = catf + E.col0; g[e].ldo = 1152; g[e].h_out3 = cat3; g[e].S3 = PS_CAT; g[e].s30 = E.s30;
+    }
+    egx_launch_gru3_pair(st, g[0], g[1]);
+  }
   const float slope = 0.01f;  // torch.nn.LeakyReLU() default (baseops.py:627-628)
   const bool do_a = out_mu != nullptr, do_c = out_value != nullptr;
   auto layer = [&](const bf16x8* xin, const void* W, const float* b, const float* res, float* outf, bf16x8* out3) {
