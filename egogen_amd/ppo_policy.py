@@ -2,9 +2,11 @@
 tianshou.  Same constructor arguments, same state_dict key set (incl. the duplicated `_actor_critic.*`
 entries the tianshou parent creates, main_ppo.py:207-216 / SURVEY 8(b)), same loss and optimiser schedule.
 
-Rollout-time pieces (policy forward, action sampling, critic values, GAE) run through libegogen_hip.so; the
-update uses torch autograd on the same parameter storage (rocBLAS GEMMs), with an optional RCCL all-reduce
-of one flat gradient buffer for data parallelism (one process per GPU).
+Rollout-time pieces (policy forward, action sampling, critic values, GAE) run through libegogen_hip.so, and so does the
+update: forward, loss and backward of a minibatch are one fixed launch chain (`egx_policy_train_step`, csrc/update3.hip) that
+writes the gradients into one flat buffer, followed by the flat clip + AdamW kernels and an optional RCCL all-reduce of that
+buffer for data parallelism (one process per GPU).  The autograd-node formulation (fused_ops.py, same kernels for its
+products) stays as the checker of the chain and serves minibatches that are not a multiple of 32 rows.
 """
 from __future__ import annotations
 

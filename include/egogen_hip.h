@@ -541,7 +541,7 @@ int egx_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PPO update: fused loss + gradient of one minibatch (crowd_ppo/ppo_policy.py:189-241) and the backward of the
- * GRU gate math.  Used as custom autograd nodes by the host; dense-layer backward stays on rocBLAS this round.
+ * GRU gate math.  Used inside egx_policy_train_step and as custom autograd nodes by the host (whose products are egx_gemm3).
  *   loss = scale * sum_rows [ -min(r A, clamp(r,1-e,1+e) A) + vf_coef (ret - V)^2 - ent_coef H ],  r = exp(logp - logp_old),
  *   A = (adv - adv_stats[0]) / (adv_stats[1] + adv_eps) when adv_stats != NULL (per-minibatch normalisation, :192-195)
  *   logvar is the RAW actor output; the clamp to [min,max] (ppo_policy.py:169) and its gradient mask are applied inside.
