@@ -557,11 +557,16 @@ class PolicyHipRunner:
         self._wstruct, self._wkey = w, key
         return w
 
-    def adopt_packed(self, packed3: "_lib.PolicyPacked3"):
-        """Use weight images somebody else keeps current (the update's `egx_policy_train` handle re-makes them after every
-        optimiser step): the runner stops packing its own."""
+    def adopt_packed(self, packed3: "_lib.PolicyPacked3", refresh=None):
+        """Use weight images somebody else keeps current (the update's `egx_policy_train` handle re-makes them at the head of
+        every train step and at the end of `learn()`): the runner stops packing its own.  `refresh`: called before a forward
+        when torch saw an in-place edit of a weight since the last forward (load_state_dict, copy_) - edits the owner cannot
+        know about."""
         w = self._weights()
         self._adopted = packed3            # keep the struct alive
+        self._adopted_refresh = refresh
+        self._adopted_src = [W for _, _, W in self._p3_src] if self._p3 is not None else []
+        self._adopted_ver = sum(int(W._version) for W in self._adopted_src)
         w.packed3 = C.pointer(packed3)
         self._p3 = None
 
@@ -574,6 +579,11 @@ class PolicyHipRunner:
         """Re-pack the dense weights (three bf16 planes in MFMA fragment order) when any parameter changed since the images
         were made: explicit mark (learn()), or an in-place edit torch saw (optim.step(), load_state_dict, copy_)."""
         if self._p3 is None:
+            if getattr(self, "_adopted_refresh", None) is not None:
+                ver = sum(int(W._version) for W in self._adopted_src)
+                if ver != self._adopted_ver:
+                    self._adopted_refresh()
+                    self._adopted_ver = ver
             return
         ver = sum(int(W._version) for _, _, W in self._p3_src)
         if not self._dirty and ver == self._p3_ver:

@@ -273,7 +273,7 @@ class GAMMAPPOPolicy(nn.Module):
         hs = {"h": h, "bufs": bufs, "stats": torch.zeros(2, **f), "key": (w.x_enc_w_ih, g.x_enc_w_ih), "packed": packed}
         self._train_handles[n] = hs
         if len(self._train_handles) == 1:   # the rollout forward reads the images this handle keeps current
-            self._runner.adopt_packed(packed)
+            self._runner.adopt_packed(packed, refresh=self._refresh_images)
             self._images_owner = n
         self._refresh_images()
         return hs
