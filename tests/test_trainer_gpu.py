@@ -476,3 +476,12 @@ def test_learn_with_train_step_equals_autograd_nodes():
     o1 = eager._runner.forward(obs)
     o2 = PolicyHipRunner(eager.shared_net, eager.actor, eager.critic).forward(obs)
     assert max_abs(o1["mu"].cpu(), o2["mu"].cpu()) <= 1e-6 and max_abs(o1["value"].cpu(), o2["value"].cpu()) <= 1e-6
+    # ... and follows a load_state_dict between updates (torch-visible in-place edit of the weights: the runner asks the
+    # owner of the adopted images to re-make them)
+    sd = {k: (v * 1.05 if v.is_floating_point() else v) for k, v in ref.state_dict().items()}
+    eager.load_state_dict(sd)
+    ref.load_state_dict(sd)
+    o3 = eager._runner.forward(obs)
+    o4 = PolicyHipRunner(ref.shared_net, ref.actor, ref.critic).forward(obs)
+    assert max_abs(o3["mu"].cpu(), o4["mu"].cpu()) <= 1e-6 and max_abs(o3["value"].cpu(), o4["value"].cpu()) <= 1e-6
+    assert max_abs(o3["mu"].cpu(), o1["mu"].cpu()) > 1e-4          # the weights did change
