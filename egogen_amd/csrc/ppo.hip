@@ -1,27 +1,24 @@
 // Fused forward+gradient kernels for the PPO update (crowd_ppo/ppo_policy.py:189-241) and the GRU gate math of the
 // policy's two encoders, so that the autograd graph of one minibatch is ~40 kernels instead of ~300 tiny elementwise ones.
+#include <algorithm>
 #include <cstring>
 #include "egx_common.h"
 
 namespace {
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 
-__device__ __forceinline__ float block_sum128(float v, float* sh) {
-  sh[threadIdx.x] = v;
-  __syncthreads();
-  for (int s = 64; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-    __syncthreads();
-  }
-  const float r = sh[0];
-  __syncthreads();
-  return r;
-}
 }  // namespace
 
-// One 128-thread block per transition.  Writes d loss / d mu, d logvar (raw, pre-clamp), d value and accumulates the
-// loss terms: out_terms[0..5] = loss, clip, vf, ent, kld, approx_kl (all already multiplied by `scale`).
-__global__ __launch_bounds__(128) void egx_ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+__device__ __forceinline__ float egx_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// One wave per transition (two of the 128 action dimensions per lane), rows dealt to the waves of the grid.  Writes d loss /
+// d mu, d logvar (raw, pre-clamp), d value and accumulates the loss terms: out_terms[0..5] = loss, clip, vf, ent, kld,
+// approx_kl (all already multiplied by `scale`) - per-wave partial sums, combined per block, six atomics per block.
+__global__ __launch_bounds__(256) void egx_ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                                                           const float* __restrict__ value, const float* __restrict__ act,
                                                           const float* __restrict__ adv, const float* __restrict__ ret,
                                                           const float* __restrict__ logp_old, const float* __restrict__ adv_stats,
@@ -30,49 +27,65 @@ __global__ __launch_bounds__(128) void egx_ppo_loss_kernel(const float* __restri
                                                           int stride /* row pitch of mu, logvar, g_mu, g_logvar */,
                                                           float* __restrict__ g_mu, float* __restrict__ g_logvar,
                                                           float* __restrict__ g_value, float* __restrict__ out_terms) {
-  __shared__ float sh[128];
-  const int row = blockIdx.x, d = threadIdx.x;
-  const size_t i = (size_t)row * stride + d;
+  __shared__ float sh[4][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float scale = scale_ptr[0];
-  const float lv_raw = logvar[i];
-  const float lv = fminf(fmaxf(lv_raw, min_lv), max_lv);
-  const bool pass = (lv_raw >= min_lv) && (lv_raw <= max_lv);  // clamp backward
-  const float inv_var = expf(-lv);
-  const float diff = act[(size_t)row * 128 + d] - mu[i];
-  const float lp_d = -0.5f * diff * diff * inv_var - 0.5f * lv - LOG_SQRT_2PI;
-  const float ent_d = 0.5f + LOG_SQRT_2PI + 0.5f * lv;
-  const float lp = block_sum128(lp_d, sh);
-  const float ent = block_sum128(ent_d, sh);
-  const float musq = block_sum128(mu[i] * mu[i], sh);
-  float A = adv[row];
-  if (adv_stats) A = (A - adv_stats[0]) / (adv_stats[1] + adv_eps);
-  const float ratio = expf(lp - logp_old[row]);
-  const float s1 = ratio * A;
-  const float rc = fminf(fmaxf(ratio, 1.f - eps_clip), 1.f + eps_clip);
-  const float s2 = rc * A;
-  // d(-min(s1,s2))/d lp: the clamp passes gradient inside [1-eps,1+eps]; torch splits ties of min() evenly, and inside
-  // the range s1 == s2 with identical derivatives, so the total is A*ratio there and when s1 < s2, else 0
-  const bool in_range = (ratio >= 1.f - eps_clip) && (ratio <= 1.f + eps_clip);
-  float dclip_dlp;
-  if (s1 < s2) dclip_dlp = -A * ratio;
-  else if (s1 > s2) dclip_dlp = in_range ? -A * ratio : 0.f;
-  else dclip_dlp = in_range ? -A * ratio : -0.5f * A * ratio;  // tie outside the range: only the s1 half carries gradient
-  const float v = value[row];
-  const float dv = ret[row] - v;
-  // gradients (loss = scale * sum_rows [clip + vf_coef*vf - ent_coef*ent])
-  g_mu[i] = scale * dclip_dlp * (diff * inv_var);
-  const float dlp_dlv = 0.5f * (diff * diff * inv_var - 1.f);
-  g_logvar[i] = pass ? scale * (dclip_dlp * dlp_dlv - ent_coef * 0.5f) : 0.f;
-  if (d == 0) {
-    g_value[row] = scale * vf_coef * (-2.f) * dv;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+    float lv[2], inv_var[2], diff[2], lp_d = 0.f, ent_d = 0.f, musq_d = 0.f;
+    bool pass[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int d = lane + 64 * h;
+      const size_t i = (size_t)row * stride + d;
+      const float lv_raw = logvar[i], m = mu[i];
+      lv[h] = fminf(fmaxf(lv_raw, min_lv), max_lv);
+      pass[h] = (lv_raw >= min_lv) && (lv_raw <= max_lv);  // clamp backward
+      inv_var[h] = expf(-lv[h]);
+      diff[h] = act[(size_t)row * 128 + d] - m;
+      lp_d += -0.5f * diff[h] * diff[h] * inv_var[h] - 0.5f * lv[h] - LOG_SQRT_2PI;
+      ent_d += 0.5f + LOG_SQRT_2PI + 0.5f * lv[h];
+      musq_d += m * m;
+    }
+    const float lp = egx_wave_sum(lp_d), ent = egx_wave_sum(ent_d), musq = egx_wave_sum(musq_d);
+    float A = adv[row];
+    if (adv_stats) A = (A - adv_stats[0]) / (adv_stats[1] + adv_eps);
+    const float ratio = expf(lp - logp_old[row]);
+    const float s1 = ratio * A;
+    const float rc = fminf(fmaxf(ratio, 1.f - eps_clip), 1.f + eps_clip);
+    const float s2 = rc * A;
+    // d(-min(s1,s2))/d lp: the clamp passes gradient inside [1-eps,1+eps]; torch splits ties of min() evenly, and inside
+    // the range s1 == s2 with identical derivatives, so the total is A*ratio there and when s1 < s2, else 0
+    const bool in_range = (ratio >= 1.f - eps_clip) && (ratio <= 1.f + eps_clip);
+    float dclip_dlp;
+    if (s1 < s2) dclip_dlp = -A * ratio;
+    else if (s1 > s2) dclip_dlp = in_range ? -A * ratio : 0.f;
+    else dclip_dlp = in_range ? -A * ratio : -0.5f * A * ratio;  // tie outside the range: only the s1 half carries gradient
+    const float v = value[row];
+    const float dv = ret[row] - v;
+    // gradients (loss = scale * sum_rows [clip + vf_coef*vf - ent_coef*ent])
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const size_t i = (size_t)row * stride + lane + 64 * h;
+      g_mu[i] = scale * dclip_dlp * (diff[h] * inv_var[h]);
+      const float dlp_dlv = 0.5f * (diff[h] * diff[h] * inv_var[h] - 1.f);
+      g_logvar[i] = pass[h] ? scale * (dclip_dlp * dlp_dlv - ent_coef * 0.5f) : 0.f;
+    }
+    if (lane == 0) g_value[row] = scale * vf_coef * (-2.f) * dv;
     const float clip_l = -fminf(s1, s2), vf_l = dv * dv;
-    atomicAdd(out_terms + 0, scale * (clip_l + vf_coef * vf_l - ent_coef * ent));
-    atomicAdd(out_terms + 1, scale * clip_l);
-    atomicAdd(out_terms + 2, scale * vf_l);
-    atomicAdd(out_terms + 3, scale * ent);
-    atomicAdd(out_terms + 4, scale * 0.5f * musq / 128.f);
-    atomicAdd(out_terms + 5, scale * (logp_old[row] - lp));
+    acc[0] += scale * (clip_l + vf_coef * vf_l - ent_coef * ent);
+    acc[1] += scale * clip_l;
+    acc[2] += scale * vf_l;
+    acc[3] += scale * ent;
+    acc[4] += scale * 0.5f * musq / 128.f;
+    acc[5] += scale * (logp_old[row] - lp);
   }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sh[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) atomicAdd(out_terms + threadIdx.x, (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]));
 }
 
 // GRU gate math backward: recomputes r, z, n from (gi, gh, hprev) and turns dh into d gi, d gh, d hprev.
@@ -359,6 +372,8 @@ __global__ __launch_bounds__(256) void egx_adamw_flat_kernel(float* __restrict__
   }
 }
 
+static int ppo_loss_blocks(int num_rows) { return std::max(1, std::min(256, egx_ceil_div(num_rows, 8))); }   // two rows per wave
+
 extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* value, const float* act, const float* adv,
                             const float* ret, const float* logp_old, const float* adv_stats, const float* scale,
                             float adv_eps, float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef,
@@ -367,7 +382,7 @@ extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* v
                   num_rows > 0, "bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   EGX_HIP_CHECK(hipMemsetAsync(out_terms, 0, 6 * sizeof(float), st));
-  hipLaunchKernelGGL(egx_ppo_loss_kernel, dim3(num_rows), dim3(128), 0, st, mu, logvar, value, act, adv, ret, logp_old,
+  hipLaunchKernelGGL(egx_ppo_loss_kernel, dim3(ppo_loss_blocks(num_rows)), dim3(256), 0, st, mu, logvar, value, act, adv, ret, logp_old,
                      adv_stats, scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef, ent_coef, num_rows, 128, g_mu, g_logvar,
                      g_value, out_terms);
   EGX_HIP_CHECK(hipGetLastError());
@@ -381,7 +396,7 @@ extern "C" int egx_ppo_loss_packed(const float* zp, const float* value, const fl
   EGX_REQUIRE(zp && value && act && adv && ret && logp_old && scale && g_zp && g_value && out_terms && num_rows > 0, "bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   EGX_HIP_CHECK(hipMemsetAsync(out_terms, 0, 6 * sizeof(float), st));
-  hipLaunchKernelGGL(egx_ppo_loss_kernel, dim3(num_rows), dim3(128), 0, st, zp, zp + 128, value, act, adv, ret, logp_old, adv_stats,
+  hipLaunchKernelGGL(egx_ppo_loss_kernel, dim3(ppo_loss_blocks(num_rows)), dim3(256), 0, st, zp, zp + 128, value, act, adv, ret, logp_old, adv_stats,
                      scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef, ent_coef, num_rows, 256, g_zp, g_zp + 128, g_value,
                      out_terms);
   EGX_HIP_CHECK(hipGetLastError());
