@@ -42,6 +42,9 @@ def _rodrigues_np(aa: np.ndarray) -> np.ndarray:
     return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
 
 
+CAND_POOL = 16   # steps of reset candidates drawn at a time (SDF scenes)
+
+
 class VecCrowdEnv:
     def __init__(self, num_agents: int, body_model: BodyModelHandle, prior: GAMMAPrimitiveCombo, vposer: VPoserEncoder,
                  scene_kind: str = "sdf", sdf_dict: Optional[dict] = None, rings: Optional[List[np.ndarray]] = None,
@@ -221,6 +224,8 @@ class VecCrowdEnv:
         self.prior._weights()
         self._graph = None
         self._injected = False
+        self._cand_pool, self._cand_pool_pos, self._cand_step = None, 0, None
+        self._z_in = self.z
         self.profile_events = []  # [(start_event, stop_event)] consumed one pair per step (bench.py)
 
         self.valid_pairs = None
@@ -315,8 +320,14 @@ class VecCrowdEnv:
         """Draw reset candidates for every agent (used only where the mask says so)."""
         A, K, g = self.A, self.K, self.gen
         if self.scene_kind == "sdf":
-            idx = torch.randint(0, self.valid_pairs.shape[0], (A * K,), generator=g, device=self.dev)
-            self.cand_pairs.copy_(self.valid_pairs[idx].reshape(A, K, 2, 3))
+            # drawn for CAND_POOL steps at a time (one RNG launch + one gather per pool instead of three launches per step);
+            # a step's candidates are a slice of the pool, handed to the reset kernel by address
+            if self._cand_pool is None or self._cand_pool_pos >= CAND_POOL:
+                idx = torch.randint(0, self.valid_pairs.shape[0], (CAND_POOL * A * K,), generator=g, device=self.dev)
+                self._cand_pool = self.valid_pairs[idx].reshape(CAND_POOL, A, K, 2, 3)
+                self._cand_pool_pos = 0
+            self._cand_step = self._cand_pool[self._cand_pool_pos]
+            self._cand_pool_pos += 1
         elif self.scene_kind == "crowd":
             self.cand_pairs.copy_(self.crowd_pairs)
             if self.agent_seeds is not None:
@@ -337,6 +348,7 @@ class VecCrowdEnv:
     def set_candidates(self, pairs, yaw=None, variant=None, scene=None):
         """Inject reset candidates (parity tests): pairs[A,K,2,3]."""
         self.cand_pairs.copy_(torch.as_tensor(pairs, dtype=torch.float32).reshape(self.A, self.K, 2, 3))
+        self._cand_step = None
         if yaw is not None:
             self.cand_yaw.copy_(torch.as_tensor(yaw, dtype=torch.float32).reshape(self.A, self.K))
         if variant is not None:
@@ -347,7 +359,8 @@ class VecCrowdEnv:
 
     def _launch_reset(self, mask):
         box = self.scene_kind in ("box", "crowd")
-        io = self._reset_io(self.A, self.K, mask, self.cand_pairs, self.cand_yaw if box else None,
+        pairs = self._cand_step if self._cand_step is not None else self.cand_pairs
+        io = self._reset_io(self.A, self.K, mask, pairs, self.cand_yaw if box else None,
                             self.cand_variant if box else None, self.cand_scene if self.scene_kind == "box" else None, None,
                             self.obs_ego, self.obs_dist, self.obs_time, self.choice)
         _lib.check(self.lib.egx_env_reset(C.byref(self._ec), C.byref(self._sc), C.byref(self._st), C.byref(io), self.A,
@@ -379,7 +392,7 @@ class VecCrowdEnv:
         lib, A = self.lib, self.A
         st = _lib.current_stream_ptr()
         # C-VAE decode + regressor (crowd_env_2f.py:109)
-        self.prior.sample_prior_into(self.state[:, 0], self.state[:, 1], 804, self.betas, self.z, self.Y_gen, self.Yb_gen)
+        self.prior.sample_prior_into(self.state[:, 0], self.state[:, 1], 804, self.betas, self._z_in, self.Y_gen, self.Yb_gen)
         _lib.check(lib.egx_assemble_params(_lib.ptr(self.seed), _lib.ptr(self.Yb_gen), A, _lib.ptr(self.pred_params), st),
                    "egx_assemble_params")
         # SMPL-X on A*20 bodies; SDF counts fused (crowd_env_2f.py:133-175)
@@ -412,7 +425,11 @@ class VecCrowdEnv:
         entries of obs are the reset observation (tianshou Collector semantics)."""
         if actions.shape != (self.A, 128):
             raise ValueError(f"actions must be [{self.A},128], got {tuple(actions.shape)}")
-        self.z.copy_(actions)
+        direct = (not self.use_graph and actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+                  and actions.device == self.z.device)
+        self._z_in = actions if direct else self.z      # the kernels read the caller's tensor where that is safe: no copy
+        if not direct:
+            self.z.copy_(actions)
         if self.use_graph:
             if self._graph is None:
                 torch.cuda.synchronize()
