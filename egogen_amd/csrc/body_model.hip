@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
                                                              unsigned short* __restrict__ feat3,  // bf16x3 planes or null
                                                              f32x4* __restrict__ A4,     // [bt][55][3][32]
                                                              float* __restrict__ out_joints, int joints_ld,
-                                                             float template_lo_feat /* 1 in the two-plane blend mode */) {
+                                                             float template_lo_feat /* 1 in the two-plane blend mode */,
+                                                             int* __restrict__ zero_counts /* [B] cleared here, or null */) {
   __shared__ float sR[4][NJ][9];
   __shared__ float sJ[4][NJ][3];
   __shared__ float sG[4][NJ][12];
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
   const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + w;
   const bool live = b < B;
+  if (zero_counts && live && j == 0) zero_counts[b] = 0;   // the SDF epilogue of the skinning kernel adds to these
   const int bb = live ? b : B - 1;
   const float* x = xb + (size_t)bb * EGX_XB_DIM;
   const float* be = betas + (size_t)(bb / fpa) * 10;
@@ -1237,7 +1239,7 @@ extern "C" int egx_lbs_joints(const egx_body_model* m, const float* xb, const fl
   char* ws = static_cast<char*>(workspace);
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream_), m->pc, xb,
                      betas, B, fpa, static_cast<float*>(nullptr), static_cast<unsigned short*>(nullptr),
-                     reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ, 0.f);
+                     reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ, 0.f, static_cast<int*>(nullptr));
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
@@ -1267,7 +1269,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   const bool split3 = mode >= 1 && !out_verts;
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, stream, m->pc, xb, betas, B, fpa,
                      split3 ? nullptr : feat, split3 ? reinterpret_cast<unsigned short*>(feat) : nullptr, A4, out_joints,
-                     EGX_NUM_JOINTS_OUT, (split3 && mode == 2) ? 1.f : 0.f);
+                     EGX_NUM_JOINTS_OUT, (split3 && mode == 2) ? 1.f : 0.f, sdf ? out_pene_count : nullptr);
   if (out_verts || need_picks || sdf) {
     LbsParams p;
     p.dirs = m->dirs; p.tj_off = m->tj_off; p.tj_idx = m->tj_idx; p.tj_w = m->tj_w; p.pick_slot = m->pick_slot;
@@ -1295,7 +1297,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
       p.sdf.cx = sdf->center[0]; p.sdf.cy = sdf->center[1]; p.sdf.cz = sdf->center[2]; p.sdf.scale = sdf->scale;
       p.sdf.coarse = static_cast<const float2*>(sdf->coarse_minmax);
       p.sdf.c0 = egx_ceil_div(sdf->d0, 4); p.sdf.c1 = egx_ceil_div(sdf->d1, 4); p.sdf.c2 = egx_ceil_div(sdf->d2, 4);
-      EGX_HIP_CHECK(hipMemsetAsync(out_pene_count, 0, (size_t)B * sizeof(int32_t), stream));
+      // out_pene_count was cleared by the pose kernel above
     }
     // one persistent workgroup per CU; per-device launch facts (CU count, raised dynamic-LDS caps) are set up once per device
     constexpr size_t lds_meta = (size_t)8 * LBS_META_BYTES, lds_verts = (size_t)8 * (LBS_META_BYTES + LBS_VERT_BYTES),
