@@ -372,6 +372,11 @@ __global__ __launch_bounds__(256) void egx_adamw_flat_kernel(float* __restrict__
   }
 }
 
+// clears the six sums (hipMemsetAsync of 24 bytes is TWO fill launches: a 16-byte part and a tail)
+__global__ void egx_zero_terms_kernel(float* __restrict__ t) {
+  if (threadIdx.x < 6) t[threadIdx.x] = 0.f;
+}
+
 static int ppo_loss_blocks(int num_rows) { return std::max(1, std::min(256, egx_ceil_div(num_rows, 8))); }   // two rows per wave
 
 extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* value, const float* act, const float* adv,
@@ -381,7 +386,7 @@ extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* v
   EGX_REQUIRE(mu && logvar && value && act && adv && ret && logp_old && scale && g_mu && g_logvar && g_value && out_terms &&
                   num_rows > 0, "bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  EGX_HIP_CHECK(hipMemsetAsync(out_terms, 0, 6 * sizeof(float), st));
+  hipLaunchKernelGGL(egx_zero_terms_kernel, dim3(1), dim3(64), 0, st, out_terms);
   hipLaunchKernelGGL(egx_ppo_loss_kernel, dim3(ppo_loss_blocks(num_rows)), dim3(256), 0, st, mu, logvar, value, act, adv, ret, logp_old,
                      adv_stats, scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef, ent_coef, num_rows, 128, g_mu, g_logvar,
                      g_value, out_terms);
@@ -395,7 +400,7 @@ extern "C" int egx_ppo_loss_packed(const float* zp, const float* value, const fl
                                    float* g_value, float* out_terms, void* stream_) {
   EGX_REQUIRE(zp && value && act && adv && ret && logp_old && scale && g_zp && g_value && out_terms && num_rows > 0, "bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  EGX_HIP_CHECK(hipMemsetAsync(out_terms, 0, 6 * sizeof(float), st));
+  hipLaunchKernelGGL(egx_zero_terms_kernel, dim3(1), dim3(64), 0, st, out_terms);
   hipLaunchKernelGGL(egx_ppo_loss_kernel, dim3(ppo_loss_blocks(num_rows)), dim3(256), 0, st, zp, zp + 128, value, act, adv, ret, logp_old, adv_stats,
                      scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef, ent_coef, num_rows, 256, g_zp, g_zp + 128, g_value,
                      out_terms);
