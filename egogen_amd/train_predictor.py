@@ -261,7 +261,10 @@ class BatchGeneratorAMASSCanonicalized:
 
     def next_batch(self, batch_size=64, noise=None):
         if noise is not None:
-            raise NotImplementedError("rotation-noise augmentation re-poses the body model (batch_gen_amass.py:226-259): not on this path")
+            # batch_gen_amass.py:226-259 re-poses the body with a noisy orientation, but reads the poses from `pose_all`, which
+            # get_rec_list fills with the MARKER features (:208), so upstream that branch produces no usable bodies; no shipped
+            # config sets `noise` (train_GAMMAPredictor.py:49 has it commented out).  Nothing to reproduce.
+            raise NotImplementedError("next_batch(noise=...): the reference's augmentation branch is not usable upstream (see comment)")
         out = self.data_all[self.index_rec:self.index_rec + batch_size]
         self.index_rec += batch_size
         return out.permute(1, 0, 2).contiguous().to(self.device)   # [t,b,d]
