@@ -369,7 +369,7 @@ def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_
               "note": "in_loop includes the wait for the slowest rank; busbw = algbw * 2(N-1)/N (ring all-reduce)"}
     graphs_ok = bool(args.update_graph) and not any(v.get("failed") for v in policy._graph_cache.values())
     return {"elapsed": elapsed, "lbs_ms": ms_list, "env": env, "policy": policy, "allreduce": ar, "graphs_ok": graphs_ok,
-            "transitions": steps * n_vec * A * world}
+            "transitions": steps * n_vec * A * world, "update_paths": dict(policy.update_paths)}
 
 
 def _lbs_in_scene_ms(env, lib, reps=8):
@@ -516,7 +516,8 @@ def main():
                    "agents_total": total_agents, "agents_per_gpu": A, "scene": args.scene, "vec_steps_per_collect": args.vec_steps,
                    "minibatch_global": bs_local * world, "minibatch_per_gpu": bs_local,
                    "parallelism": f"dp{world}" if world > 1 else "single", "hip_graph_env": bool(args.graph),
-                   "hip_graph_update": m["graphs_ok"], "update": "hand-written launch chain (csrc/update3.hip)" if m["policy"]._train_handles else "autograd nodes + library GEMMs"},
+                   "hip_graph_update": m["graphs_ok"], "update": "hand-written launch chain (csrc/update3.hip)" if m["policy"]._train_handles else "autograd nodes + library GEMMs",
+                   "update_paths": m["update_paths"]},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
@@ -534,7 +535,8 @@ def main():
     if world > 1 and args.scaling == "strong" and args.also_weak:
         mw = _measure(args, world, rank, args.agents, args.batch_size, scene, ops, args.steps, args.warmup, with_lbs_events=False)
         result["weak"] = {"value": mw["transitions"] / mw["elapsed"], "unit": "env-steps/s", "ms_per_step": mw["elapsed"] / args.steps * 1e3,
-                          "agents_per_gpu": args.agents, "minibatch_per_gpu": args.batch_size, "allreduce": mw["allreduce"]}
+                          "agents_per_gpu": args.agents, "minibatch_per_gpu": args.batch_size, "allreduce": mw["allreduce"],
+                          "update_paths": mw["update_paths"]}
         del mw
         torch.cuda.empty_cache()
     if world == 1 and args.extra_configs and args.scene == "single_box" and args.agents == 512:

@@ -15,6 +15,7 @@
 //     (x W_ih^T and h W_hh^T), so the gate math runs in its epilogue (was: paired GEMM launch + pointwise launch).
 // Weights are packed once (motion prior: at load; policy: once per collect).
 #include <cstddef>
+#include <cstdlib>
 #include <mutex>
 #include "egx_nets.h"
 
@@ -23,11 +24,21 @@ namespace {
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef float f32x4a1 __attribute__((ext_vector_type(4), aligned(4)));
 
-// x[8] -> three bf16 planes (v_cvt_pk_bf16_f32, round to nearest even; the residuals are exact in fp32)
-__device__ __forceinline__ void d3_split(const float (&x)[8], bf16x8 (&pl)[3]) {
+// Arithmetic of a product ("prec" of D3Plain / D3Gru) = how many of the bf16 planes of each operand take part:
+//   prec 0: three planes, six partial products (2^-24 relative: fp32-equivalent)
+//   prec 2: two planes (hi, mid: 16 significant bits per operand), three partial products - the LBS blend GEMM's default mode
+//   prec 1: the leading plane only (operands rounded to bf16), one product - "bf16 MFMA, fp32 accumulate"
+// Accumulation, biases, activations and every fp32 output are the same in all three.  Images always have room for three
+// planes; a layer only READS the planes its mode uses and only WRITES those planes of the activation images it produces
+// (weight images and raw-input images always carry all three: they are shared with launches of other modes).
+__host__ __device__ constexpr int d3_planes(int prec) { return prec == 0 ? 3 : (prec == 2 ? 2 : 1); }
+
+// x[8] -> NP bf16 planes (v_cvt_pk_bf16_f32, round to nearest even; the residuals are exact in fp32)
+template <int NP = 3>
+__device__ __forceinline__ void d3_split(const float (&x)[8], bf16x8 (&pl)[NP]) {
   float r[8];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
+  for (int p = 0; p < NP; ++p) {
     bf16v8 h;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -39,23 +50,24 @@ __device__ __forceinline__ void d3_split(const float (&x)[8], bf16x8 (&pl)[3]) {
   }
 }
 
-// acc += a . b with the six significant partial products (mid.mid, hi.lo, lo.hi, hi.mid, mid.hi, hi.hi: small ones first);
-// `one`: the leading product only (operands rounded to bf16, fp32 accumulation - the "bf16 MFMA policy" of BASELINE config 5,
-// egx_policy_set_precision).  For a block of MI x NI output tiles, product-major: consecutive MFMAs go to different
-// accumulators, so none waits for the previous one's result.
-template <int MI, int NI>
-__device__ __forceinline__ void d3_mma_tiles(const bf16x8 (&fa)[MI][3], const bf16x8 (&fb)[NI][3], f32x4 (&acc)[MI][NI], bool one) {
-  if (one) {
+// acc += a . b with the significant partial products of the mode, small ones first (NPL = 3: mid.mid, hi.lo, lo.hi, hi.mid,
+// mid.hi, hi.hi; NPL = 2: hi.mid, mid.hi, hi.hi; NPL = 1: hi.hi).  For a block of MI x NI output tiles, product-major:
+// consecutive MFMAs go to different accumulators, so none waits for the previous one's result.
+template <int MI, int NI, int NPL>
+__device__ __forceinline__ void d3_mma_tiles(const bf16x8 (&fa)[MI][NPL], const bf16x8 (&fb)[NI][NPL], f32x4 (&acc)[MI][NI]) {
+  constexpr int NPROD = NPL == 3 ? 6 : (NPL == 2 ? 3 : 1);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
-    return;
-  }
-#pragma unroll
-  for (int pr = 0; pr < 6; ++pr) {
-    const int pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
-    const int pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
+  for (int pr = 0; pr < NPROD; ++pr) {
+    int pa, pb;
+    if (NPL == 3) {
+      pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
+      pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
+    } else if (NPL == 2) {
+      pa = (pr == 0) ? 0 : (pr == 1) ? 1 : 0;
+      pb = (pr == 0) ? 1 : (pr == 1) ? 0 : 0;
+    } else {
+      pa = pb = 0;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -181,7 +193,7 @@ __device__ __forceinline__ float d3_finish(const D3Plain& a, float v, int m, int
 // Packed images of a finished tile (values in `tile`, pitch TN + 4).  Row-major image (the consumer's A operand): 16-row tiles
 // MI mt + i, k-steps s30 + nt NI/2 + j.  Transposed image (rows = this layer's columns, reduction index = its rows - what a
 // weight-gradient product reads): row tiles NI nt + j, k-steps s3T0 + mt MI/2 + i.  One wave per fragment.
-template <int MI, int NI, int NW>
+template <int MI, int NI, int NW, int NPL>
 __device__ __forceinline__ void d3_write_packed(const D3Plain& a, const float* tile, int mt, int nt, int batch, int wave, int lane) {
   constexpr int PITCH = 16 * NI + 4;
   constexpr int NR = MI * (NI / 2), NTT = NI * (MI / 2);
@@ -206,10 +218,10 @@ __device__ __forceinline__ void d3_write_packed(const D3Plain& a, const float* t
       for (int e = 0; e < 8; ++e) x[e] = tile[(32 * i + 8 * kg + e) * PITCH + c];
       o = a.out3T + ((size_t)(NI * nt + j) * a.S3T + a.s3T0 + mt * (MI / 2) + i) * 3 * 64 + lane;
     }
-    bf16x8 pl[3];
-    d3_split(x, pl);
+    bf16x8 pl[NPL];
+    d3_split<NPL>(x, pl);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+    for (int p = 0; p < NPL; ++p) o[p * 64] = pl[p];
   }
 }
 
@@ -244,7 +256,7 @@ __device__ __forceinline__ D3Plain d3_pick(int which) {
 }
 
 // MI x NI MFMA tiles of 16 x 16 per workgroup of NW waves (instantiated: 2 x 2 tiles, four waves).
-template <int TRIP, int MI, int NI, int NW>
+template <int TRIP, int MI, int NI, int NW, int NPL>
 __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
   constexpr int TM = 16 * MI, TN = 16 * NI, NACC = MI * NI * 4, PITCH = TN + 4;
   const int bx = (int)blockIdx.x;
@@ -263,7 +275,6 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
   const bf16x8* Ab = a.A + (size_t)batch * a.batch_strideA;
   const int per = (a.S + NW - 1) / NW;
   const int s_lo = wave * per, s_hi = min(a.S, s_lo + per);
-  const bool one = a.prec != 0;
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -279,12 +290,12 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
 #pragma unroll
   for (int j = 0; j < NI; ++j) pb[j] = a.B + (size_t)min(NI * nt + j, b_tiles - 1) * a.S * 3 * 64 + lane;
   for (int s = s_lo; s < s_hi; s += TRIP) {
-    bf16x8 fa[TRIP][MI][3], fb[TRIP][NI][3];
+    bf16x8 fa[TRIP][MI][NPL], fb[TRIP][NI][NPL];
 #pragma unroll
     for (int u = 0; u < TRIP; ++u) {
       const int su = min(s + u, s_hi - 1);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) fa[u][i][p] = pa[i][(size_t)(su * 3 + p) * 64];
 #pragma unroll
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
 #pragma unroll
     for (int u = 0; u < TRIP; ++u) {
       if (s + u >= s_hi) break;
-      d3_mma_tiles<MI, NI>(fa[u], fb[u], acc, one);
+      d3_mma_tiles<MI, NI, NPL>(fa[u], fb[u], acc);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
   }
   if (!a.out3 && !a.out3T) return;
   __syncthreads();
-  d3_write_packed<MI, NI, NW>(a, tile, mt, nt, batch, wave, lane);
+  d3_write_packed<MI, NI, NW, NPL>(a, tile, mt, nt, batch, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -346,7 +357,7 @@ struct D3Gru2 {
   D3Gru g0, g1;
   int blocks0;   // blocks [0, blocks0) work on g0, the rest on g1 (the policy's two encoders)
 };
-template <int TRIP>
+template <int TRIP, int NPL>
 __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
   const bool second = (int)blockIdx.x >= two.blocks0;
   const D3Gru& a = second ? two.g1 : two.g0;
@@ -380,12 +391,12 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) pb[g] = B + (size_t)(g * CT + ct) * S * 3 * 64 + lane;
     for (int s = s_lo; s < s_hi; s += TRIP) {
-      bf16x8 fa[TRIP][2][3], fb[TRIP][3][3];
+      bf16x8 fa[TRIP][2][NPL], fb[TRIP][3][NPL];
 #pragma unroll
       for (int u = 0; u < TRIP; ++u) {
         const int su = min(s + u, s_hi - 1);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) fa[u][mi][p] = pa[mi][(size_t)(su * 3 + p) * 64];
 #pragma unroll
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
 #pragma unroll
       for (int u = 0; u < TRIP; ++u) {
         if (s + u >= s_hi) break;
-        d3_mma_tiles<2, 3>(fa[u], fb[u], acc[sd], a.prec != 0);
+        d3_mma_tiles<2, 3, NPL>(fa[u], fb[u], acc[sd]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -458,11 +469,11 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
     float x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = tile[(8 * kg + e) * 20 + c];
-    bf16x8 pl[3];
-    d3_split(x, pl);
+    bf16x8 pl[NPL];
+    d3_split<NPL>(x, pl);
     bf16x8* o = a.h_out3T + ((size_t)((a.col0T >> 4) + ct) * a.S3T + a.s3T0 + mt) * 3 * 64 + lane;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+    for (int p = 0; p < NPL; ++p) o[p * 64] = pl[p];
   }
   if (a.h_out3) {
     // 16 columns = k groups 2 (ct & 1), 2 (ct & 1) + 1 of k-step s30 + ct / 2: half of the lanes of each fragment
@@ -470,11 +481,11 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
       const int row = 16 * wave + (lane & 15), g = lane >> 4;   // g in {0, 1}
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(&tile[row * 20 + 8 * g]), x1 = *reinterpret_cast<const f32x4*>(&tile[row * 20 + 8 * g + 4]);
       const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      bf16x8 pl[3];
-      d3_split(x, pl);
+      bf16x8 pl[NPL];
+      d3_split<NPL>(x, pl);
       bf16x8* o = a.h_out3 + ((size_t)(2 * mt + wave) * a.S3 + a.s30 + (ct >> 1)) * 3 * 64 + 32 * (ct & 1) + lane;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+      for (int p = 0; p < NPL; ++p) o[p * 64] = pl[p];
     }
   }
 }
@@ -780,7 +791,7 @@ int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, 
 
 // ---- launchers ------------------------------------------------------------------------------------------
 namespace {
-template <int TRIP, int MI, int NI, int NW>
+template <int TRIP, int MI, int NI, int NW, int NPL>
 void d3_launch_cfg(hipStream_t st, const D3Plain* ps, int n) {
   constexpr int TM = 16 * MI, TN = 16 * NI;
   constexpr size_t lds = (size_t)(NW * MI * NI * 4 * 64 + TM * (TN + 4)) * sizeof(float);
@@ -792,7 +803,7 @@ void d3_launch_cfg(hipStream_t st, const D3Plain* ps, int n) {
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
       std::lock_guard<std::mutex> lk(mu);
       if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_dense3_kernel<TRIP, MI, NI, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&egx_dense3_kernel<TRIP, MI, NI, NW, NPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
       }
@@ -807,18 +818,44 @@ void d3_launch_cfg(hipStream_t st, const D3Plain* ps, int n) {
     ends[i] = total;
   }
   f.end0 = ends[0]; f.end1 = ends[1]; f.end2 = ends[2];
-  hipLaunchKernelGGL((egx_dense3_kernel<TRIP, MI, NI, NW>), dim3(total), dim3(64 * NW), lds, st, f);
+  hipLaunchKernelGGL((egx_dense3_kernel<TRIP, MI, NI, NW, NPL>), dim3(total), dim3(64 * NW), lds, st, f);
+}
+
+// k-steps per burst of the deep (S > 16) layers in the two- and one-plane modes: development knobs, read once
+int d3_env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : dflt;
 }
 }  // namespace
 
 // 32 x 32 tile per 4-wave workgroup, the reduction split over the waves; three k-steps per round trip for deep reductions.
 // (Measured for the update's 1152-deep layers, profiles/r03_update_experiments.md: 64 x 64 and 64 x 32 tiles, eight-wave
 // split-K, a software-pipelined loop and two k-steps per trip all land within a few per cent of this form or behind it.)
+// All layers of a launch share the arithmetic mode of the first (the callers build them from one setting).
 void egx_launch_dense3_n(hipStream_t st, const D3Plain* ps, int n) {
   int smax = 0;
   for (int i = 0; i < n; ++i) smax = std::max(smax, ps[i].S);
-  if (smax > 16) d3_launch_cfg<3, 2, 2, 4>(st, ps, n);
-  else d3_launch_cfg<2, 2, 2, 4>(st, ps, n);
+  const bool deep = smax > 16;
+  switch (ps[0].prec) {
+    case 2: {
+      static const int trip = d3_env_int("EGX_D3_TRIP_P2", 3);
+      if (!deep) d3_launch_cfg<2, 2, 2, 4, 2>(st, ps, n);
+      else if (trip >= 5) d3_launch_cfg<5, 2, 2, 4, 2>(st, ps, n);
+      else d3_launch_cfg<3, 2, 2, 4, 2>(st, ps, n);
+      break;
+    }
+    case 1: {
+      static const int trip = d3_env_int("EGX_D3_TRIP_P1", 5);
+      if (!deep) d3_launch_cfg<2, 2, 2, 4, 1>(st, ps, n);
+      else if (trip >= 9) d3_launch_cfg<9, 2, 2, 4, 1>(st, ps, n);
+      else if (trip >= 5) d3_launch_cfg<5, 2, 2, 4, 1>(st, ps, n);
+      else d3_launch_cfg<3, 2, 2, 4, 1>(st, ps, n);
+      break;
+    }
+    default:
+      if (deep) d3_launch_cfg<3, 2, 2, 4, 3>(st, ps, n);
+      else d3_launch_cfg<2, 2, 2, 4, 3>(st, ps, n);
+  }
 }
 void egx_launch_dense3(hipStream_t st, const D3Plain& p) { egx_launch_dense3_n(st, &p, 1); }
 void egx_launch_dense3_pair(hipStream_t st, const D3Plain& p, const D3Plain& q) {
@@ -835,7 +872,11 @@ static void d3_launch_gru(hipStream_t st, const D3Gru& g0, const D3Gru* g1) {
   two.g0 = g0; two.g1 = g1 ? *g1 : g0;
   two.blocks0 = d3_blocks((g0.M + 31) >> 5, g0.H >> 4);
   const int total = two.blocks0 + (g1 ? d3_blocks((g1->M + 31) >> 5, g1->H >> 4) : 0);
-  hipLaunchKernelGGL(egx_gru3_kernel<2>, dim3(total), dim3(256), lds, st, two);
+  switch (g0.prec) {
+    case 2: hipLaunchKernelGGL((egx_gru3_kernel<2, 2>), dim3(total), dim3(256), lds, st, two); break;
+    case 1: hipLaunchKernelGGL((egx_gru3_kernel<4, 1>), dim3(total), dim3(256), lds, st, two); break;
+    default: hipLaunchKernelGGL((egx_gru3_kernel<2, 3>), dim3(total), dim3(256), lds, st, two);
+  }
 }
 int egx_launch_gru3(hipStream_t st, const D3Gru& g) {
   d3_launch_gru(st, g, nullptr);

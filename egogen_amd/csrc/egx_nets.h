@@ -81,7 +81,8 @@ struct D3Plain {
   int batches = 1;
   size_t batch_strideA = 0, batch_stride3 = 0;
   int batch_rows_out = 0;
-  int prec = 0;   // 0: six partial products (fp32-equivalent); 1: leading product only (operands rounded to bf16)
+  int prec = 0;   // 0: three planes, six partial products (fp32-equivalent); 2: two planes, three products (16 operand bits);
+                  // 1: leading plane only (operands rounded to bf16).  See dense3.hip::d3_planes.
   // ---- training (update3.hip)
   float* out_act = nullptr;       // fp32 [M, N] (ld ldact): the activation BEFORE the residual is added (saved for backward)
   int ldact = 0;

@@ -279,7 +279,8 @@ extern "C" size_t egx_policy_workspace_bytes(int n) {
 }
 
 extern "C" int egx_policy_set_precision(int bf16) {
-  EGX_REQUIRE(bf16 == 0 || bf16 == 1, "precision must be 0 (fp32 MFMA) or 1 (bf16 operands, fp32 accumulate)");
+  EGX_REQUIRE(bf16 == 0 || bf16 == 1 || bf16 == 2,
+              "precision must be 0 (fp32-equivalent), 2 (operands as two bf16 terms) or 1 (bf16 operands), fp32 accumulate in all");
   g_policy_bf16.store(bf16);
   return EGX_OK;
 }

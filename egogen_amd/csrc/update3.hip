@@ -226,6 +226,7 @@ struct egx_policy_train {
   PackEntry* tab_loss = nullptr; int n_loss = 0, frags_loss = 0;
   std::vector<PackEntry> h_inputs;   // host copy: the source pointers of the observation change per call
   const float* bound_state = nullptr; const float* bound_ego = nullptr;
+  int prec = 0;   // arithmetic of every product of the chain (D3Plain::prec): egx_policy_train_set_precision
 };
 
 namespace {
@@ -319,7 +320,10 @@ extern "C" int egx_policy_train_create(const egx_policy_weights* w, const egx_po
     egx_set_error("egx_policy_train_create: device allocation failed");
     return EGX_ERR_HIP;
   }
-  EGX_HIP_CHECK(hipMemset(h->ar.base, 0, h->ar.cap));
+  // every failure below releases the handle, its arena and whatever tables were uploaded (the caller never sees `h`)
+  auto fail = [&](int rc_) { egx_policy_train_destroy(h); return rc_; };
+#define U3_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { egx_set_error(std::string("egx_policy_train_create: ") + hipGetErrorString(e_)); return fail(EGX_ERR_HIP); } } while (0)
+  U3_CHECK(hipMemset(h->ar.base, 0, h->ar.cap));
   layout(h);
   const int n = h->n, Sn = h->Sn;
   // rows of ones of the transposed activation images the epilogues fill (the tables write their own)
@@ -330,6 +334,7 @@ extern "C" int egx_policy_train_create(const egx_policy_weights* w, const egx_po
   ones(h->catT, CAT, Sn, 0, Sn);
   for (int b = 0; b < 2; ++b)
     for (bf16x8* img : {h->br[b].a1T, h->br[b].u1T, h->br[b].a3T, h->br[b].u2T}) ones(img, CAT, Sn, 0, Sn);
+  U3_CHECK(hipGetLastError());
   // ---- pack tables
   std::vector<PackEntry> tw;
   auto add = [](std::vector<PackEntry>& v, const float* src, int red, int cols, int ld, int col0, bf16x8* dst, int S_total, int s0,
@@ -356,7 +361,7 @@ extern "C" int egx_policy_train_create(const egx_policy_weights* w, const egx_po
   }
   h->n_weights = (int)tw.size();
   int rc = upload_table(tw, &h->tab_weights, &h->frags_weights);
-  if (rc) return rc;
+  if (rc) return fail(rc);
   // inputs: the two frames of every encoder as operands, and [frame 0; frame 1]^T (+ ones) for the weight gradient of W_ih
   for (int e = 0; e < 2; ++e) {
     Encoder& En = h->enc[e];
@@ -374,8 +379,9 @@ extern "C" int egx_policy_train_create(const egx_policy_weights* w, const egx_po
     add(tl, B.ghead, n, B.nout, B.nout, 0, B.gheadT, Sn, 0, 1, -1);
   }
   h->n_loss = (int)tl.size();
-  if ((rc = upload_table(tl, &h->tab_loss, &h->frags_loss))) return rc;
-  EGX_HIP_CHECK(hipDeviceSynchronize());
+  if ((rc = upload_table(tl, &h->tab_loss, &h->frags_loss))) return fail(rc);
+  U3_CHECK(hipDeviceSynchronize());
+#undef U3_CHECK
   *out = h;
   return EGX_OK;
 }
@@ -390,6 +396,13 @@ extern "C" int egx_policy_train_refresh(egx_policy_train* h, void* stream) {
   EGX_REQUIRE(h, "null handle");
   run_table(static_cast<hipStream_t>(stream), h->tab_weights, h->n_weights, h->frags_weights);
   EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
+extern "C" int egx_policy_train_set_precision(egx_policy_train* h, int prec) {
+  EGX_REQUIRE(h, "null handle");
+  EGX_REQUIRE(prec == 0 || prec == 1 || prec == 2, "precision must be 0 (three bf16 planes: fp32-equivalent), 2 (two planes) or 1 (bf16)");
+  h->prec = prec;
   return EGX_OK;
 }
 
@@ -423,6 +436,15 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
   const int n = h->n, Sn = h->Sn;
   constexpr int S_HD = HD / 32, S_CAT = CAT / 32, S_G = 3 * HD / 32;
   const float slope = 0.01f;   // torch.nn.LeakyReLU() default (baseops.py:627-628)
+  const int prec = h->prec;
+  auto launch_n = [prec](hipStream_t s_, D3Plain* ps, int cnt) {
+    for (int i = 0; i < cnt; ++i) ps[i].prec = prec;
+    egx_launch_dense3_n(s_, ps, cnt);
+  };
+  auto launch_gru = [prec](hipStream_t s_, D3Gru& g0, D3Gru& g1) {
+    g0.prec = g1.prec = prec;
+    return egx_launch_gru3_pair(s_, g0, g1);
+  };
 
   // ================= forward =================
   run_table(st, h->tab_inputs, h->n_inputs, h->frags_inputs);
@@ -438,7 +460,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
       q.gi_out = E.gi1; q.h_out = E.h1f; q.ldo = HD; q.h_out3 = E.h1_r; q.S3 = S_HD;
       q.h_out3T = E.hprevT; q.S3T = 2 * Sn; q.s3T0 = Sn; q.col0T = 0;
     }
-    egx_launch_gru3_pair(st, g[0], g[1]);
+    launch_gru(st, g[0], g[1]);
     for (int e = 0; e < 2; ++e) {   // step 2 -> [hx | he | pe]
       Encoder& E = h->enc[e];
       D3Gru& q = g[e];
@@ -447,7 +469,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
       q.h_out = h->catf + E.cat_off; q.ldo = CAT; q.h_out3 = h->cat_r; q.S3 = S_CAT; q.s30 = E.cat_off / 32;
       q.h_out3T = h->catT; q.S3T = Sn; q.s3T0 = 0; q.col0T = E.cat_off;
     }
-    egx_launch_gru3_pair(st, g[0], g[1]);
+    launch_gru(st, g[0], g[1]);
   }
   {
     D3Plain L[2];
@@ -468,7 +490,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
         q.res = res[b]; q.ldr = CAT; q.out = outf[b]; q.ldo = CAT;
         q.out3 = o3[b]; q.S3 = S_CAT; q.out3T = o3T[b]; q.S3T = Sn;
       }
-      egx_launch_dense3_n(st, L, 2);
+      launch_n(st, L, 2);
     };
     Branch &Ba = h->br[0], &Bc = h->br[1];
     // h = hx; per unit: h = lrelu(fc2(lrelu(fc1(h)))) + h   (models_policy_ppo.py:24-39, baseops.py:615-641)
@@ -482,7 +504,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
       q = D3Plain();
       q.M = n; q.N = B.nout; q.A = B.u2_r; q.SA = S_CAT; q.S = S_CAT; q.B = B.Wout_r; q.bias = B.bout; q.out = B.head; q.ldo = B.nout;
     }
-    egx_launch_dense3_n(st, L, 2);
+    launch_n(st, L, 2);
   }
   // ================= loss and its gradient w.r.t. the two heads (ppo_policy.py:189-241) =================
   int rc = egx_ppo_loss_packed(h->br[0].head, h->br[1].head, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_logvar, max_logvar,
@@ -501,7 +523,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
   Branch &Ba = h->br[0], &Bc = h->br[1];
   D3Plain W[4], D[2];
   for (int b = 0; b < 2; ++b) wgrad(W[b], h->br[b].gheadT, h->br[b].u2T, h->br[b].nout, h->br[b].gWout, h->br[b].gbout);
-  egx_launch_dense3_n(sw, W, 2);
+  launch_n(sw, W, 2);
   // input gradient of one layer for both blocks: d = g_in W^T-image (+ skip) -> fp32 `out` raw, images gated by act'(a[gate])
   auto dgrad = [&](const bf16x8* const (&gin)[2], const int (&S_in)[2], const bf16x8* const (&Wt)[2], float* const (&res)[2],
                    float* const (&outf)[2], int gate, int lout) {
@@ -516,7 +538,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
         d.out3 = B.g_r[lout]; d.S3 = S_CAT; d.out3T = B.gT[lout]; d.S3T = Sn;
       }
     }
-    egx_launch_dense3_n(st, D, 2);
+    launch_n(st, D, 2);
   };
   const int S_head[2] = {egx_ceil_div(Ba.nout, 32), egx_ceil_div(Bc.nout, 32)}, S_full[2] = {S_CAT, S_CAT};
   float* const none[2] = {nullptr, nullptr};
@@ -549,8 +571,8 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
     bf16x8* const x0[2] = {h->catT, h->catT};
     float* const dhx[2] = {Ba.dhx, Bc.dhx};
     if ((rc = layer_bwd(0, x0, du1, dhx, -1))) return rc;                     // dhx = g1 W1 + du1
-    egx_launch_dense3_n(sw, WL, 4);
-    egx_launch_dense3_n(sw, WL + 4, 4);
+    launch_n(sw, WL, 4);
+    launch_n(sw, WL + 4, 4);
   }
   // ---- the two GRU encoders (dhx = actor's + critic's)
   {
@@ -573,7 +595,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
       d = D3Plain();
       d.M = n; d.N = HD; d.A = E.dgh_r; d.SA = S_G; d.S = S_G; d.B = E.Whh_t; d.res = E.dhp; d.ldr = HD; d.out = E.dh1; d.ldo = HD;
     }
-    egx_launch_dense3_n(st, P, 2);
+    launch_n(st, P, 2);
     for (int e = 0; e < 2; ++e) {   // step 1 (h0 = 0: gh = b_hh)
       Encoder& E = h->enc[e];
       GruBwd& q = *gb[e];
@@ -592,7 +614,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
       c.M = 3 * HD; c.N = HD + 1; c.A = E.dghT; c.SA = 2 * Sn; c.S = 2 * Sn; c.B = E.hprevT; c.out = E.gWhh; c.ldo = HD;
       c.n_split = HD; c.bias_out = E.gbhh;
     }
-    egx_launch_dense3_n(sw, P, 4);
+    launch_n(sw, P, 4);
   }
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;

@@ -25,6 +25,7 @@ from .models import ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase, Polic
 
 _EPS = float(np.finfo(np.float32).eps)  # tianshou BasePolicy._eps
 _LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
+_UPDATE_PREC = {"f32": 0, "bf16x2": 2, "bf16": 1}
 
 
 class RolloutBatch:
@@ -94,6 +95,11 @@ class GAMMAPPOPolicy(nn.Module):
         # the minibatch as a fixed chain of hand-written launches (csrc/update3.hip); EGX_TRAIN_STEP=0: the autograd nodes
         self.use_train_step = bool(_ignored.get("use_train_step", os.environ.get("EGX_TRAIN_STEP", "1") != "0"))
         self._train_handles: dict = {}
+        # arithmetic of the chain's products (egx_policy_train_set_precision): "f32" = three bf16 terms per operand (2^-24),
+        # "bf16x2" = two terms, "bf16" = operands rounded to bf16; fp32 accumulation and fp32 gradients in all of them
+        self.update_precision = str(_ignored.get("update_precision", os.environ.get("EGX_UPDATE_PREC", "f32")))
+        if self.update_precision not in _UPDATE_PREC:
+            raise ValueError(f"update_precision must be one of {sorted(_UPDATE_PREC)}, got {self.update_precision!r}")
         # dense layers of the update as LinearFn nodes (library GEMMs + fused activation / bias-gradient / accumulation
         # kernels).  Their weight gradients are ACCUMULATED into the flat buffer: callers zero it once per minibatch.
         self.use_fused_linear = bool(_ignored.get("use_fused_linear", True))
@@ -101,6 +107,7 @@ class GAMMAPPOPolicy(nn.Module):
         self.use_flat_optimizer = bool(_ignored.get("use_flat_optimizer", os.environ.get("EGX_FLAT_OPTIMIZER", "1") != "0"))
         self._flat_opt_state = None
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.update_paths: dict = {}       # minibatches of learn() by formulation: "chain", "chain+graph", "autograd", "autograd+graph"
         self.allreduce_events: list = []   # [(start, stop)] torch.cuda.Event pairs, one consumed per gradient all-reduce
         self._allreduce_done: list = []
 
@@ -241,11 +248,18 @@ class GAMMAPPOPolicy(nn.Module):
         """`egx_policy_train` for minibatches of n rows, or None where the hand-written step does not apply (CPU tensors, a
         minibatch that is not a multiple of 32 rows, an optimiser the flat AdamW kernel does not cover, ablation switches)."""
         if not (self.use_train_step and self.use_fused_loss and self.use_fused_linear and n % 32 == 0 and self.actor.z_dim == 128
-                and self._flat_opt_state == "ready" and self._flat_grad is not None and self._flat_grad.is_cuda and self._norm_adv):
+                and self._flat_opt_state == "ready" and self._flat_grad is not None and self._flat_grad.is_cuda and self._norm_adv
+                and self._chain_shapes_ok()):
             return None
         hs = self._train_handles.get(n)
         if hs is not None:
             return hs
+        if self._graph_cache:
+            # a captured (clip + AdamW + image refresh) graph re-makes the images of the handles that existed at capture time
+            # only: a handle created later (the merged last minibatch of a pass has its own size) would keep forwarding
+            # through weights that are k - 1 optimiser steps old.  Drop the graphs; the next minibatch re-captures them with
+            # every handle in the refresh.
+            self._graph_cache.clear()
         lib = _lib.load()
         self._ensure_flat_grads()
         w = self._runner._weights()
@@ -263,6 +277,7 @@ class GAMMAPPOPolicy(nn.Module):
         g.critic_out_w, g.critic_out_b = gp(c.out_fc.weight), gp(c.out_fc.bias)
         h = C.c_void_p()
         _lib.check(lib.egx_policy_train_create(C.byref(w), C.byref(g), int(n), C.byref(h)), "egx_policy_train_create")
+        _lib.check(lib.egx_policy_train_set_precision(h, _UPDATE_PREC[self.update_precision]), "egx_policy_train_set_precision")
         dev = self._flat_grad.device
         f = dict(dtype=torch.float32, device=dev)
         bufs = [torch.empty(n, 804, **f), torch.empty(n, 64, **f), torch.empty(n, 1, **f), torch.empty(n, 1, **f),
@@ -277,6 +292,21 @@ class GAMMAPPOPolicy(nn.Module):
             self._images_owner = n
         self._refresh_images()
         return hs
+
+    def _chain_shapes_ok(self) -> bool:
+        """csrc/update3.hip is written for the released policy: two 512-wide GRU encoders, 2 residual units of two 1152-wide
+        layers with LeakyReLU(0.01), a 256-wide actor head and a scalar critic head.  Anything else trains through the
+        autograd nodes."""
+        ok = getattr(self, "_chain_ok", None)
+        if ok is None:
+            a, c, s = self.actor.pnet, self.critic.vnet, self.shared_net
+            def block_ok(blk, nout):
+                return (blk.residual and len(blk.layers) == 2 and blk.out_fc.out_features == nout and blk.out_fc.in_features == 1152
+                        and all(m.act_name == "lrelu" and len(m.layers) == 2 and
+                                all(fc.in_features == 1152 and fc.out_features == 1152 for fc in m.layers) for m in blk.layers))
+            ok = (s.h_dim == 512 and s.x_enc.input_size == 402 and s.ego_enc.input_size == 32 and block_ok(a, 256) and block_ok(c, 1))
+            self._chain_ok = ok
+        return ok
 
     def _drop_train_handles(self):
         lib = _lib.load() if self._train_handles else None
@@ -327,11 +357,13 @@ class GAMMAPPOPolicy(nn.Module):
                                        _lib.ptr(log_out), st)
         _lib.check(rc, "egx_policy_train_step")
 
-    def _fwd_bwd(self, batch, idx, gstats, log_out):
+    def _fwd_bwd(self, batch, idx, gstats, log_out) -> str:
+        """Forward, loss and backward of one minibatch into the flat gradient; returns which formulation ran ("chain": the
+        hand-written launch chain of csrc/update3.hip, "autograd": the autograd nodes)."""
         hs = self._train_handle(int(idx.shape[0])) if idx.is_cuda else None
         if hs is not None:
             self._fwd_bwd_train_step(hs, batch, idx, gstats, log_out)
-            return
+            return "chain"
         obs, act, adv, ret, lpo = self._gather(batch, idx)
         loss, terms = self.minibatch_loss(obs, act, adv, ret, lpo, gstats)
         self._flat_grad.zero_()
@@ -347,6 +379,7 @@ class GAMMAPPOPolicy(nn.Module):
             log_out.copy_(packed)
         else:
             log_out.copy_(torch.stack([terms[k].detach() for k in ("loss", "loss/clip", "loss/vf", "loss/ent", "loss/kld", "approx_kl")]))
+        return "autograd"
 
     def _clip_and_step(self):
         if self.use_flat_optimizer and self._flat_opt_state == "ready":
@@ -499,11 +532,11 @@ class GAMMAPPOPolicy(nn.Module):
             g2 = None
             if self.world_size == 1:
                 with torch.cuda.graph(g1):
-                    self._fwd_bwd(batch, st["idx"], gs(), st["log"])
+                    st["path"] = self._fwd_bwd(batch, st["idx"], gs(), st["log"])
                     self._clip_and_step()
             else:
                 with torch.cuda.graph(g1):
-                    self._fwd_bwd(batch, st["idx"], gs(), st["log"])
+                    st["path"] = self._fwd_bwd(batch, st["idx"], gs(), st["log"])
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, pool=g1.pool()):
                     self._clip_and_step()
@@ -602,16 +635,18 @@ class GAMMAPPOPolicy(nn.Module):
                         self._all_reduce_grad()
                         st["g2"].replay()
                     last_log = st["log"].clone()
+                    self.update_paths[st["path"] + "+graph"] = self.update_paths.get(st["path"] + "+graph", 0) + 1
                 else:
                     gstats = None
                     if ws > 1:
                         gstats = (gstats_all[i, 0], gstats_all[i, 1], gstats_all[i, 2])
                     log = torch.zeros(6, device=dev)
-                    self._fwd_bwd(batch, idx, gstats, log)
+                    path = self._fwd_bwd(batch, idx, gstats, log)
                     if ws > 1:
                         self._all_reduce_grad()
                     self._clip_and_step()
                     last_log = log
+                    self.update_paths[path] = self.update_paths.get(path, 0) + 1
                 logs.append(last_log[:5])
             # early stop on the last minibatch's approximate KL (ppo_policy.py:252-257); inert at repeat=1
             if repeat > 1 and last_log is not None:

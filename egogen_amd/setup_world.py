@@ -212,7 +212,8 @@ def build_policy(args, device="cuda", policy_cfg: Optional[dict] = None) -> GAMM
                             weight_kld=args.weight_kld, reward_normalization=args.rew_norm, eps_clip=args.eps_clip,
                             value_clip=args.value_clip, dual_clip=args.dual_clip, advantage_normalization=args.norm_adv,
                             recompute_advantage=args.recompute_adv, deterministic_eval=args.deterministic_eval, seed=args.seed,
-                            use_update_graph=graph)
+                            use_update_graph=graph,
+                            **({"update_precision": args.update_precision} if getattr(args, "update_precision", None) else {}))
     return policy
 
 

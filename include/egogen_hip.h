@@ -363,11 +363,17 @@ int egx_policy_train_step(egx_policy_train* h, const float* dist, const float* t
                           const float* ret, const float* logp_old, const float* adv_stats, const float* scale, float adv_eps,
                           float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef, float* out_terms,
                           void* stream);
+/* Arithmetic of every product of the chain (forward, input gradients, weight gradients): 0 = each fp32 operand as three bf16
+ * terms, six partial products (2^-24 relative: fp32-equivalent; default), 2 = two terms, three products (16 significant bits
+ * per operand, the arithmetic of the LBS blend GEMM's default mode), 1 = operands rounded to bf16, one product ("bf16 MFMA"
+ * of north_star).  fp32 accumulation, biases, activations, loss and all gradients OUTPUTS are fp32 in every mode.  Measured
+ * against a float64 evaluation of crowd_ppo/ppo_policy.py:189-241 in tests/test_trainer_gpu.py (profiles/r04_p3_yardstick.txt). */
+int egx_policy_train_set_precision(egx_policy_train* h, int prec);
 
-/* Arithmetic of the dense layers inside egx_policy_forward (process-wide): 0 = fp32 MFMA (default; 1e-4 parity with the
- * reference's fp32 policy), 1 = operands rounded to bf16, products on the bf16 MFMA, fp32 accumulation - BASELINE config 5
- * ("main_crowd_eval ... bf16 MFMA policy"), whose parity is statistical.  Gate math, biases, activations
- * and outputs stay fp32. */
+/* Arithmetic of the dense layers inside egx_policy_forward (process-wide): 0 = fp32-equivalent (default; 1e-4 parity with the
+ * reference's fp32 policy), 2 = operands as two bf16 terms (16 significant bits, three partial products), 1 = operands
+ * rounded to bf16, products on the bf16 MFMA, fp32 accumulation - BASELINE config 5 ("main_crowd_eval ... bf16 MFMA
+ * policy"), whose parity is statistical.  Gate math, biases, activations and outputs stay fp32. */
 int egx_policy_set_precision(int bf16);
 int egx_policy_get_precision(void);
 

@@ -1,7 +1,9 @@
 """GPU tests of the world_size > 1 path (BASELINE configs[3]): two ranks share ONE device and talk over
-gloo (RCCL refuses two ranks on one GPU); the code under test - the fused, HIP-graph-replayed PPO update with the
-advantage-moment and flat-gradient all-reduces between its two graphs, and bench.py's rank launcher - is the code the
-8-GPU run executes over RCCL."""
+gloo (RCCL refuses two ranks on one GPU); the code under test - the hand-written update chain (`egx_policy_train_step`,
+csrc/update3.hip) with global advantage statistics, replayed as two HIP graphs per minibatch with the flat-gradient all-reduce
+between them and the weight-image refresh inside the second, and bench.py's rank launcher - is the code the 8-GPU run executes
+over RCCL.  Per-rank minibatches are 32 / 64 rows (multiples of 32: otherwise `_train_handle()` returns None and the autograd
+nodes run instead - every test here asserts that this did NOT happen)."""
 import json
 import os
 import subprocess
@@ -42,80 +44,151 @@ def _make_policy(graph):
     return sw.build_policy(a)
 
 
-def _dp_worker(rank, world, port, n_local, n_steps, out_path):
+def _flat(b, name):
+    t = getattr(b, name)[:b.n]            # observations hold n + 1 time rows (the one after the last step)
+    return t.reshape((b.n * b.A,) + tuple(t.shape[2:]))
+
+
+def _probe_obs(n=32):
+    g = torch.Generator().manual_seed(555)
+    return {"state": (torch.randn(n, 2, 402, generator=g) * 0.3).cuda(), "egosensing": (torch.rand(n, 2, 32, generator=g) * 2 - 1).cuda(),
+            "dist": torch.rand(n, generator=g).cuda(), "time": torch.rand(n, generator=g).cuda()}
+
+
+def _dp_worker(rank, world, port, n_local, n_steps, n_learn, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from egogen_amd.models import PolicyHipRunner
     from egogen_amd.ppo_policy import RolloutBatch
     pol = _make_policy(True)
     assert pol.world_size == world
     b = RolloutBatch(n_steps, n_local, "cuda")
     _fill(b, 100 + rank, pol)
     pol._perm_gen.manual_seed(7)
-    losses = pol.learn(b, n_local * world, 1)                   # n_steps global minibatches of n_local * world rows
+    losses, grads = [], []
+    for _ in range(n_learn):
+        losses += pol.learn(b, n_local * world, 1)["loss"]      # n_steps global minibatches of n_local * world rows per pass
+        grads.append(pol._flat_grad.cpu().clone())
+    # the code under test is the hand-written chain (csrc/update3.hip) replayed as two graphs per minibatch - NOT the autograd
+    # fallback, which is what every per-rank minibatch that is not a multiple of 32 rows silently takes
+    assert set(pol._train_handles) == {n_local}, pol._train_handles.keys()
+    assert pol.update_paths == {"chain+graph": n_steps * n_learn}, pol.update_paths
     assert not any(v.get("failed") for v in pol._graph_cache.values()), "graph capture fell back to eager"
-    assert all(v.get("g2") is not None for v in pol._graph_cache.values()), "world > 1 must replay two graphs per minibatch"
-    if rank == 0:
-        torch.save({"grad": pol._flat_grad.cpu(), "loss": losses["loss"],
-                    "sd": {k: v.cpu() for k, v in pol.state_dict().items()}}, out_path)
+    assert all(v.get("g1") is not None and v.get("g2") is not None and v.get("path") == "chain" for v in pol._graph_cache.values()), \
+        "world > 1 must replay two graphs per minibatch around the all-reduce"
+    # the weight images the next rollout forward reads were re-made by the last replay of the second graph
+    probe = _probe_obs()
+    o_live = pol._runner.forward(probe)
+    o_fresh = PolicyHipRunner(pol.shared_net, pol.actor, pol.critic).forward(probe)   # packs the CURRENT parameters itself
+    for k in ("mu", "logvar", "value"):
+        assert torch.equal(o_live[k], o_fresh[k]), f"rank {rank}: rollout forward after learn() reads stale weight images ({k})"
+    torch.save({"grads": grads, "loss": losses, "sd": {k: v.cpu() for k, v in pol.state_dict().items()},
+                "mu": o_live["mu"].cpu(), "value": o_live["value"].cpu()}, out_path + f".{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_graph_replayed_update_equals_single_process(tmp_path):
-    """GPU twin of tests/test_ppo_cpu.py::test_data_parallel_update_equals_single_process, through the fused custom-autograd
-    update replayed as two HIP graphs per minibatch with the all-reduces between them."""
+def _single_process_reference(world, n_local, n_steps, n_learn):
+    """One process, eager, on the data of both ranks.  Every rank walks the SAME permutation of its local rows (shared seed),
+    so global minibatch k of a pass = rows perm[k-th span] of every rank: per pass the ranks' data are laid out so that the
+    identity permutation reproduces exactly those minibatches."""
     from egogen_amd.ppo_policy import RolloutBatch
-    world, n_local, n_steps = 2, 16, 3
-    out = str(tmp_path / "dp.pt")
-    mp.spawn(_dp_worker, args=(world, 29500 + os.getpid() % 2000, n_local, n_steps, out), nprocs=world, join=True)
-    dp = torch.load(out)
-    # single process, eager, on the data of both ranks: rank r's row i of the shared permutation -> global row
     pol = _make_policy(False)
     parts = []
     for r in range(world):
         b = RolloutBatch(n_steps, n_local, "cuda")
         _fill(b, 100 + r, pol)
         parts.append(b)
-    # every rank walks the SAME permutation of its local rows (shared seed), so global minibatch k = rows perm[k-th span] of
-    # every rank: lay the ranks' data out so that a single-process permutation reproduces exactly those minibatches
     N = n_steps * n_local
-    perm = torch.randperm(N, generator=torch.Generator().manual_seed(7))
-    big = RolloutBatch(n_steps, n_local * world, "cuda")
-
-    def flat(b, name):
-        t = getattr(b, name)[:b.n]        # observations hold n + 1 time rows (the one after the last step)
-        return t.reshape((b.n * b.A,) + tuple(t.shape[2:]))
-
-    order = []
-    for k in range(n_steps):                                      # span k of the permutation, rank-major inside the minibatch
-        for r in range(world):
-            order += [(r, int(i)) for i in perm[k * n_local:(k + 1) * n_local]]
-    for name in ("state", "ego", "dist", "time", "act", "adv", "returns", "logp_old"):
-        rows = torch.stack([flat(parts[r], name)[i] for r, i in order])
-        flat(big, name).copy_(rows)
-    # identity "permutation" over the re-ordered rows: minibatch k = rows [k*2n, (k+1)*2n)
+    pg = torch.Generator().manual_seed(7)
+    losses, grads = [], []
     orig_randperm = torch.randperm
-    try:
-        torch.randperm = lambda n, generator=None: torch.arange(n)
-        ref_losses = pol.learn(big, n_local * world, 1)
-    finally:
-        torch.randperm = orig_randperm
-    assert len(ref_losses["loss"]) == len(dp["loss"]) == n_steps
-    # logged losses are all-reduced sums of per-rank terms already scaled by 1/n_global = the global minibatch loss
-    np.testing.assert_allclose(dp["loss"], ref_losses["loss"], rtol=2e-4, atol=2e-5)
-    g_ref, g_dp = pol._flat_grad.cpu(), dp["grad"]                # gradient of the LAST minibatch (after all-reduce + clip)
-    assert float(g_ref.abs().max()) > 0
-    assert float((g_ref - g_dp).abs().max()) <= 2e-4 * float(g_ref.abs().max())
-    moved = sum(int((v.cpu() - dp["sd"][k]).abs().gt(2e-4).sum()) for k, v in pol.state_dict().items())
-    assert moved < 5000, moved
+    for _ in range(n_learn):
+        perm = orig_randperm(N, generator=pg)
+        big = RolloutBatch(n_steps, n_local * world, "cuda")
+        order = []
+        for k in range(n_steps):                                  # span k of the permutation, rank-major inside the minibatch
+            for r in range(world):
+                order += [(r, int(i)) for i in perm[k * n_local:(k + 1) * n_local]]
+        for name in ("state", "ego", "dist", "time", "act", "adv", "returns", "logp_old"):
+            _flat(big, name).copy_(torch.stack([_flat(parts[r], name)[i] for r, i in order]))
+        try:
+            torch.randperm = lambda n, generator=None: torch.arange(n)
+            losses += pol.learn(big, n_local * world, 1)["loss"]
+        finally:
+            torch.randperm = orig_randperm
+        grads.append(pol._flat_grad.cpu().clone())
+    assert set(pol._train_handles) == {n_local * world} and pol.update_paths == {"chain": n_steps * n_learn}, pol.update_paths
+    return pol, losses, grads
+
+
+def _run_dp(tmp_path, world, n_local, n_steps, n_learn):
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_worker, args=(world, 29500 + os.getpid() % 2000, n_local, n_steps, n_learn, out), nprocs=world, join=True)
+    return [torch.load(out + f".{r}") for r in range(world)]
+
+
+@pytest.mark.parametrize("n_local", [32, 64])   # 32 rows per rank = the 8-way split of the 256-row minibatch (BASELINE configs[3])
+def test_two_rank_chain_single_step_equals_single_process(tmp_path, n_local):
+    """ONE optimiser step on two ranks through the default update path - `egx_policy_train_step` with the global advantage
+    statistics (`use_gstats`), graph 1 | all-reduce of the flat gradient | graph 2 (clip AFTER the reduce, AdamW, image refresh):
+    the all-reduced + clipped gradient, the logged loss and the parameters equal the single-process step on the concatenated
+    minibatch.  Same weights on both sides, so only the summation order of the weight gradients differs."""
+    world = 2
+    dp = _run_dp(tmp_path, world, n_local, 1, 1)
+    pol, ref_losses, ref_grads = _single_process_reference(world, n_local, 1, 1)
+    for r in range(world):
+        np.testing.assert_allclose(dp[r]["loss"], ref_losses, rtol=2e-5, atol=2e-6)
+        g_ref, g_dp = ref_grads[0], dp[r]["grads"][0]
+        assert float(g_ref.abs().max()) > 0
+        assert float((g_ref - g_dp).abs().max()) <= 1e-5 * float(g_ref.abs().max()), r
+        assert float((g_ref - g_dp).norm()) <= 2e-6 * float(g_ref.norm()), r
+    for k, v in dp[0]["sd"].items():                              # replicas stay bit-identical
+        assert torch.equal(v, dp[1]["sd"][k]), k
+    # AdamW's first step moves every parameter by lr * sign(g) whatever |g| is: a gradient entry within round-off of zero may
+    # differ by 2 lr between two summation orders; everything else must agree to round-off
+    lr = 3e-4
+    n_far = 0
+    for k, v in pol.state_dict().items():
+        d = (v.cpu() - dp[0]["sd"][k]).abs()
+        assert float(d.max()) <= 2 * lr * 1.01, (k, float(d.max()))
+        n_far += int((d > 2e-6).sum())
+    assert n_far <= 200, n_far
+
+
+def test_two_rank_chain_two_passes_equal_single_process(tmp_path):
+    """Two `learn()` passes of three minibatches on two ranks: replays of both graphs with a new index set / new global
+    statistics per minibatch, the weight images re-made inside graph 2 feeding the NEXT minibatch's forward and the rollout
+    forward after the update."""
+    world, n_local, n_steps, n_learn = 2, 32, 3, 2
+    dp = _run_dp(tmp_path, world, n_local, n_steps, n_learn)
+    pol, ref_losses, ref_grads = _single_process_reference(world, n_local, n_steps, n_learn)
+    assert len(ref_losses) == len(dp[0]["loss"]) == n_steps * n_learn
+    np.testing.assert_allclose(dp[0]["loss"], ref_losses, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dp[1]["loss"], dp[0]["loss"], rtol=0, atol=0)   # the logged losses are all-reduced: identical
+    for p_ in range(n_learn):                                     # gradient of the last minibatch of each pass (after all-reduce + clip)
+        g_ref, g_dp = ref_grads[p_], dp[0]["grads"][p_]
+        assert float((g_ref - g_dp).norm()) <= 2e-3 * float(g_ref.norm()), p_
+    for k, v in dp[0]["sd"].items():
+        assert torch.equal(v, dp[1]["sd"][k]), k
+    lr, steps = 3e-4, n_steps * n_learn
+    moved = 0
+    for k, v in pol.state_dict().items():
+        d = (v.cpu() - dp[0]["sd"][k]).abs()
+        assert float(d.max()) <= 2 * lr * steps, (k, float(d.max()))
+        moved += int((d > 2e-5).sum())
+    assert moved < 20000, moved                                   # of 13.2 M parameters (Adam sign flips of near-zero gradients)
+    # the rollout forward of a rank after the update = the single-process policy's
+    o = pol._runner.forward(_probe_obs())
+    assert float((o["mu"].cpu() - dp[0]["mu"]).abs().max()) <= 2e-4 and float((o["value"].cpu() - dp[0]["value"]).abs().max()) <= 2e-4
 
 
 def _bench(extra_env, *flags, timeout=900):
     env = dict(os.environ, PYTHONPATH=ROOT, **extra_env)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--agents", "8", "--batch-size", "8",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--agents", "32", "--batch-size", "64",
            "--num-verts", "1024", "--sdf-res", "32", "--no-cpu-baseline", "--vec-steps", "2"] + list(flags)
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -137,8 +210,10 @@ def test_bench_gpus2_spawns_two_ranks():
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["scaling"] == "strong"
-    assert res["config"]["agents_per_gpu"] == 4 and res["config"]["agents_total"] == 8
+    assert res["config"]["agents_per_gpu"] == 16 and res["config"]["agents_total"] == 32
     assert res["config"]["hip_graph_update"] is True
-    assert res["allreduce"]["calls_per_step"] == 2 and res["allreduce"]["in_loop_avg_ms"] > 0
-    assert res["weak"]["agents_per_gpu"] == 8 and res["weak"]["value"] > 0
+    # 32 rows per rank and minibatch: the hand-written chain, replayed as graphs - never the autograd fallback
+    assert set(res["config"]["update_paths"]) == {"chain+graph"}, res["config"]
+    assert res["allreduce"]["calls_per_step"] == 1 and res["allreduce"]["in_loop_avg_ms"] > 0
+    assert res["weak"]["agents_per_gpu"] == 32 and res["weak"]["value"] > 0 and set(res["weak"]["update_paths"]) == {"chain+graph"}
     assert res["value"] > 0 and res["roofline"]["avg_launch_ms"] > 0
