@@ -641,6 +641,35 @@ def test_learn_matches_oracle_fp64_parameters():
     assert frac["bf16x2"] <= 0.05 and frac["bf16"] <= 0.5, frac
 
 
+def test_merged_last_minibatch_reads_current_weight_images():
+    """Batch.split(merge_last=True): 160 transitions at batch size 64 = minibatches of 64 and 96 rows -> TWO train handles, the
+    second created after the graphs of the first size were captured.  A captured (clip + AdamW + image refresh) graph refreshes
+    the handles it knew at capture time only; the late handle must not forward through weights that are a step old: graph mode
+    and eager mode perform the same launches on the same data, so their parameters must agree to the last bit."""
+    from egogen_amd import setup_world as sw
+    out = []
+    for graph in (False, True):
+        a = _Args()
+        a.update_graph = graph
+        pol = sw.build_policy(a)
+        if out:
+            pol.load_state_dict(out[0][2])
+        sd0 = {k: v.clone() for k, v in pol.state_dict().items()}
+        b = _filled_batch(5, 32, 4, pol)
+        pol._perm_gen.manual_seed(5)
+        losses = []
+        for _ in range(3):
+            losses += pol.learn(b, 64, 1)["loss"]
+        assert set(pol._train_handles) == {64, 96}, pol._train_handles.keys()
+        if graph:
+            assert pol.update_paths.get("chain+graph", 0) >= 2 and pol.update_paths.get("chain", 0) >= 3, pol.update_paths
+            assert not any(v.get("failed") for v in pol._graph_cache.values())
+        out.append((losses, torch.cat([q.detach().flatten() for q in pol.parameters()]).clone(), sd0))
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-6, atol=1e-7)
+    d = (out[1][1] - out[0][1]).abs()
+    assert float(d.max()) <= 1e-7, (float(d.max()), int((d > 0).sum()))
+
+
 def test_learn_with_train_step_equals_autograd_nodes():
     """GAMMAPPOPolicy.learn over a whole collect: the hand-written step (eager and as replayed HIP graphs) performs the same
     optimiser steps as the autograd-node path - losses of every minibatch and the parameters afterwards."""
