@@ -116,7 +116,7 @@ class EnvResetIO(C.Structure):
     _fields_ = [("num_candidates", C.c_int)] + \
                [(n, C.c_void_p) for n in ("mask", "cand_pairs", "cand_yaw", "cand_variant", "cand_scene", "cand_valid", "tab_joints",
                                           "tab_markers", "tab_glorot", "tab_transl", "tab_pose", "obs_ego", "obs_dist",
-                                          "obs_time", "out_choice")]
+                                          "obs_time", "out_choice", "out_pending", "forced_count")]
 
 
 # name -> (restype, argtypes); must list every symbol of include/egogen_hip.h

@@ -54,8 +54,13 @@ class VecCrowdEnv:
                  keep_rollout: bool = False, device: str = "cuda", crowd_bbox: Optional[torch.Tensor] = None,
                  crowd_member: int = 0, crowd_pairs=None, crowd_floor_half: float = 4.0,
                  crowd_rings: Optional[List[np.ndarray]] = None, crowd_static: bool = False, agent_seeds: Optional[List[dict]] = None,
-                 vp_thresh: float = 11.0, goal_terminates: bool = True, gender: str = "male"):
-        """`gender` names the body model / motion prior the caller passed in (`crowd_env_2f.py:393` picks
+                 vp_thresh: float = 11.0, goal_terminates: bool = True, gender: str = "male", reset_rounds: Optional[int] = None):
+        """`reset_rounds`: box scenes - launches of the reset kernel per reset.  The reference draws starts until one passes
+        the walkability check (`while True`, crowd_env_2f_box.py:349-416); here a launch tries `num_candidates` (8) draws per
+        agent and the agents none of whose draws passed are re-launched with fresh draws (device mask, no host sync) up to
+        `reset_rounds` (4) launches = 32 draws; whoever is still without a valid start after the last round keeps its last
+        draw and is counted in `forced_accepts()`.
+        `gender` names the body model / motion prior the caller passed in (`crowd_env_2f.py:393` picks
         genop_2frame_male | female by it; every sampler but the EgoBody one draws from ['male'], environments.py:254,555,906);
         it is recorded in the saved rollouts.  `crowd_rings` / `crowd_static` / `agent_seeds` / `vp_thresh` / `goal_terminates` are the EgoBody-evaluation variant of
         the crowd scenes (crowd_env_egobody_eval.py, see CrowdGroupEnv): the scene's walkable polygon as exterior, one motion
@@ -123,6 +128,7 @@ class VecCrowdEnv:
 
         # ---- scenes ----
         self.sdf = None
+        self.R = 1   # reset rounds (box scenes: set below)
         if scene_kind == "sdf":
             if sdf_dict is None or rings is None or pairs is None:
                 raise ValueError("sdf scene needs sdf_dict, rings (walkable polygon) and start/target pairs")
@@ -141,6 +147,7 @@ class VecCrowdEnv:
             P = min(len(s["pairs"]) for s in box_scenes)
             self.box_pairs = torch.tensor(np.stack([np.asarray(s["pairs"][:P], np.float32) for s in box_scenes]), **f32)
             self.K = int(num_candidates or 8)
+            self.R = int(reset_rounds or 4)
         elif scene_kind == "crowd":
             # main_crowd_eval.py: every scene holds G members; the walkable polygon of a member is the 8x8 m floor minus
             # the marker boxes of the others (dummy_vector_env.py:34-39, crowd_env_crowd_eval.py:796-822)
@@ -162,13 +169,18 @@ class VecCrowdEnv:
         self.map_lin = torch.linspace(-self.cfg["map_extent"], self.cfg["map_extent"], self.cfg["map_res"]).to(self.dev)
 
         # ---- candidate buffers ----
-        K = self.K
-        self.cand_pairs = z(A, K, 2, 3)
-        self.cand_yaw = z(A, K)
-        self.cand_variant = torch.zeros(A, K, **i32)
-        self.cand_scene = torch.zeros(A, K, **i32)
+        K, R = self.K, self.R
+        self._cand_pairs_all = z(R, A, K, 2, 3)                   # round-major: round r's draws are one contiguous block
+        self._cand_yaw_all = z(R, A, K)
+        self._cand_variant_all = torch.zeros(R, A, K, **i32)
+        self._cand_scene_all = torch.zeros(R, A, K, **i32)
+        self.cand_pairs, self.cand_yaw = self._cand_pairs_all[0], self._cand_yaw_all[0]
+        self.cand_variant, self.cand_scene = self._cand_variant_all[0], self._cand_scene_all[0]
         self.choice = torch.zeros(A, **i32)
         self.ones_mask = torch.ones(A, **i32)
+        self.pending = torch.zeros(A, **i32)                      # agents whose draws of the last launch all failed the start check
+        self.forced = torch.zeros(1, **i32)                       # starts committed in penetration after the last round
+        self._rounds_ready = R
 
         # ---- C structs ----
         c = self.cfg
@@ -271,8 +283,11 @@ class VecCrowdEnv:
         self.tab_transl = torch.tensor(transl, **f32).contiguous()
         self.tab_pose = torch.tensor(pose, **f32).contiguous()
 
-    def _reset_io(self, A, K, mask, cand_pairs, cand_yaw, cand_variant, cand_scene, cand_valid, obs_ego, obs_dist, obs_time, choice):
+    def _reset_io(self, A, K, mask, cand_pairs, cand_yaw, cand_variant, cand_scene, cand_valid, obs_ego, obs_dist, obs_time, choice,
+                  pending=None, forced=None):
         io = _lib.EnvResetIO()
+        io.out_pending = pending.data_ptr() if pending is not None else None
+        io.forced_count = forced.data_ptr() if forced is not None else None
         io.num_candidates = int(K)
         io.mask = mask.data_ptr() if mask is not None else None
         io.cand_pairs = cand_pairs.data_ptr()
@@ -337,34 +352,56 @@ class VecCrowdEnv:
             u = torch.rand(A, K, generator=g, device=self.dev) * 2 - 1
             self.cand_yaw.copy_(u * (2 * np.pi * 0.2))           # environments.py:1100-1101 (CrowdMotion.gen_init_body)
         else:
-            sc = torch.randint(0, self.num_scenes, (A * K,), generator=g, device=self.dev)
-            pi = torch.randint(0, self.box_pairs.shape[1], (A * K,), generator=g, device=self.dev)
-            self.cand_pairs.copy_(self.box_pairs[sc, pi].reshape(A, K, 2, 3))
-            self.cand_scene.copy_(sc.reshape(A, K).to(torch.int32))
-            self.cand_variant.copy_(torch.randint(0, len(self.variant_starts), (A, K), generator=g, device=self.dev).to(torch.int32))
-            u = torch.rand(A, K, generator=g, device=self.dev) * 2 - 1
-            self.cand_yaw.copy_(u * (2 * np.pi * 0.1))           # environments.py:529
+            # the draws of ALL rounds in one go (the same four RNG launches whatever the number of rounds); the retry rounds
+            # only read theirs for agents that are still pending
+            R = self.R
+            sc = torch.randint(0, self.num_scenes, (R * A * K,), generator=g, device=self.dev)
+            pi = torch.randint(0, self.box_pairs.shape[1], (R * A * K,), generator=g, device=self.dev)
+            self._cand_pairs_all.copy_(self.box_pairs[sc, pi].reshape(R, A, K, 2, 3))
+            self._cand_scene_all.copy_(sc.reshape(R, A, K).to(torch.int32))
+            self._cand_variant_all.copy_(torch.randint(0, len(self.variant_starts), (R, A, K), generator=g, device=self.dev).to(torch.int32))
+            u = torch.rand(R, A, K, generator=g, device=self.dev) * 2 - 1
+            self._cand_yaw_all.copy_(u * (2 * np.pi * 0.1))      # environments.py:529
+            self._rounds_ready = R
 
     def set_candidates(self, pairs, yaw=None, variant=None, scene=None):
-        """Inject reset candidates (parity tests): pairs[A,K,2,3]."""
-        self.cand_pairs.copy_(torch.as_tensor(pairs, dtype=torch.float32).reshape(self.A, self.K, 2, 3))
+        """Inject reset candidates (parity tests): pairs[A,r*K,2,3] = agent a's draws in the order the reference's loop would
+        see them, for r <= reset_rounds rounds of K (the next reset runs exactly r launches)."""
+        A, K = self.A, self.K
+        pairs = torch.as_tensor(pairs, dtype=torch.float32).reshape(A, -1, 2, 3)
+        r = pairs.shape[1] // K
+        if r < 1 or r > self.R or pairs.shape[1] != r * K:
+            raise ValueError(f"candidates per agent must be a multiple of K={K} up to {self.R * K}, got {pairs.shape[1]}")
+        rm = lambda t, *tail: t.reshape(A, r, K, *tail).transpose(0, 1)   # [A, r*K, ...] -> round-major [r, A, K, ...]
+        self._cand_pairs_all[:r].copy_(rm(pairs, 2, 3))
         self._cand_step = None
         if yaw is not None:
-            self.cand_yaw.copy_(torch.as_tensor(yaw, dtype=torch.float32).reshape(self.A, self.K))
+            self._cand_yaw_all[:r].copy_(rm(torch.as_tensor(yaw, dtype=torch.float32)))
         if variant is not None:
-            self.cand_variant.copy_(torch.as_tensor(variant, dtype=torch.int32).reshape(self.A, self.K))
+            self._cand_variant_all[:r].copy_(rm(torch.as_tensor(variant, dtype=torch.int32)))
         if scene is not None:
-            self.cand_scene.copy_(torch.as_tensor(scene, dtype=torch.int32).reshape(self.A, self.K))
+            self._cand_scene_all[:r].copy_(rm(torch.as_tensor(scene, dtype=torch.int32)))
+        self._rounds_ready = r
         self._injected = True
 
     def _launch_reset(self, mask):
         box = self.scene_kind in ("box", "crowd")
-        pairs = self._cand_step if self._cand_step is not None else self.cand_pairs
-        io = self._reset_io(self.A, self.K, mask, pairs, self.cand_yaw if box else None,
-                            self.cand_variant if box else None, self.cand_scene if self.scene_kind == "box" else None, None,
-                            self.obs_ego, self.obs_dist, self.obs_time, self.choice)
-        _lib.check(self.lib.egx_env_reset(C.byref(self._ec), C.byref(self._sc), C.byref(self._st), C.byref(io), self.A,
-                                          _lib.current_stream_ptr()), "egx_env_reset")
+        rounds = self._rounds_ready if self.scene_kind == "box" else 1
+        for r in range(rounds):
+            pairs = self._cand_step if self._cand_step is not None else self._cand_pairs_all[r]
+            last = r == rounds - 1
+            io = self._reset_io(self.A, self.K, mask if r == 0 else self.pending, pairs, self._cand_yaw_all[r] if box else None,
+                                self._cand_variant_all[r] if box else None, self._cand_scene_all[r] if self.scene_kind == "box" else None,
+                                None, self.obs_ego, self.obs_dist, self.obs_time, self.choice,
+                                pending=self.pending if self.scene_kind == "box" else None,
+                                forced=self.forced if (self.scene_kind == "box" and last) else None)
+            _lib.check(self.lib.egx_env_reset(C.byref(self._ec), C.byref(self._sc), C.byref(self._st), C.byref(io), self.A,
+                                              _lib.current_stream_ptr()), "egx_env_reset")
+
+    def forced_accepts(self) -> int:
+        """Starts committed although none of an agent's reset_rounds x K draws passed the start check, since construction
+        (one host sync).  0 means every episode so far started like the reference's `while True` loop would have started it."""
+        return int(self.forced.item())
 
     def obs(self) -> Dict[str, torch.Tensor]:
         return {"state": self.state, "egosensing": self.obs_ego, "dist": self.obs_dist, "time": self.obs_time}
@@ -455,8 +492,8 @@ class CrowdEnv:
         if vec_env.A != 1:
             raise ValueError("CrowdEnv wraps a 1-agent VecCrowdEnv")
         self.vec = vec_env
-        self.action_space = {"low": -6.0, "high": 6.0, "shape": (128,)}
-        self.observation_space = {"state": (2, 402), "egosensing": (2, 32), "dist": (), "time": ()}
+        from .spaces import crowd_env_spaces
+        self.action_space, self.observation_space = crowd_env_spaces()   # crowd_env_2f.py:49-51 (gymnasium's when installed)
 
     def seed(self, seed):
         self.vec.gen.manual_seed(int(seed))

@@ -587,6 +587,9 @@ struct ResetArgs {
   // obs
   float* obs_ego; float* obs_dist; float* obs_time;
   int* out_choice;  // [A] chosen candidate or null
+  int* pending;        // [A] or null: 1 = none of this launch's K candidates passed the start check (the last one was committed
+                       // so that the state is well defined) - the caller re-launches with this array as the mask
+  int* forced_count;   // [1] or null: += 1 for every agent this launch left pending (set on the caller's LAST round only)
 };
 }  // namespace
 
@@ -594,7 +597,10 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
   __shared__ float s_red[BLK];
   __shared__ float s_f[64];
   const int a = blockIdx.x, tid = threadIdx.x;
-  if (p.mask && p.mask[a] == 0) return;
+  if (p.mask && p.mask[a] == 0) {
+    if (tid == 0 && p.pending && p.pending != p.mask) p.pending[a] = 0;
+    return;
+  }
   const EnvCfg& c = p.cfg;
   for (int k = 0; k < p.K; ++k) {
     const int scene = p.sc.crowd_bbox ? a : (p.cand_scene ? p.cand_scene[(size_t)a * p.K + k] : (p.scene_idx ? p.scene_idx[a] : 0));
@@ -796,6 +802,8 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
       w[0] = s_f[36]; w[1] = s_f[37]; w[2] = s_f[38]; w[3] = wp[0]; w[4] = wp[1]; w[5] = wp[2];
       if (p.out_choice) p.out_choice[a] = k;
       if (p.cand_scene && p.scene_idx) p.scene_idx[a] = scene;
+      if (p.pending) p.pending[a] = accept ? 0 : 1;
+      if (!accept && p.forced_count) atomicAdd(p.forced_count, 1);
     }
     break;
   }
@@ -877,6 +885,7 @@ extern "C" int egx_env_reset(const egx_env_config* cfg, const egx_env_scenes* sc
   p.state = st->state; p.seed = st->seed; p.R0 = st->R0; p.T0 = st->T0; p.dist = st->dist; p.steps = st->steps;
   p.wpath = st->wpath; p.scene_idx = st->scene_idx;
   p.obs_ego = io->obs_ego; p.obs_dist = io->obs_dist; p.obs_time = io->obs_time; p.out_choice = io->out_choice;
+  p.pending = io->out_pending; p.forced_count = io->forced_count;
   hipLaunchKernelGGL(egx_env_reset_kernel, dim3(A), dim3(BLK), 0, static_cast<hipStream_t>(stream_), p);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;

@@ -184,14 +184,34 @@ class GAMMAPrimitiveCombo(nn.Module):
         self._ws = _Workspace()
         self._wstruct = None
         self._wkey = None
+        self._gen = 0   # bumped whenever the parameters change (mark_dirty / load_state_dict / _apply): the packed images are copies
+
+    def mark_dirty(self):
+        """The parameters changed: re-derive the folded / packed weight images before the next `sample_prior`.  Called by
+        load_state_dict and by .to() / .cuda() / .float(); in-place edits torch versions (`optimizer.step()`, `p.copy_()`) are
+        noticed through the tensors' version counters; a kernel that writes the parameters BY ADDRESS must call this itself."""
+        self._gen += 1
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        self.mark_dirty()
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self.mark_dirty()
+        return out
 
     def _weights(self) -> _lib.PriorWeights:
         p, r = self.predictor, self.regressor.pnet
-        # pointer + in-place version of the tensors the folded decoder weights depend on
-        reg_w = [r.in_fc.weight, r.out_fc.weight] + [r.layers[b].layers[k].weight for b in range(10) for k in range(2)]
-        key = (p.x_enc.weight_ih_l0.data_ptr(), r.out_fc.weight.data_ptr(), p.d_rnn.weight_ih._version, p.d_out.weight._version,
-               p.d_out.bias._version) + tuple(t._version for t in reg_w) + \
-              tuple(t._version for t in self.parameters())   # the packed images are copies: stale once a weight changes
+        # in-place edits torch can see (optimizer.step(), copy_, a sub-module's load_state_dict) bump a tensor's _version; the sum
+        # over a cached parameter list costs a few microseconds per call (the generator `self.parameters()` walked the module
+        # tree on every env step).  Writes by ADDRESS are invisible here: they need mark_dirty().
+        plist = self.__dict__.get("_plist")
+        if plist is None or self.__dict__.get("_plist_gen") != self._gen:
+            plist = list(self.parameters())
+            self.__dict__["_plist"], self.__dict__["_plist_gen"] = plist, self._gen
+        key = (p.x_enc.weight_ih_l0.data_ptr(), r.out_fc.weight.data_ptr(), self._gen, sum(t._version for t in plist))
         if self._wstruct is not None and self._wkey == key:
             return self._wstruct
         w = _lib.PriorWeights()

@@ -235,10 +235,12 @@ class GAMMARegressorTrainOP:
         self.model.train()
         self.grads = FlatGrads(self.model)
         self.use_cont = self.modelconfig.get("use_cont", False)
+        from . import synth
         if body_model is None:
-            from . import setup_world, synth
+            from . import setup_world
             body_model, _ = setup_world.load_body_model(self.modelconfig["gender"])
-            markers = synth.marker_ids(body_model["v_template"].shape[0]) if markers is None else markers
+        if markers is None:
+            markers = synth.marker_ids(body_model["v_template"].shape[0])
         self.markers = self.model.markers = [int(v) for v in markers]
         self.bm = MarkerBodyModel(body_model, self.markers).to(self.device)
 

@@ -474,7 +474,8 @@ typedef struct egx_env_step_io {
 } egx_env_step_io;
 
 typedef struct egx_env_reset_io {
-  int num_candidates;        /* K start/target candidates per agent: first accepted wins, last is forced */
+  int num_candidates;        /* K start/target candidates per agent: first accepted wins; when none passes, the last is
+                              * committed and the agent is reported in out_pending (see below)             */
   const int32_t* mask;       /* [A] 1 = reset, or NULL = all                                              */
   const float* cand_pairs;   /* [A,K,2,3]                                                                 */
   const float* cand_yaw;     /* [A,K] final yaw jitter (box sampler, environments.py:528-538) or NULL     */
@@ -490,6 +491,13 @@ typedef struct egx_env_reset_io {
   float* obs_dist;           /* [A]      */
   float* obs_time;           /* [A]      */
   int32_t* out_choice;       /* [A] index of the committed candidate, or NULL                              */
+  /* The reference draws until a start passes (`while True: ... if num_pene[0] == 0: break`, crowd_env_2f_box.py:349-416).
+   * One launch tries K candidates; out_pending[a] = 1 where all K failed, 0 elsewhere (also for agents the mask skips).  The
+   * caller launches again with fresh candidates and mask = out_pending (the same array may be passed as both) until its
+   * retry budget is spent; on that last launch it passes forced_count, which then counts the agents that START IN
+   * PENETRATION - a deviation from the reference's unbounded loop that must be observable (VecCrowdEnv.forced_accepts). */
+  int32_t* out_pending;      /* [A] or NULL */
+  int32_t* forced_count;     /* [1] += agents left pending by this launch, or NULL */
 } egx_env_reset_io;
 
 /* Yb = cat(seed, Yb_gen) with _blend_params (crowd_env_2f.py:117-123,729-739) -> pred_params [A,20,93] */

@@ -239,7 +239,7 @@ def test_single_agent_crowd_env_view_rollout_matches_oracle(tmp_path):
     w = _room0_world(1, keep_rollout=True)
     vec, o = w["env"], w["oracle"]
     env = CrowdEnv(vec)
-    assert env.action_space["shape"] == (128,) and env.observation_space["state"] == (2, 402)
+    assert env.action_space.shape == (128,) and env.observation_space["state"].shape == (2, 402)
     pair = vec.valid_pairs[3:4].cpu().numpy()
     vec.set_candidates(pair.reshape(1, 1, 2, 3))
     obs, info = env.reset()
@@ -280,6 +280,58 @@ def test_single_agent_crowd_env_view_rollout_matches_oracle(tmp_path):
         assert max_abs(mp["smplx_params"][..., 6:], r["smplx_params"][..., 6:]) <= 2e-4
         drift.append(max_abs(mp["blended_marker"], r["blended_marker"]))
     print("un-synchronised marker drift per primitive:", ["%.2e" % d for d in drift])
+
+
+def test_crowd_env_behind_a_sequential_vector_env_loop():
+    """The per-agent `CrowdEnv` is what tianshou's `DummyVectorEnv` / `Collector` hold (main_ppo.py:97-101; the reference's own
+    copy: crowd_ppo/dummy_vector_env.py:81-128): they read `action_space.shape / .sample() / .contains()`, iterate
+    `observation_space.spaces`, send one action per env, collect (obs, rew, terminated, truncated, info) tuples, add `env_id`
+    to the info dict, `np.stack` the pieces and reset finished envs by id.  The same loop, written out, over two views."""
+    from egogen_amd.crowd_env import CrowdEnv
+    worlds = [_room0_world(1), _room0_world(1)]
+    envs = [CrowdEnv(w["env"]) for w in worlds]
+    sp = envs[0].action_space
+    assert sp.shape == (128,) and float(sp.low.min()) == -6.0 and float(sp.high.max()) == 6.0 and sp.dtype == np.float32
+    osp = envs[0].observation_space
+    assert list(osp.spaces.keys()) == ["state", "egosensing", "dist", "time"]
+    assert osp["state"].shape == (2, 402) and osp["egosensing"].shape == (2, 32) and osp["dist"].shape == (1,) and osp["time"].shape == (1,)
+    assert (float(osp["state"].low.min()), float(osp["state"].high.max())) == (-2.0, 2.0) and float(osp["dist"].low.min()) == 0.0
+    sp.seed(0)
+    a0 = sp.sample()
+    assert a0.shape == (128,) and a0.dtype == np.float32 and sp.contains(a0) and not sp.contains(np.full(128, 7.0, np.float32))
+
+    def to_np(obs):
+        return {k: v.detach().cpu().numpy() for k, v in obs.items()}
+
+    # DummyVectorEnv.reset: every worker resets, observations stacked
+    ret = [e.reset(seed=11 + i) for i, e in enumerate(envs)]
+    obs_list = [to_np(r[0]) for r in ret]
+    assert all(r[1] == {} for r in ret)
+    for o in obs_list:      # what a Collector would put into its buffer lies in the declared spaces, up to the egosensing scale
+        assert set(o) == set(osp.spaces) and all(o[k].shape == osp[k].shape for k in o)
+        assert osp["dist"].contains(o["dist"]) and osp["time"].contains(o["time"]) and osp["state"].contains(o["state"])
+    ids = list(range(len(envs)))
+    n_done = 0
+    for step in range(16):
+        action = np.stack([sp.sample() * 0.1 for _ in ids])      # policy output, one row per ready env
+        assert len(action) == len(ids)
+        result = []
+        for i, j in enumerate(ids):                               # workers[j].send(action[i]) ... recv()
+            env_return = list(envs[j].step(action[i]))
+            env_return[-1]["env_id"] = j
+            result.append(env_return)
+        obs_l, rew_l, term_l, trunc_l, info_l = tuple(zip(*result))
+        obs_stack = np.stack([to_np(o)["state"] for o in obs_l])
+        rew, term, trunc, info = np.stack(rew_l), np.stack(term_l), np.stack(trunc_l), np.stack(info_l)
+        assert obs_stack.shape == (2, 2, 402) and rew.shape == (2,) and rew.dtype == np.float64
+        assert term.dtype == bool and trunc.dtype == bool and not trunc.any() and [d["env_id"] for d in info] == ids
+        assert np.isfinite(rew).all()
+        done = np.logical_or(term, trunc)
+        for j in np.where(done)[0]:                               # Collector: reset the finished envs by id
+            o, inf = envs[j].reset()
+            assert inf == {} and to_np(o)["time"].tolist() == [1.0]
+            n_done += 1
+    assert n_done >= 1, "max_depth 13 must end at least one episode within 16 steps"
 
 
 def test_rollout_primitives_matches_reference_restatement():

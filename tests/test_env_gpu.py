@@ -176,6 +176,68 @@ def test_reset_and_step_box_match_oracle():
         _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
 
 
+def test_box_reset_retries_like_the_reference_loop():
+    """crowd_env_2f_box.py:349-416 draws starts `while True` until one passes the walkability check.  Scene set with ~25 %
+    acceptance (three of four draws put the body onto the obstacle): the kernel tries K draws per launch and the agents with
+    no accepted draw are re-launched (device mask) with the next K - the committed start is the FIRST accepted draw of the
+    agent's sequence, exactly what the reference's loop (the oracle, one draw at a time) returns; nobody is force-accepted.
+    One agent gets a sequence without any valid draw: it is the one `forced_accepts()` reports."""
+    A = 6
+    w = build_world(A=A, scene_kind="box", n_pairs=32, n_scenes=3)
+    env, oo = w["env"], w["oracle"]
+    K, R = env.K, env.R
+    assert R >= 3
+    n = K * R
+    rng = np.random.default_rng(3)
+    scene = rng.integers(0, 3, (A, n))
+    pidx = rng.integers(0, 32, (A, n))
+    pairs = np.stack([[w["box_scenes"][scene[a, j]]["pairs"][pidx[a, j]] for j in range(n)] for a in range(A)]).astype(np.float32)
+    bad = rng.uniform(size=(A, n)) < 0.75
+    bad[0, :K + 2] = True            # agent 0: nothing valid in round 0 -> accepted in round 1 at the earliest
+    bad[1, :2 * K + 1] = True        # agent 1: round 2 at the earliest
+    bad[A - 1, :] = True             # the last agent never sees a valid draw
+    for a in range(A):
+        for j in range(n):
+            if bad[a, j]:            # start on the obstacle's centre: the seed body's marker box covers non-walkable cells
+                sc = w["box_scenes"][scene[a, j]]
+                pairs[a, j, 0, :2] = 0.5 * (sc["box_lo"] + sc["box_hi"])
+    variant = rng.integers(0, len(env.variant_starts), (A, n))
+    yaw = rng.uniform(-1, 1, (A, n)).astype(np.float32) * 2 * np.pi * 0.1
+    env.set_candidates(pairs, yaw, variant, scene)
+    obs = env.reset()
+    # the reference's loop, one draw at a time
+    sel, n_acc = [], 0
+    for a in range(A):
+        pick = n - 1
+        for j in range(n):
+            poses, trans, betas = _seed_inputs(env, 1, [variant[a, j]])
+            tr, go, bp, wp = oo.next_body(torch.as_tensor(pairs[a, j, 0:1]), torch.as_tensor(pairs[a, j, 1:2]), poses, trans, betas,
+                                          yaw_jitter=torch.as_tensor(yaw[a, j:j + 1]))
+            _, accept = oo.reset_from(tr, go, bp, betas, wp, scene_idx=[scene[a, j]])
+            n_acc += int(bool(accept[0]))
+            if bool(accept[0]):
+                pick = j
+                break
+        sel.append(pick)
+    assert sel[0] >= K and sel[1] >= 2 * K and sel[A - 1] == n - 1, sel
+    assert all(not bad[a, sel[a]] for a in range(A - 1)), "the oracle accepted a start on the obstacle"
+    assert env.pending.cpu().tolist() == [0] * (A - 1) + [1]
+    assert env.forced_accepts() == 1
+    ka, ar = np.array(sel), np.arange(A)
+    assert env.choice.cpu().tolist() == (ka % K).tolist()
+    oobs, _ = _oracle_reset(w, pairs[ar, ka], variant[ar, ka], yaw[ar, ka], scene[ar, ka])
+    _compare_state(w)
+    assert env.scene_idx.cpu().tolist() == scene[ar, ka].tolist()
+    _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
+    # a masked auto-reset: only the flagged agents are touched, untouched agents are not reported pending
+    before = env.state.clone()
+    mask = torch.tensor([0, 1, 0, 0, 0, 0], dtype=torch.int32, device="cuda")
+    env.set_candidates(pairs[:, ::-1].copy(), yaw[:, ::-1].copy(), variant[:, ::-1].copy(), scene[:, ::-1].copy())
+    env.reset(mask)
+    assert torch.equal(env.state[[0, 2, 3, 4, 5]], before[[0, 2, 3, 4, 5]])
+    assert env.pending.cpu().tolist()[0] == 0 and env.pending.cpu().tolist()[A - 1] == 0
+
+
 def test_graph_replay_equals_eager():
     A = 4
     w = build_world(A=A, scene_kind="sdf")
