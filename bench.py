@@ -72,6 +72,10 @@ def get_args():
     p.add_argument("--skin-weights", type=int, default=4, help="non-zero skinning weights per vertex of the synthetic body (4..16)")
     p.add_argument("--lbs-blend", type=str, default="", choices=["", "f32", "bf16x3", "bf16x2"],
                    help="arithmetic of the LBS blend GEMM (default: the library's default, two bf16 planes)")
+    p.add_argument("--update-prec", type=str, default="bf16x2", choices=["f32", "bf16x2", "bf16"],
+                   help="arithmetic of the PPO update's products (GAMMAPPOPolicy update_precision): three / two / one bf16 terms per operand")
+    p.add_argument("--policy-prec", type=str, default="bf16x2", choices=["f32", "bf16x2", "bf16"],
+                   help="arithmetic of the rollout policy's dense layers (egx_policy_set_precision)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="time cap of each secondary CPU-baseline leg")
     p.add_argument("--cpu-repeats", type=int, default=3, help="repeats of the headline CPU leg (min / median reported)")
@@ -286,6 +290,7 @@ def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_
     body, prior, vposer = ops
     pa = PolicyArgs()
     pa.update_graph = bool(args.update_graph)
+    pa.update_precision = args.update_prec
     env = sw.build_env(A, scene, body, prior, vposer, seed=rank, use_graph=bool(args.graph))
     policy = sw.build_policy(pa)
     policy.train()
@@ -440,6 +445,7 @@ def main():
     body = BodyModelHandle(bm, synth.marker_ids(args.num_verts), synth.feet_vids(args.num_verts))
     if args.lbs_blend:
         _lib.check(lib.egx_lbs_set_blend_mode({"f32": 0, "bf16x3": 1, "bf16x2": 2}[args.lbs_blend]), "egx_lbs_set_blend_mode")
+    _lib.check(lib.egx_policy_set_precision({"f32": 0, "bf16x2": 2, "bf16": 1}[args.policy_prec]), "egx_policy_set_precision")
     ops = (body, sw.build_motion_prior(seed=0), sw.build_vposer(seed=0))
     scene = sw.build_scene(args.scene, sdf_res=args.sdf_res, seed=0)
     _log("assets built")

@@ -37,9 +37,10 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
     # BASELINE config 5: the policy's dense layers on the bf16 MFMA (operands rounded to bf16, fp32 accumulate) unless
     # --policy-dtype fp32; everything else (motion prior, SMPL-X, collision) stays fp32
     from egogen_amd import _lib
-    bf16 = (getattr(args, "policy_dtype", None) or "bf16") == "bf16"
-    _lib.check(_lib.load().egx_policy_set_precision(1 if bf16 else 0), "egx_policy_set_precision")
-    print("policy dense layers:", "bf16 operands / fp32 accumulate" if bf16 else "fp32")
+    dt = getattr(args, "policy_dtype", None) or "bf16"
+    _lib.check(_lib.load().egx_policy_set_precision({"fp32": 0, "bf16x2": 2, "bf16": 1}[dt]), "egx_policy_set_precision")
+    print("policy dense layers:", {"bf16": "bf16 operands / fp32 accumulate", "bf16x2": "operands as two bf16 terms / fp32 accumulate",
+                                   "fp32": "fp32-equivalent (three bf16 terms)"}[dt])
     if args.resume_path:
         policy.load_state_dict(torch.load(args.resume_path, map_location="cuda")["model"])
         print("Loaded agent from: ", args.resume_path)
@@ -90,6 +91,11 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
             m._injected = False
             obs[k] = m.obs()
     print(f'Final reward: {np.mean(done_ret)}, length: {np.mean(done_len)}')
+    stats_path = os.environ.get("EGX_CROWD_STATS")
+    if stats_path:   # per-episode returns / lengths (statistical parity of the bf16 policy)
+        import json
+        with open(stats_path, "w") as f:
+            json.dump({"reward": done_ret, "length": done_len, "scenes": S, "humans_per_scene": G}, f)
     return {"rew": float(np.mean(done_ret)), "len": float(np.mean(done_len)), "episodes": done_cnt}
 
 

@@ -74,18 +74,26 @@ def get_args(argv=None, extra=()):
     p.add_argument("--sdf-res", type=int, default=256)
     p.add_argument("--save-rollout", type=int, default=None, help="write log/eval_results/motion_*.pkl (default: only with --watch)")
     p.add_argument("--num-verts", type=int, default=synth.NUM_VERTS, help="reduced synthetic body (tests)")
-    p.add_argument("--policy-dtype", type=str, default=None, choices=["fp32", "bf16"],
-                   help="arithmetic of the rollout policy's dense layers (default: fp32; main_crowd_eval.py: bf16, BASELINE config 5)")
+    p.add_argument("--policy-dtype", type=str, default=None, choices=["fp32", "bf16x2", "bf16"],
+                   help="arithmetic of the policy's dense layers, rollout forward and PPO update alike: fp32 = each operand as three "
+                        "bf16 terms (2^-24, fp32-equivalent), bf16x2 = two terms (16 significant bits; every gradient within 1e-4 of "
+                        "float64, tests/test_trainer_gpu.py), bf16 = operands rounded to bf16; fp32 accumulation in all.  Default: "
+                        "bf16x2 for training (main_ppo*.py), bf16 for main_crowd_eval.py (BASELINE config 5)")
     p.add_argument("--num-scenes", type=int, default=None, help="main_crowd_eval.py: independent 4-human scenes per GPU")
     for flag, kw in extra:
         p.add_argument(flag, **kw)
     return p.parse_args(argv)
 
 
-def _apply_policy_dtype(args):
-    if getattr(args, "policy_dtype", None):
-        from egogen_amd import _lib
-        _lib.check(_lib.load().egx_policy_set_precision(1 if args.policy_dtype == "bf16" else 0), "egx_policy_set_precision")
+_PREC_CODE = {"fp32": 0, "bf16x2": 2, "bf16": 1}
+
+
+def _apply_policy_dtype(args, default="bf16x2"):
+    """Sets the rollout-forward arithmetic process-wide and returns the name of the update's (`update_precision`)."""
+    from egogen_amd import _lib
+    name = getattr(args, "policy_dtype", None) or default
+    _lib.check(_lib.load().egx_policy_set_precision(_PREC_CODE[name]), "egx_policy_set_precision")
+    return {"fp32": "f32"}.get(name, name)
 
 
 def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True):
@@ -95,7 +103,7 @@ def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True
     if not torch.cuda.is_available():
         raise SystemExit("crowd_ppo needs a HIP device: the MI355X path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    _apply_policy_dtype(args)
+    args.update_precision = _apply_policy_dtype(args)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     # load_model (crowd_ppo/primitive_model.py:74-96): yaml -> results/crowd_ppo/<cfg_name>/<run>/ tree + config.yaml

@@ -14,6 +14,8 @@ imported, never called, on these code paths - SURVEY.md section 8(c)):
   crowd_ppo/crowd_env_2f_box.py::CrowdEnv._get_feature (with the walkability map) and
   exp_GAMMAPrimitive/utils/batch_gen_amass.py::get_map                   -> getmap_ref.npz
   crowd_ppo/utils.py::save_rollout_results                               -> rollout_ref.npz + rollout_ref.pkl
+  experiments/HMR/prohmr/utils/konia_transform.py::rotation_matrix_to_angle_axis (`python scripts/gen_goldens.py rot2aa`)
+      -> rot2aa_ref.npz (value-level pin of the oracle's torchgeometry R -> axis-angle restatement)
   exp_GAMMAPrimitive/utils/utils_canonicalize_samp.py::canonicalize_subsequence (`python scripts/gen_goldens.py canonicalize`)
       -> canonicalize_ref.npz.  The script builds smplx body models at import; `smplx.create` is replaced by an adapter around
       oracle/smplx_lbs.py on the synthetic full-size model (smplx itself is absent), so the fixture pins the SCRIPT's arithmetic
@@ -538,7 +540,36 @@ def gen_regressor_train():
     print("regressor_train_ref", items, items_b, os.path.getsize(os.path.join(OUT, "regressor_train_ref.npz")))
 
 
+def gen_rot2aa():
+    """rotation matrix -> axis-angle: VALUE-level golden from the in-tree kornia-derived copy
+    (experiments/HMR/prohmr/utils/konia_transform.py:316-341 -> rotation_matrix_to_quaternion :349-443 + quaternion_to_angle_axis
+    :560-630).  motion/ calls torchgeometry 0.1.2's function of the same name (baseops.py:119-162, 560-598), which is absent;
+    the in-tree copy is a LATER algorithm (different branch structure) of the same mathematical function: away from
+    theta ~ pi, where the sign of the axis is a convention, and from theta ~ 0, both return the unique rotation vector.  So its
+    outputs pin the oracle's restatement of tgm at the value level (not branch by branch) -> rot2aa_ref.npz."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "konia_transform", os.path.join(REF, "..", "experiments", "HMR", "prohmr", "utils", "konia_transform.py"))
+    kt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kt)
+    g = torch.Generator().manual_seed(78)
+    n = 256
+    axis = torch.randn(n, 3, generator=g)
+    axis = axis / axis.norm(dim=1, keepdim=True)
+    theta = torch.cat([torch.logspace(-3, 0.45, n - 32), torch.linspace(2.0, 3.0, 32)])   # 1e-3 .. 3.0 rad: all four quaternion branches
+    aa = axis * theta[:, None]
+    R = kt.angle_axis_to_rotation_matrix(aa.clone())       # pinned direction (aa2rot_ref.npz); exact rotations as inputs
+    out = kt.rotation_matrix_to_angle_axis(R.clone())
+    # which quaternion branch each sample exercises (trace > 0, else the largest diagonal entry)
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    branch = torch.where(tr > 0, torch.zeros(n, dtype=torch.long), 1 + torch.argmax(torch.stack([R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]], 1), 1))
+    print("rot2aa_ref", out.shape, "branches", torch.bincount(branch, minlength=4).tolist(), "max |out - aa|", float((out - aa).abs().max()))
+    np.savez_compressed(os.path.join(OUT, "rot2aa_ref.npz"), R=R.numpy(), aa_out=out.numpy(), aa_in=aa.numpy(), branch=branch.numpy())
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["rot2aa"]:
+        sys.exit(gen_rot2aa())
     if sys.argv[1:] == ["canonicalize"]:
         sys.exit(gen_canonicalize())
     if sys.argv[1:] == ["regressor_train"]:

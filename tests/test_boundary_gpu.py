@@ -282,6 +282,27 @@ def test_single_agent_crowd_env_view_rollout_matches_oracle(tmp_path):
     print("un-synchronised marker drift per primitive:", ["%.2e" % d for d in drift])
 
 
+def test_rotmat_to_angle_axis_device_function_matches_in_tree_copy_values():
+    """`egx_tgm_rotmat_to_aa` (the R -> axis-angle tail of the regressor, of reset and of `update_transl_glorot`) through the
+    C ABI: with the identity frame `egx_update_transl_glorot` returns log(exp(glorot)), compared with the golden of the
+    reference tree's own rotation_matrix_to_angle_axis (tests/golden/rot2aa_ref.npz, scripts/gen_goldens.py rot2aa)."""
+    from egogen_amd import _lib
+    from tests.helpers import load_golden
+    lib = _lib.load()
+    g = load_golden("rot2aa_ref.npz")
+    n = g["aa_in"].shape[0]
+    xb = torch.zeros(n, 93)
+    xb[:, 3:6] = torch.from_numpy(g["aa_in"])
+    xb = xb.cuda()
+    R, T, delta = torch.eye(3).reshape(1, 3, 3).cuda(), torch.zeros(1, 3).cuda(), torch.zeros(n, 3).cuda()
+    out = torch.empty_like(xb)
+    _lib.check(lib.egx_update_transl_glorot(_lib.ptr(R), _lib.ptr(T), 1, _lib.ptr(delta), _lib.ptr(xb), n, _lib.ptr(out),
+                                            _lib.current_stream_ptr()), "egx_update_transl_glorot")
+    theta = np.linalg.norm(g["aa_in"], axis=1)
+    err = np.abs(out[:, 3:6].cpu().numpy() - g["aa_out"]).max(axis=1)
+    assert err[theta < 2.0].max() < 1e-6 and err.max() < 5e-6, (err[theta < 2.0].max(), err.max())
+
+
 def test_crowd_env_behind_a_sequential_vector_env_loop():
     """The per-agent `CrowdEnv` is what tianshou's `DummyVectorEnv` / `Collector` hold (main_ppo.py:97-101; the reference's own
     copy: crowd_ppo/dummy_vector_env.py:81-128): they read `action_space.shape / .sample() / .contains()`, iterate

@@ -77,6 +77,24 @@ def test_angle_axis_to_rotation_matrix_matches_in_tree_copy():
     # and the HIP-side convention (egx_tgm_aa_to_rotmat mirrors the same function) is covered by tests/test_env_gpu.py
 
 
+def test_rotation_matrix_to_angle_axis_matches_in_tree_copy_values():
+    """rot.tgm_rotation_matrix_to_angle_axis (torchgeometry 0.1.2 restated: R -> quaternion by the four-mask rule -> axis-angle
+    by 2 atan2) against the VALUES of the reference tree's kornia-derived rotation_matrix_to_angle_axis
+    (experiments/HMR/prohmr/utils/konia_transform.py:316-341), a later algorithm of the same function: 256 rotations with
+    theta from 1e-3 to 3.0 rad, all four quaternion branches populated.  Away from theta = pi the rotation vector is unique,
+    so the two must agree to fp32 round-off (the conditioning of the inverse grows like 1 / (pi - theta): 3e-6 at 3 rad)."""
+    from oracle import rot
+    g = load_golden("rot2aa_ref.npz")
+    assert np.bincount(g["branch"], minlength=4).min() >= 8          # every branch of the quaternion conversion is exercised
+    out = rot.tgm_rotation_matrix_to_angle_axis(torch.from_numpy(g["R"])).numpy()
+    theta = np.linalg.norm(g["aa_in"], axis=1)
+    err = np.abs(out - g["aa_out"]).max(axis=1)
+    assert err[theta < 2.0].max() < 1e-6 and err.max() < 3e-6, (err[theta < 2.0].max(), err.max())
+    # float64 evaluation of the restatement: closer still to the exact rotation vector than either fp32 algorithm
+    out64 = rot.tgm_rotation_matrix_to_angle_axis(torch.from_numpy(g["R"]).double()).numpy()
+    assert np.abs(out64 - g["aa_in"]).max() < 3e-6
+
+
 def test_get_feature_and_blend_params_match_reference():
     """oracle.env.get_feature / blend_params against crowd_env_2f.CrowdEnv._get_feature / _blend_params run unbound
     (scripts/gen_goldens.py); the fixture holds a marker and a pelvis exactly on the target (the clip(min=1e-12) branch)."""

@@ -259,25 +259,55 @@ def test_main_egobody_eval_entry_point(tmp_path):
 
 
 def test_crowd_eval_bf16_policy_is_statistically_equivalent(tmp_path):
-    """Config 5 (bf16 policy): episode statistics over 64 four-human scenes (256 humans) against the fp32 policy, same
-    seeds - statistical parity, not 1e-4."""
+    """Config 5 (bf16 policy): per-episode statistics over 256 four-human scenes (1024 humans, SURVEY 8(d) C5: >= 256 scenes)
+    against the fp32 policy, same seeds - statistical parity, not 1e-4: means, and the two-sample Kolmogorov-Smirnov distance of
+    the reward and episode-length distributions (critical value at alpha = 0.001 for n = m = 1024: 1.95 sqrt(2 / n) = 0.086).
+    EGX_C5_HIST=<file>: write both histograms (committed as profiles/r04_c5_histograms.txt)."""
+    import json
     import re
     env = dict(os.environ, PYTHONPATH=ROOT)
-    res = {}
-    for dt in ("fp32", "bf16"):
+    res, dist_ = {}, {}
+    S = 256
+    for dt in ("fp32", "bf16x2", "bf16"):
         wd = tmp_path / dt
         wd.mkdir()
-        cmd = [sys.executable, os.path.join(ROOT, "crowd_ppo", "main_crowd_eval.py"), "--test-num", "256", "--num-verts", "1024",
-               "--seed", "3", "--num-scenes", "64", "--policy-dtype", dt]
-        r = subprocess.run(cmd, cwd=wd, env=env, capture_output=True, text=True, timeout=900)
+        cmd = [sys.executable, os.path.join(ROOT, "crowd_ppo", "main_crowd_eval.py"), "--test-num", str(4 * S), "--num-verts", "1024",
+               "--seed", "3", "--num-scenes", str(S), "--policy-dtype", dt]
+        r = subprocess.run(cmd, cwd=wd, env=dict(env, EGX_CROWD_STATS=str(wd / "stats.json")), capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         m = re.search(r"Final reward: ([-0-9.eE+]+), length: ([-0-9.eE+]+)", r.stdout)
         assert m, r.stdout[-1000:]
         res[dt] = (float(m.group(1)), float(m.group(2)))
         assert ("bf16 operands" in r.stdout) == (dt == "bf16")
-    (r32, l32), (r16, l16) = res["fp32"], res["bf16"]
-    assert abs(l32 - l16) <= 0.5, res                                   # mean episode length (steps)
-    assert abs(r32 - r16) <= 0.1 * max(1.0, abs(r32)), res              # mean episode reward
+        st = json.load(open(wd / "stats.json"))
+        assert st["scenes"] == S and st["humans_per_scene"] == 4 and len(st["reward"]) >= 4 * S
+        dist_[dt] = (np.asarray(st["reward"][:4 * S]), np.asarray(st["length"][:4 * S]))
+
+    def ks(a, b):
+        grid = np.sort(np.concatenate([a, b]))
+        return float(np.max(np.abs(np.searchsorted(np.sort(a), grid, side="right") / len(a) - np.searchsorted(np.sort(b), grid, side="right") / len(b))))
+
+    lines = [f"# main_crowd_eval.py, {S} four-human scenes ({4 * S} episodes per policy arithmetic), seed 3, random-init policy"]
+    r_edges = np.linspace(min(d[0].min() for d in dist_.values()), max(d[0].max() for d in dist_.values()), 13)
+    l_edges = np.arange(0.5, 12.5)
+    for dt, (rw, ln) in dist_.items():
+        lines.append(f"{dt:>7s}  mean reward {rw.mean():8.4f}  mean length {ln.mean():6.3f}")
+        lines.append("         reward hist  " + " ".join(f"{c:4d}" for c in np.histogram(rw, r_edges)[0]))
+        lines.append("         length hist  " + " ".join(f"{c:4d}" for c in np.histogram(ln, l_edges)[0]))
+    lines.append("         reward bin edges " + " ".join(f"{e:.2f}" for e in r_edges))
+    crit = 1.95 * np.sqrt(2.0 / (4 * S))
+    for dt in ("bf16x2", "bf16"):
+        kr, kl = ks(dist_["fp32"][0], dist_[dt][0]), ks(dist_["fp32"][1], dist_[dt][1])
+        lines.append(f"KS distance fp32 vs {dt}: reward {kr:.4f}, length {kl:.4f} (critical value alpha=0.001: {crit:.4f})")
+        assert kr <= crit and kl <= crit, (dt, kr, kl, crit)
+        (r32, l32), (r16, l16) = res["fp32"], res[dt]
+        assert abs(l32 - l16) <= 0.25, res                                  # mean episode length (steps)
+        assert abs(r32 - r16) <= 0.05 * max(1.0, abs(r32)), res             # mean episode reward
+    print("\n".join(lines))
+    out = os.environ.get("EGX_C5_HIST")
+    if out:
+        with open(out, "w") as f:
+            f.write("\n".join(lines) + "\n")
 
 
 def test_update_glue_kernels():
@@ -565,7 +595,10 @@ def test_train_step_matches_oracle_fp64(mode):
         elif mode == "bf16x2":
             assert rch <= 1e-4 and mch <= 1e-4, (n_, rch, mch)          # north_star: 1e-4 relative
         else:
-            assert rch <= 3e-2, (n_, rch)                                # bf16 operands: a wrong term / transposition is O(1)
+            # operands rounded to bf16 (2^-9 per element) through five layers forward and back, with leaky-ReLU sides decided
+            # in that arithmetic: measured 0.5 - 4.2 % per tensor on MI355X (profiles/r04_p3_yardstick.txt); a wrong term,
+            # a transposition or a missing skip gradient is O(1)
+            assert rch <= 1e-1, (n_, rch)
     lines.append(f"# worst rel-L2 ratio chain / fp32-yardstick: {worst:.2f}")
     out = os.environ.get("EGX_P3_TABLE")
     if out:
@@ -627,18 +660,34 @@ def test_learn_matches_oracle_fp64_parameters():
         pol._perm_gen.manual_seed(11)
         pol.learn(b, bs, 1)
         pol.learn(b, bs, 1)
-        far, tot, dmax = 0, 0, 0.0
+        far, tot, dmax, err2, upd2 = 0, 0, 0.0, 0.0, 0.0
         for k, v in pol.state_dict().items():
             if k.startswith("_actor_critic."):
                 continue
             d = (v.detach().cpu().double() - P[k].detach()).abs()
             dmax = max(dmax, float(d.max()))
             far += int((d > 2e-5).sum()); tot += d.numel()
-        frac[mode] = far / tot
+            err2 += float((d * d).sum())
+            upd2 += float(((P[k].detach() - sd0[k].cpu().double()) ** 2).sum())
+        frac[mode] = (far / tot, (err2 / upd2) ** 0.5)
         assert dmax <= 2 * lr * steps * 1.01, (mode, dmax)
-    print("fraction of parameters further than 2e-5 from the float64 schedule:", frac)
-    assert frac["f32"] <= 3 * frac["autograd-nodes fp32"] + 1e-4, frac
-    assert frac["bf16x2"] <= 0.05 and frac["bf16"] <= 0.5, frac
+    # (fraction of parameters further than 2e-5 from the float64 schedule, ||theta - theta64|| / ||theta64 - theta0||)
+    print("distance from the float64 schedule after 8 optimiser steps:", {k: ("%.4f" % a, "%.4f" % b) for k, (a, b) in frac.items()})
+    out = os.environ.get("EGX_P3_TABLE")
+    if out:
+        with open(out, "a") as f:
+            f.write("# learn() x 2 (8 optimiser steps, 64-row minibatches, replayed graphs) against the same schedule in float64:\n"
+                    "# mode                   share of parameters > 2e-5 away   ||theta - theta64|| / ||theta64 - theta0||\n")
+            for k, (a, b) in frac.items():
+                f.write(f"  {k:<22s} {a:10.4f} {b:34.4f}\n")
+            f.write("\n")
+    yard = frac["autograd-nodes fp32"]
+    # the hand-written chain in its fp32-equivalent mode is as close to float64 as torch fp32 autograd on library products is
+    assert frac["f32"][0] <= 3 * yard[0] + 1e-4 and frac["f32"][1] <= 3 * yard[1] + 1e-4, frac
+    # two bf16 terms per operand: every gradient within 1e-4 of float64 (test above) -> the same trajectory as fp32 up to the
+    # AdamW sign noise both share; bf16 operands: a different (noisier) trajectory, bounded, reported
+    assert frac["bf16x2"][0] <= 3 * yard[0] + 1e-4 and frac["bf16x2"][1] <= 3 * yard[1] + 1e-4, frac
+    assert frac["bf16"][1] <= 0.5, frac
 
 
 def test_merged_last_minibatch_reads_current_weight_images():
