@@ -76,6 +76,7 @@ def get_args():
                    help="arithmetic of the PPO update's products (GAMMAPPOPolicy update_precision): three / two / one bf16 terms per operand")
     p.add_argument("--policy-prec", type=str, default="bf16x2", choices=["f32", "bf16x2", "bf16"],
                    help="arithmetic of the rollout policy's dense layers (egx_policy_set_precision)")
+    p.add_argument("--repeats", type=int, default=3, help="timed regions of --steps cycles each; value = the median region")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="time cap of each secondary CPU-baseline leg")
     p.add_argument("--cpu-repeats", type=int, default=3, help="repeats of the headline CPU leg (min / median reported)")
@@ -257,6 +258,28 @@ def cpu_baseline(args, scene):
             "legs": legs}
 
 
+def _baseline_config_name(args, world):
+    """Which entry of BASELINE.json `configs` a run is."""
+    total = args.agents if args.scaling == "strong" else args.agents * world
+    if args.scene == "box":
+        k = "BASELINE configs[2] (512 agents, random-box scene set, full PPO loop)" if (total == 512 and world == 1) else \
+            ("BASELINE configs[3] (512 agents x N env shards, gradient all-reduce) on the configs[2] scene set" if world > 1 else
+             f"BASELINE configs[2] scene set at {total} agents")
+    elif args.scene == "single_box":
+        if world > 1:
+            k = "BASELINE configs[3] (N env shards, gradient all-reduce) on the configs[1] scene (single-box SDF)"
+        elif total == 512:
+            k = ("BASELINE configs[1] scene (static single-box SDF, LBS + SDF kernels) at configs[2]'s scale (512 agents, full PPO "
+                 "loop): the heavier hybrid of the two")
+        elif total == 64:
+            k = "BASELINE configs[1] (64 agents, static single-box SDF scene) inside the full PPO loop"
+        else:
+            k = f"BASELINE configs[1] scene at {total} agents"
+    else:
+        k = "BASELINE configs[0] scene (room0-shaped SDF) in the batched loop"
+    return k
+
+
 def _log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -282,7 +305,7 @@ def _spawn_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_lbs_events=True):
+def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_lbs_events=True, repeats=1):
     """Build env + policy for `A` agents on this rank, run `warmup` untimed and `steps` timed on-policy cycles."""
     from egogen_amd import _lib, setup_world as sw
     from egogen_amd.trainer import Collector
@@ -325,19 +348,32 @@ def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_
         policy.allreduce_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                                    for _ in range(steps * n_mb + 8)]
         policy._allreduce_done = []
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one_step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_region():
+        """EXACTLY `steps` cycles between barrier + synchronize on both sides; the maximum over the ranks."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    elapsed = timed_region()          # the region the LBS launch events and the all-reduce events belong to
+    extra_regions = []
+    for _ in range(max(0, repeats - 1)):   # the same region again: spread of the measurement (like the CPU leg's repeats)
+        env.profile_events = []
+        if world > 1:
+            policy.allreduce_events = []
+        extra_regions.append(timed_region())
 
     if args.graph and evs:
         # a captured step cannot carry per-launch events: time the same kernel on eager passes right after the region
@@ -373,8 +409,14 @@ def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_
               "standalone_busbw_GBps": nbytes / (alone_ms * 1e-3) / 1e9 * 2 * (world - 1) / world,
               "note": "in_loop includes the wait for the slowest rank; busbw = algbw * 2(N-1)/N (ring all-reduce)"}
     graphs_ok = bool(args.update_graph) and not any(v.get("failed") for v in policy._graph_cache.values())
-    return {"elapsed": elapsed, "lbs_ms": ms_list, "env": env, "policy": policy, "allreduce": ar, "graphs_ok": graphs_ok,
-            "transitions": steps * n_vec * A * world, "update_paths": dict(policy.update_paths)}
+    forced = env.forced_accepts() if hasattr(env, "forced_accepts") else 0
+    if world > 1:
+        t = torch.tensor([forced], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        forced = int(t.item())
+    return {"elapsed": elapsed, "regions": [elapsed] + extra_regions, "lbs_ms": ms_list, "env": env, "policy": policy, "allreduce": ar,
+            "graphs_ok": graphs_ok, "transitions": steps * n_vec * A * world, "update_paths": dict(policy.update_paths),
+            "forced_accepts": forced}
 
 
 def _lbs_in_scene_ms(env, lib, reps=8):
@@ -399,9 +441,44 @@ def _lbs_in_scene_ms(env, lib, reps=8):
         out.append(ms.value)
         lib.egx_event_destroy(e0)
         lib.egx_event_destroy(e1)
-    inside = float((env._lbs_out["pene_count"].reshape(A, 20).sum(1) == 0).float().mean().item())
+    cnt = env._lbs_out["pene_count"].reshape(A, 20)
+    inside = float((cnt.sum(1) == 0).float().mean().item())
     return {"avg_launch_ms": float(np.mean(out[1:])), "launches": len(out) - 1, "bodies_per_launch": A * 20,
-            "fraction_of_agents_with_zero_penetration": inside}
+            "fraction_of_agents_with_zero_penetration": inside, "mean_penetrating_vertices_per_body": float(cnt.float().mean().item())}
+
+
+def _lbs_penetrating_ms(env, lib, reps=8):
+    """As `_lbs_in_scene_ms`, with the agents moved INTO geometry: every freshly reset agent's world frame is translated so
+    that its pelvis sits within 0.35 m of the obstacle's centre (scene single_box: the 1 m box at (1.5, 0, 0.5)).  Thousands of
+    vertices per body are then inside the obstacle or within its level-set band: the bracket table decides the clear cases,
+    the undecided ones take the queue + eight-corner path of the SDF epilogue - the launch a policy that walks into obstacles
+    would produce.  (State is restored by the next reset.)"""
+    from egogen_amd import _lib
+    if env.sdf is None:
+        return None
+    env.reset()
+    A = env.A
+    g = torch.Generator(device=env.T0.device).manual_seed(1)
+    T0 = env.T0.clone()
+    T0[:, 0] = 1.5 + (torch.rand(A, generator=g, device=T0.device) - 0.5) * 0.7
+    T0[:, 1] = 0.0 + (torch.rand(A, generator=g, device=T0.device) - 0.5) * 0.7
+    xb = env.seed[:, [0, 1] * 10, :].contiguous().reshape(A * 20, 93)
+    out = []
+    for _ in range(reps):
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.egx_event_create(C.byref(e0)), "event")
+        _lib.check(lib.egx_event_create(C.byref(e1)), "event")
+        _lib.check(lib.egx_profile_next_lbs(e0, e1), "egx_profile_next_lbs")
+        env.bm.forward(xb, env.betas, 20, want_verts=False, sdf=env.sdf, R0=env.R0, T0=T0, out=env._lbs_out)
+        ms = C.c_float()
+        _lib.check(lib.egx_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
+        out.append(ms.value)
+        lib.egx_event_destroy(e0)
+        lib.egx_event_destroy(e1)
+    cnt = env._lbs_out["pene_count"].reshape(A, 20)
+    return {"avg_launch_ms": float(np.mean(out[1:])), "launches": len(out) - 1, "bodies_per_launch": A * 20,
+            "fraction_of_bodies_with_penetration": float((cnt > 0).float().mean().item()),
+            "mean_penetrating_vertices_per_body": float(cnt.float().mean().item())}
 
 
 def main():
@@ -449,9 +526,12 @@ def main():
     ops = (body, sw.build_motion_prior(seed=0), sw.build_vposer(seed=0))
     scene = sw.build_scene(args.scene, sdf_res=args.sdf_res, seed=0)
     _log("assets built")
-    m = _measure(args, world, rank, A, bs_local, scene, ops, args.steps, args.warmup)
-    elapsed, ms_list = m["elapsed"], m["lbs_ms"]
-    _log(f"timed region done: {elapsed:.3f}s")
+    m = _measure(args, world, rank, A, bs_local, scene, ops, args.steps, args.warmup, repeats=args.repeats)
+    ms_list = m["lbs_ms"]
+    regions = m["regions"]
+    elapsed = float(np.median(regions))      # `value` / `ms_per_step` = the MEDIAN of the timed regions (each exactly --steps cycles)
+    _log("timed regions done: " + ", ".join(f"{t:.3f}s" for t in regions))
+    assert m["forced_accepts"] == 0, f"{m['forced_accepts']} episodes started in penetration (no valid start among the reset draws)"
     lbs_ms = float(np.mean(ms_list))
     blend = int(lib.egx_lbs_get_blend_mode())
     # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (profiles/*_lbs_pmc*.json); it
@@ -485,6 +565,10 @@ def main():
     else:
         kernel_name, peak, peak_note, executed = "egx_lbs_fused_kernel", PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA peak", None
     in_scene = _lbs_in_scene_ms(m["env"], lib)
+    penetrating = _lbs_penetrating_ms(m["env"], lib) if args.scene == "single_box" else None
+    if penetrating is not None:
+        penetrating["achieved"] = FLOP_PER_BODY * bodies / (penetrating["avg_launch_ms"] * 1e-3) / 1e12
+        penetrating["frac"] = penetrating["achieved"] / peak
     other_mode = None
     if in_scene is not None:
         in_scene["achieved"] = FLOP_PER_BODY * bodies / (in_scene["avg_launch_ms"] * 1e-3) / 1e12
@@ -510,12 +594,22 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "regions": {"n": len(regions), "steps_each": args.steps, "ms_per_step": [t / args.steps * 1e3 for t in regions],
+                    "value_min": m["transitions"] / max(regions), "value_median": m["transitions"] / elapsed,
+                    "value_max": m["transitions"] / min(regions)},
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32" if blend == 0 else f"f32 (blend GEMM operands as {3 if blend == 1 else 2}-term bf16 splits, fp32 accumulate)",
+        "dtype": ("f32" if blend == 0 else f"f32 (blend GEMM operands as {3 if blend == 1 else 2}-term bf16 splits, fp32 accumulate)")
+                 + {"f32": "", "bf16x2": "; PPO update products on 2-term bf16 splits", "bf16": "; PPO update products on bf16 operands"}[args.update_prec]
+                 + {"f32": "", "bf16x2": "; rollout policy layers on 2-term bf16 splits", "bf16": "; rollout policy layers on bf16 operands"}[args.policy_prec],
+        "precision": {"lbs_blend": {0: "f32", 1: "bf16x3", 2: "bf16x2"}[blend], "ppo_update": args.update_prec, "rollout_policy": args.policy_prec,
+                      "motion_prior": "f32 (3-term bf16 splits, 2^-24)", "accumulate": "f32",
+                      "note": "bf16xN = every fp32 operand carried as N bf16 terms (8 N significant bits), partial products on the bf16 "
+                              "MFMA, fp32 accumulation; the strictly fp32-equivalent configuration (--lbs-blend bf16x3 --update-prec f32 "
+                              "--policy-prec f32) is timed in other_configs"},
         "data": "synthetic",
-        "config": {"workload": f"crowd_ppo PPO loop: {total_agents} agents over {world} GPU(s) ({A}/GPU), scene={args.scene}"
+        "config": {"workload": f"{_baseline_config_name(args, world)} - crowd_ppo PPO loop: {total_agents} agents over {world} GPU(s) ({A}/GPU), scene={args.scene}"
                                f"{'' if args.scene == 'box' else f' SDF {args.sdf_res}^3'}, synthetic SMPL-X body V={args.num_verts}, "
                                f"{args.vec_steps} vector steps/collect ({args.vec_steps * total_agents} transitions), "
                                f"global minibatch {bs_local * world}, repeat 1",
@@ -529,7 +623,8 @@ def main():
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
                      "flop_per_body": FLOP_PER_BODY, "vertices_evaluated": verts_eval, "vertices_total": bm_handle.V,
                      "peak_note": peak_note, "executed_bf16_tflops": executed,
-                     "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene, "other_blend_mode": other_mode,
+                     "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene, "in_scene_penetrating": penetrating,
+                     "other_blend_mode": other_mode,
                      "sustained_matrix_rate_note": "72 back-to-back v_mfma_f32_32x32x16_bf16 take 46, not 32, cycles each on this part "
                                                    "(clock-limited: 1720 of 2500 TFLOP/s in a load-free micro-benchmark, profiles/r01_ubench.md "
                                                    "section 4, profiles/r02_lbs_experiments.md); `peak` is the data-sheet figure"},
@@ -555,8 +650,10 @@ def main():
                               ["--agents", "128", "--batch-size", "64"]),
                              ("per-rank shape of the 8-way strong split (configs[3] at N = 8): 64 agents, 32-sample minibatch",
                               ["--agents", "64", "--batch-size", "32"]),
-                             ("headline workload with the LBS blend GEMM as a three-plane bf16 split (2^-24: fp32-equivalent)",
-                              ["--lbs-blend", "bf16x3"]),
+                             ("headline workload, STRICTLY fp32-equivalent arithmetic everywhere (LBS blend, PPO update and rollout policy on "
+                              "three-term bf16 splits: 2^-24 per product)", ["--lbs-blend", "bf16x3", "--update-prec", "f32", "--policy-prec", "f32"]),
+                             ("headline workload with the policy's dense layers (rollout + update) on bf16 operands: north_star's 'bf16 MFMA' "
+                              "(gradients ~1-4 % from float64, profiles/r04_p3_yardstick.txt)", ["--update-prec", "bf16", "--policy-prec", "bf16"]),
                              ("headline workload on a synthetic body with 12 skinning weights per vertex (real SMPL-X has 4..~12)",
                               ["--skin-weights", "12"])):
             cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--extra-configs", "0", "--steps", str(args.steps),
@@ -567,8 +664,14 @@ def main():
                 line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
                 r2 = json.loads(line)
                 others.append({"workload": label, "value": r2["value"], "unit": r2["unit"], "ms_per_step": r2["ms_per_step"],
-                               "lbs_avg_launch_ms": r2["roofline"]["avg_launch_ms"], "lbs_frac": r2["roofline"]["frac"],
-                               "lbs_peak": r2["roofline"]["peak"], "steps": r2["steps"], "command": " ".join(cmd[1:])})
+                               "regions": r2.get("regions"), "lbs_avg_launch_ms": r2["roofline"]["avg_launch_ms"],
+                               "lbs_frac": r2["roofline"]["frac"], "lbs_peak": r2["roofline"]["peak"], "steps": r2["steps"],
+                               "precision": r2.get("precision"), "command": " ".join(cmd[1:])})
+                if "--scene" in flags and "box" in flags:   # BASELINE configs[2] verbatim: a first-class record, not a footnote
+                    result["configs2"] = {k: r2[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "regions",
+                                                             "dtype", "data", "config", "precision") if k in r2}
+                    result["configs2"]["lbs"] = {k: r2["roofline"][k] for k in ("kernel", "avg_launch_ms", "achieved", "peak", "frac",
+                                                                                "vertices_evaluated", "vertices_total")}
             except Exception as e:
                 others.append({"workload": label, "value": None, "error": f"{type(e).__name__}: {e}"})
         result["other_configs"] = others

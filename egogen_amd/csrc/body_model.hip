@@ -967,8 +967,23 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
 #ifdef EGX_LBS_DEVELOPMENT
     if (const char* e = getenv("EGX_LBS_VERTEX_ORDER")) natural = std::string(e) == "natural";
 #endif
+    // The vertices the environment reads (markers, vertex joints, landmark corners: 241 of 10 475) come FIRST, packed into
+    // ceil(241 / 32) = 8 tiles: a call that asks for neither all vertices nor SDF counts (box / crowd / EgoBody scenes, reset
+    // tables, get_jts / get_markers) then evaluates 8 vertex tiles instead of every tile that happens to hold one of them
+    // (~half of the 328 under the joint order alone).  Both parts keep the joint-coherent order among themselves.
+    std::vector<char> is_pick(V, 0);
+    auto mark = [&](const int* ids, int n) {
+      for (int i = 0; i < n; ++i)
+        if (ids[i] >= 0 && ids[i] < V) is_pick[ids[i]] = 1;   // out-of-range ids are reported below (slot_of)
+    };
+    if (d->marker_vids_host) mark(d->marker_vids_host, d->num_markers);
+    mark(d->extra_vids_host, NEXTRA);
+    mark(d->lmk_vids_host, NLMK * 3);
     if (!natural)
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (is_pick[a] != is_pick[b]) return is_pick[a] > is_pick[b];
+        return key[a] < key[b];
+      });
     for (int v = 0; v < V; ++v) perm[v] = order[v];
   }
 

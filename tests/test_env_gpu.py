@@ -1,5 +1,6 @@
 """GPU parity of the batched CrowdEnv (reset + step, SDF and box scenes) against the CPU oracle,
-through the C ABI.  Tolerance: north_star's 1e-4 relative fp32 (absolute floor stated per quantity)."""
+through the C ABI.  Tolerance: north_star's 1e-4 relative fp32, ELEMENT-WISE, plus an absolute floor per kind of quantity that
+is derived from what fp32 itself costs (fp32 oracle vs float64 oracle, profiles/r04_env_tolerances.txt) - see `_close`."""
 import os
 
 import numpy as np
@@ -11,15 +12,57 @@ from tests.helpers import build_world, max_abs
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4
+TOL = 1e-4   # north_star: 1e-4 relative fp32
+
+# Element-wise bound of every comparison:  |gpu - oracle| <= 1e-4 |oracle| + c[kind] x S.
+# The absolute floor exists because an fp32 result that happens to lie near 0 is not known any better than its neighbours: a
+# canonical-frame coordinate is a difference of world coordinates of size S metres (S = the largest coordinate in play, up to
+# 30 m when the random-init motion prior throws a body away), i.e. it carries ~S x 2^-23 per operation whatever its own size.
+# The constants are tied to what fp32 ITSELF costs on these quantities - the CPU oracle in float32 against the same oracle in
+# float64 over a reset + one step (scripts/env_tolerance_yardstick.py -> profiles/r04_env_tolerances.txt, S ~ 6 m there):
+#   coordinates in metres   4.0e-5 (joints / projected markers)  = 6.1e-6 S   -> c = 5e-6
+#   unit vectors, rotations 7.4e-6 (state features, R0)          = 2.2e-6 S   -> c = 1e-5  (an angle: position error / ~0.2 m limb)
+#   egosensing              1.2e-4 (rays past polygon corners)                -> c = 1.5e-4
+#   rewards                 1.4e-5 on values of ~7: inside the 1e-4 relative term; c = 5e-6 for the terms near 0
+# i.e. the HIP path may differ from the fp32 oracle by about as much as the fp32 oracle differs from the truth.  Measured on
+# MI355X (EGX_TOL_REPORT): 0.05 - 0.5 of these bounds.
+_FLOOR_C = {"m": 5e-6, "unit": 1e-5, "ego": 1.5e-4, "reward": 5e-6}
 
 
-def _close(a, b, tol=TOL, what=""):
+def _kind(what):
+    w = what.lower()
+    if "egosensing" in w:
+        return "ego"
+    if w.startswith("r_") or "reward" in w:
+        return "reward"
+    if any(k in w for k in ("state", "r0", "glorot", "seed pose", "obs dist", "obs time")):
+        return "unit"
+    return "m"
+
+
+def _world_scale(w):
+    """Largest world coordinate in play (metres): where the bodies are."""
+    o = w["oracle"]
+    return max(1.0, float(o.T0.abs().max()), float(o.wpath.abs().max()))
+
+
+def _close(a, b, tol=TOL, what="", scale=None):
     a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, np.float64)
     b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, np.float64)
-    scale = max(1.0, float(np.abs(b).max()))
-    err = float(np.abs(a - b).max())
-    assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol * scale:.3e}"
+    S = max(1.0, float(np.abs(b).max()) if b.size else 1.0, float(scale or 0.0))
+    d = np.abs(a - b)
+    rep = os.environ.get("EGX_TOL_REPORT")
+    if tol < 1e-5:      # quantities that must agree exactly / to the last bits (integer-valued terms, copied tables)
+        bound = np.full_like(d, tol * S)
+    else:
+        bound = TOL * np.abs(b) + _FLOOR_C[_kind(what)] * S
+    if rep:   # development aid: how much of each bound is used
+        with open(rep, "a") as f:
+            f.write(f"{what:<28s} n={a.size:<8d} S={S:9.3e} max|d|={d.max() if d.size else 0:9.3e} "
+                    f"max d/bound={np.max(d / np.maximum(bound, 1e-300)) if d.size else 0:9.3e}\n")
+    bad = d > bound
+    assert not bad.any(), (f"{what}: {int(bad.sum())} of {d.size} entries outside 1e-4 |b| + floor; worst |d| {d.max():.3e} "
+                           f"at |b| {np.abs(b).flat[int(np.argmax(d - bound))]:.3e}, bound {bound.flat[int(np.argmax(d - bound))]:.3e}")
 
 
 def _seed_inputs(env, A, variant):
@@ -47,15 +90,16 @@ def _sync_oracle_from_gpu(w):
 
 def _compare_state(w, tol=TOL):
     env, o = w["env"], w["oracle"]
-    _close(env.state, o.state, tol, "state")
-    _close(env.seed[..., :3], o.body_param_seed[..., :3], tol, "seed transl")
-    _close(env.seed[..., 6:], o.body_param_seed[..., 6:], tol, "seed pose")
+    S = _world_scale(w)
+    _close(env.state, o.state, tol, "state", S)
+    _close(env.seed[..., :3], o.body_param_seed[..., :3], tol, "seed transl", S)
+    _close(env.seed[..., 6:], o.body_param_seed[..., 6:], tol, "seed pose", S)
     from oracle.rot import tgm_angle_axis_to_rotation_matrix as aa2R
-    _close(aa2R(env.seed[..., 3:6].reshape(-1, 3).cpu()), aa2R(o.body_param_seed[..., 3:6].reshape(-1, 3)), tol, "seed glorot")
-    _close(env.R0, o.R0, tol, "R0")
-    _close(env.T0, o.T0.reshape(-1, 3), tol, "T0")
-    _close(env.dist, o.dist, tol, "dist")
-    _close(env.wpath, o.wpath, tol, "wpath")
+    _close(aa2R(env.seed[..., 3:6].reshape(-1, 3).cpu()), aa2R(o.body_param_seed[..., 3:6].reshape(-1, 3)), tol, "seed glorot", S)
+    _close(env.R0, o.R0, tol, "R0", S)
+    _close(env.T0, o.T0.reshape(-1, 3), tol, "T0", S)
+    _close(env.dist, o.dist, tol, "dist", S)
+    _close(env.wpath, o.wpath, tol, "wpath", S)
 
 
 def test_reset_sdf_matches_oracle():
@@ -66,7 +110,7 @@ def test_reset_sdf_matches_oracle():
     obs = env.reset()
     oobs, accept = _oracle_reset(w, pairs, [0] * 5)
     _compare_state(w)
-    _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
+    _close(obs["egosensing"], oobs["egosensing"], TOL, "egosensing", _world_scale(w))
     _close(obs["dist"], oobs["dist"].reshape(-1), TOL, "obs dist")
     assert torch.all(obs["time"] == 1)
     # the pre-validated acceptance mask equals the oracle's start check
@@ -101,14 +145,14 @@ def test_step_sdf_matches_oracle(finetuning):
         oobs, orew, oterm = o.step(z)
         L = o.last
         _close(env.Y_gen, L["Y_gen"], TOL, "Y_gen (marker trajectories)")
-        _close(env.pred_params[..., :3], L["pred_params"][..., :3], 2e-4, "pred transl")
-        _close(env.joints.reshape(A, 20, -1, 3), L["joints"], 2e-4, "SMPL-X joints")
-        _close(env.markers.reshape(A, 20, -1, 3), L["markers_proj"], 2e-4, "projected markers")
+        _close(env.pred_params[..., :3], L["pred_params"][..., :3], TOL, "pred transl")
+        _close(env.joints.reshape(A, 20, -1, 3), L["joints"], TOL, "SMPL-X joints")
+        _close(env.markers.reshape(A, 20, -1, 3), L["markers_proj"], TOL, "projected markers")
         names = ["r_skate", "r_floor", "r_face", "r_look", "r_goal", "r_target_dist", "r_pene", "r_vp"]
         for i, nme in enumerate(names):
             if nme == "r_pene":
                 continue
-            _close(env.rterms[:, i], L[nme], 2e-4, nme)
+            _close(env.rterms[:, i], L[nme], TOL, nme)
         # integer penetration counts: exact except for vertices within fp32 round-off (2e-5 m) of the zero level set; the
         # tolerance of r_pene = exp(-sum(count) / 20 / 10) and of the reward follows from that bound, nothing is added to it
         dcnt = (env.pene_count.reshape(A, 20).cpu().long() - L["pene_count"]).abs()
@@ -121,9 +165,9 @@ def test_step_sdf_matches_oracle(finetuning):
         d_rew = (rew.cpu().double() - orew.double()).abs()
         assert (d_rew <= w_pene * slack + 2e-4 * max(1.0, float(orew.abs().max()))).all(), d_rew.max()
         assert term.cpu().bool().tolist() == oterm.tolist()
-        _compare_state(w, 3e-4)
-        _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
-        _close(obs["dist"], oobs["dist"].reshape(-1), 2e-4, "obs dist")
+        _compare_state(w)
+        _close(obs["egosensing"], oobs["egosensing"], TOL, "egosensing", _world_scale(w))
+        _close(obs["dist"], oobs["dist"].reshape(-1), TOL, "obs dist")
         _close(obs["time"], oobs["time"].reshape(-1), 1e-6, "obs time")
 
 
@@ -162,7 +206,7 @@ def test_reset_and_step_box_match_oracle():
     oobs, _ = _oracle_reset(w, pairs[ar, ka], variant[ar, ka], yaw[ar, ka], scene[ar, ka])
     _compare_state(w)
     assert env.scene_idx.cpu().tolist() == scene[ar, ka].tolist()
-    _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
+    _close(obs["egosensing"], oobs["egosensing"], TOL, "egosensing", _world_scale(w))
     g = torch.Generator().manual_seed(5)
     for it in range(2):
         _sync_oracle_from_gpu(w)
@@ -170,10 +214,10 @@ def test_reset_and_step_box_match_oracle():
         obs, rew, term = env.step(z.cuda(), auto_reset=False)
         oobs, orew, oterm = o.step(z)
         _close(env.rterms[:, 6], o.last["r_pene"], 1e-6, "r_pene (box)")
-        _close(rew, orew, 3e-4, "reward")
+        _close(rew, orew, TOL, "reward")
         assert term.cpu().bool().tolist() == oterm.tolist()
-        _compare_state(w, 3e-4)
-        _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
+        _compare_state(w)
+        _close(obs["egosensing"], oobs["egosensing"], TOL, "egosensing", _world_scale(w))
 
 
 def test_box_reset_retries_like_the_reference_loop():
@@ -228,7 +272,7 @@ def test_box_reset_retries_like_the_reference_loop():
     oobs, _ = _oracle_reset(w, pairs[ar, ka], variant[ar, ka], yaw[ar, ka], scene[ar, ka])
     _compare_state(w)
     assert env.scene_idx.cpu().tolist() == scene[ar, ka].tolist()
-    _close(obs["egosensing"], oobs["egosensing"], 2e-4, "egosensing")
+    _close(obs["egosensing"], oobs["egosensing"], TOL, "egosensing", _world_scale(w))
     # a masked auto-reset: only the flagged agents are touched, untouched agents are not reported pending
     before = env.state.clone()
     mask = torch.tensor([0, 1, 0, 0, 0, 0], dtype=torch.int32, device="cuda")
@@ -328,10 +372,10 @@ def test_crowd_group_matches_oracle_with_sequential_hole_updates():
             obs, rew, term = m.step(z.cuda(), auto_reset=False)
             oobs, orew, oterm = o.step(z)
             _close(m.rterms[:, 6], o.last["r_pene"], 1e-6, f"r_pene member {k}")
-            _close(rew, orew, 3e-4, f"reward member {k}")
+            _close(rew, orew, TOL, f"reward member {k}")
             assert term.cpu().bool().tolist() == oterm.tolist()
-            _close(obs["egosensing"], oobs["egosensing"], 2e-4, f"egosensing member {k}")
-            _close(grp.bbox[k], o.own_bbox(), 2e-4, f"published box member {k}")
+            _close(obs["egosensing"], oobs["egosensing"], TOL, f"egosensing member {k}", max(1.0, float(o.T0.abs().max())))
+            _close(grp.bbox[k], o.own_bbox(), TOL, f"published box member {k}")
     # some rays must actually be shortened by another member's box in this layout
     assert float(grp.members[0].obs_ego.min()) < 0.9
 
@@ -499,10 +543,10 @@ def test_egobody_pair_matches_oracle(static_scene):
             oobs, orew, oterm = o.step(z)
             _close(m.rterms[:, 6], o.last["r_pene"], 1e-6, f"r_pene member {k}")
             _close(m.rterms[:, 7], o.last["r_vp"], 1e-6, f"r_vp member {k}")
-            _close(rew, orew, 3e-4, f"reward member {k}")
+            _close(rew, orew, TOL, f"reward member {k}")
             assert term.cpu().bool().tolist() == oterm.tolist() and not term.any()       # two steps < max_depth
             saw_goal |= bool((o.last["r_goal"] > 0).any())
-            _close(obs["egosensing"], oobs["egosensing"], 2e-4, f"egosensing member {k}")
+            _close(obs["egosensing"], oobs["egosensing"], TOL, f"egosensing member {k}", max(1.0, float(o.T0.abs().max())))
             flags[k] |= o.last["invalid"]                                                # the kernel ORs over the steps
             assert m.invalid.cpu().tolist() == flags[k].tolist()
     if not static_scene:   # the other member's box must shorten some ray / block some cell in this layout
