@@ -115,6 +115,15 @@ class BodyModelHandle:
             self._ws[key] = ws
         return ws
 
+    def cull_stats(self, B: int):
+        """(items evaluated, items of an unculled call) of the LAST culled SDF forward of B bodies on the current stream's
+        workspace (`egx_lbs_cull_stats`; synchronises with the host).  An item = one vertex tile x 256 bodies."""
+        lib = _lib.load()
+        act, tot = C.c_int32(), C.c_int32()
+        torch.cuda.current_stream().synchronize()
+        _lib.check(lib.egx_lbs_cull_stats(self.handle, _lib.ptr(self.workspace(B)), int(B), C.byref(act), C.byref(tot)), "egx_lbs_cull_stats")
+        return int(act.value), int(tot.value)
+
     def forward(self, xb: torch.Tensor, betas: torch.Tensor, frames_per_agent: int, want_verts=False,
                 want_joints=True, want_markers=True, sdf: Optional[SdfScene] = None,
                 R0: Optional[torch.Tensor] = None, T0: Optional[torch.Tensor] = None, out: Optional[dict] = None):

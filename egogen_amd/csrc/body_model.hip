@@ -124,6 +124,12 @@ struct egx_body_model {
   int* extra_slot = nullptr;   // [21]
   int* lmk_slot = nullptr;     // [153]
   float* lmk_bary = nullptr;   // [153]
+  // free-space culling of SDF work items (see egx_lbs_cull_kernel): per-tile bounds of how far a posed vertex can be from the
+  // posed joints it is bound to
+  float* cull_E = nullptr;     // [NVT][64]: [0,10) shape terms, [10,61) pose terms per movable joint (compact order), rest 0
+  float* cull_D0 = nullptr;    // [tj_off[NVT]]: rest distance bound per (tile, joint of its list)
+  int cull_ok = 0;             // skinning weights are a convex combination (>= 0, rows sum to 1): the bound holds
+  float rest_pelvis[3] = {0.f, 0.f, 0.f};   // root joint of the mean shape (host copy)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -137,19 +143,27 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
                                                              f32x4* __restrict__ A4,     // [bt][55][3][32]
                                                              float* __restrict__ out_joints, int joints_ld,
                                                              float template_lo_feat /* 1 in the two-plane blend mode */,
-                                                             int* __restrict__ zero_counts /* [B] cleared here, or null */) {
+                                                             int* __restrict__ zero_counts /* [B] cleared here, or null */,
+                                                             const int* __restrict__ agent_of_slot /* culled launches: slot order */,
+                                                             float* __restrict__ fvec /* [64][Bp] |beta|, ||R_j - I||_F or null */,
+                                                             float* __restrict__ jpos /* [55][3][Bp] posed joints + transl or null */,
+                                                             int Bp) {
   __shared__ float sR[4][NJ][9];
   __shared__ float sJ[4][NJ][3];
   __shared__ float sG[4][NJ][12];
   __shared__ __attribute__((aligned(16))) unsigned short sF3[4][3][KS3 * 16];  // bf16x3 planes of the 4 bodies of the block
   const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + w;
-  const bool live = b < B;
+  // a block works on four SLOTS of the operand buffers; slot s holds body agent_of_slot[s / fpa] * fpa + s % fpa (identity
+  // without the table): inputs and per-body outputs are addressed by body, the GEMM operands by slot
+  const int slot = blockIdx.x * 4 + w;
+  const bool live = slot < B;
+  const int ss = live ? slot : B - 1;
+  const int b = agent_of_slot ? agent_of_slot[ss / fpa] * fpa + ss % fpa : ss;
   if (zero_counts && live && j == 0) zero_counts[b] = 0;   // the SDF epilogue of the skinning kernel adds to these
-  const int bb = live ? b : B - 1;
+  const int bb = b;
   const float* x = xb + (size_t)bb * EGX_XB_DIM;
   const float* be = betas + (size_t)(bb / fpa) * 10;
-  const int bt = bb >> 5, n = bb & 31;
+  const int bt = ss >> 5, n = ss & 31;
   float* featb = feat ? feat + (size_t)bt * KGROUPS * 64 * 4 : nullptr;  // tile base
   unsigned short* feat3b = feat3 ? feat3 + (size_t)bt * KS3 * 3 * 64 * 8 : nullptr;
   auto feat_store = [&](int k, float v) {
@@ -197,6 +211,17 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       sJ[w][j][c] = s;
     }
     for (int e = 0; e < 9; ++e) sR[w][j][e] = R[e];
+    if (live && fvec) {
+      if (j < 10) fvec[(size_t)j * Bp + slot] = fabsf(be[j]);
+      if (j >= 1 && (j < 22 || j > 24)) {
+        float q = 0.f;
+        for (int e = 0; e < 9; ++e) {
+          const float dlt = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+          q += dlt * dlt;
+        }
+        fvec[(size_t)(10 + egx_compact_joint(j)) * Bp + slot] = sqrtf(q) * 1.000001f;
+      }
+    }
     if (live) {
       if (j < 10) feat_store(j, be[j]);
       if (j >= 1 && (j < 22 || j > 24)) {
@@ -218,7 +243,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
     // bodies of the block are neighbours in n, so a quarter-wave writes 64 contiguous bytes
     for (int c = threadIdx.x; c < KS3 * 3 * 2 * 4; c += 256) {
       const int wb = c & 3, hf = (c >> 2) & 1, pl = (c >> 3) % 3, sidx = c / 24;
-      const int body = blockIdx.x * 4 + wb;
+      const int body = blockIdx.x * 4 + wb;   // slot
       if (body < B) {
         const int4 frag = *reinterpret_cast<const int4*>(&sF3[wb][pl][sidx * 16 + hf * 8]);
         unsigned short* dst = feat3 + ((((size_t)(body >> 5) * KS3 + sidx) * 3 + pl) * 64 + hf * 32 + (body & 31)) * 8;
@@ -264,6 +289,11 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       float* o = out_joints + ((size_t)b * joints_ld + j) * 3;
       o[0] = G[3] + x[0]; o[1] = G[7] + x[1]; o[2] = G[11] + x[2];
     }
+    if (jpos) {
+      jpos[(size_t)(j * 3 + 0) * Bp + slot] = G[3] + x[0];
+      jpos[(size_t)(j * 3 + 1) * Bp + slot] = G[7] + x[1];
+      jpos[(size_t)(j * 3 + 2) * Bp + slot] = G[11] + x[2];
+    }
   }
 }
 
@@ -295,6 +325,11 @@ struct LbsParams {
   const float* R0;     // [A][9] or null
   const float* T0;     // [A][3] or null
   int* pene;           // [B]
+  // culled launches (egx_lbs_cull_kernel): operand slot -> body order, and per-XCD lists of the active work items
+  const int* agent_of_slot;   // [B / fpa] or null (identity)
+  const int* items;           // [8][items_stride] codes tile_index * nbg + body_group, or null (walk every item)
+  const int* item_counts;     // [8]
+  int items_stride;
 };
 
 // one v_fma_f32, opaque to the SLP vectoriser (which would pair adjacent rows into v_pk_fma_f32 again)
@@ -391,9 +426,11 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
   bool bvalid[NB];
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
-    body[q] = (bt0 + q) * 32 + n;
-    bvalid[q] = body[q] < p.B;
-    const int bb = bvalid[q] ? body[q] : p.B - 1;
+    const int slot = (bt0 + q) * 32 + n;     // operand slot; the body it holds (culled launches re-order the agents):
+    bvalid[q] = slot < p.B;
+    const int sl = bvalid[q] ? slot : p.B - 1;
+    body[q] = p.agent_of_slot ? p.agent_of_slot[sl / p.fpa] * p.fpa + sl % p.fpa : sl;
+    const int bb = body[q];
     tr[q][0] = p.xb[(size_t)bb * EGX_XB_DIM + 0];
     tr[q][1] = p.xb[(size_t)bb * EGX_XB_DIM + 1];
     tr[q][2] = p.xb[(size_t)bb * EGX_XB_DIM + 2];
@@ -467,7 +504,7 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
       // eight-corner interpolation; executed in place that would run for the whole wave whenever ONE lane needs it, and
       // with 64 different bodies across the lanes that is almost every row.  Undecided points are therefore appended
       // to a wave-private LDS queue and evaluated densely (64 queued points per pass) by sdf_flush().
-      const int ag = (bvalid[q] ? body[q] : p.B - 1) / p.fpa;
+      const int ag = body[q] / p.fpa;
       // canonical frame -> world (R0, T0) -> unclamped voxel coordinates ((w - c) scale + 1) d / 2 - 1 / 2 folded into one
       // affine map per body (align_corners=False, utils.py:58-68); the clamp (padding "border") happens in the lookup /
       // before the exact evaluation.  The folded rounding differs from the reference's chain by ~1e-7 relative - far
@@ -573,8 +610,11 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
     __builtin_amdgcn_wave_barrier();
     const int c = s_cnt[lane];            // lane = q*32 + n: one global atomic per body and item
     s_cnt[lane] = 0;
-    const int bd = (bt0 + (lane >> 5)) * 32 + (lane & 31);
-    if (c != 0 && bd < p.B) atomicAdd(p.pene + bd, c);
+    const int sd = (bt0 + (lane >> 5)) * 32 + (lane & 31);
+    if (c != 0 && sd < p.B) {
+      const int bd = p.agent_of_slot ? p.agent_of_slot[sd / p.fpa] * p.fpa + sd % p.fpa : sd;
+      atomicAdd(p.pene + bd, c);
+    }
     __builtin_amdgcn_wave_barrier();
   }
 #ifdef EGX_LBS_TIMING
@@ -847,11 +887,7 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
   const int PB = max(1, min(p.bg_block, max(nper, 1)));
   unsigned long long tacc[4] = {0, 0, 0, 0};
   (void)tacc;
-  for (int item = stream; item < n_items; item += n_streams) {
-    const int blk = item / (nvt * PB);
-    const int pb = min(PB, nper - blk * PB);
-    const int r = item - blk * nvt * PB;
-    const int vti = vt_lo + r / pb, bg = bg_lo + blk * PB + r % pb;
+  auto run_item = [&](int vti, int bg) {
     const int vt = p.tiles ? p.tiles[vti] : vti;
     const int bt0 = bg * 8 + wave * NB;
     __syncthreads();  // previous item: every wave is done with the metadata and with the stage ring
@@ -885,15 +921,216 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) sum += acc[c][q][r];
       if (sum == 123.456f) p.pene[0] = 1;
-      continue;
+      return;
     }
     lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP>(p, w, acc, vt, bt0, JT);
+  };
+  if (p.items) {
+    // culled launch: this XCD's list of active items (egx_lbs_compact_kernel: an item whose 256 bodies are provably in free
+    // space for the whole vertex tile is not on it), dealt round-robin to the XCD's workgroups
+    const int xcd = blockIdx.x & 7, ns = gridDim.x >> 3, st = blockIdx.x >> 3;
+    const int cnt = p.item_counts[xcd];
+    const int* list = p.items + (size_t)xcd * p.items_stride;
+    for (int i = st; i < cnt; i += ns) {
+      const int code = list[i];
+      const int vti = code / p.nbg;
+      run_item(vti, code - vti * p.nbg);
+    }
+  } else {
+    for (int item = stream; item < n_items; item += n_streams) {
+      const int blk = item / (nvt * PB);
+      const int pb = min(PB, nper - blk * PB);
+      const int r = item - blk * nvt * PB;
+      run_item(vt_lo + r / pb, bg_lo + blk * PB + r % pb);
+    }
   }
 #ifdef EGX_LBS_TIMING
   if (lane == 0)
     for (int i = 0; i < 4; ++i) atomicAdd(&g_lbs_t[i], tacc[i]);
 #endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// Free-space culling of the SDF work items (training path: split blend modes, picks + penetration counts, no vertex output).
+//
+// The penetration count needs EVERY vertex of every body (crowd_env_2f.py:165-175), which is what makes the blend GEMM the
+// dominant cost - but a vertex can only count where the scene has geometry.  A posed vertex lies in the convex hull of balls
+// around the posed joints it is bound to (radii bounded per tile at load, egx_body_model_create), so a (vertex tile, body)
+// pair whose hull's bounding box - mapped to voxel coordinates - only covers cells of the free-space pyramid with max < 0
+// cannot contribute to the count: trilinear interpolation is a convex combination of the samples a cell's bracket covers.
+// A work item (tile x 256 bodies) all of whose bodies pass that test is skipped ENTIRELY (GEMM, skinning, SDF) unless the tile
+// holds picked vertices.  The result is bit-identical to the unculled launch (tests/test_lbs_gpu.py); what changes is how much
+// of the scene-independent work is done.  Three small launches in front of the fused kernel:
+//   egx_lbs_agent_order_kernel  agents whose neighbourhood is free first: bodies near geometry share body groups
+//   egx_lbs_cull_kernel         the test per (tile, body), OR-reduced per item
+//   egx_lbs_compact_kernel      per-XCD item lists (non-picked tiles dealt by tile chunk: an XCD streams an eighth of the bases)
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int CULL_TILES_PER_BLOCK = 16;
+constexpr float CULL_SLACK_M = 2e-3f;        // metres added to every radius: covers the fp32 / bf16x2 evaluation of the vertex
+constexpr float CULL_SLACK_VOX = 0.02f;      // voxels added to the box: covers the rounding of the affine map
+
+// raw (unclamped) voxel-coordinate box [lo, hi] -> true if every point in it interpolates to a value < 0 (free space)
+__device__ __forceinline__ bool cull_box_free(const SdfDev& s, const float* __restrict__ mips, const float (&lo)[3], const float (&hi)[3]) {
+  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return false;   // NaN / inverted: not provable
+  const int cdim[3] = {s.c0, s.c1, s.c2};
+  int jl[3], jh[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    jl[a] = (int)__builtin_amdgcn_fmed3f(floorf(fmaf(lo[a], 0.25f, 1.f)), 0.f, (float)(cdim[a] + 1));
+    jh[a] = (int)__builtin_amdgcn_fmed3f(floorf(fmaf(hi[a], 0.25f, 1.f)), 0.f, (float)(cdim[a] + 1));
+  }
+  for (int l = 0; l <= EGX_SDF_MIP_LEVELS; ++l) {
+    if ((jh[0] >> l) - (jl[0] >> l) > 1 || (jh[1] >> l) - (jl[1] >> l) > 1 || (jh[2] >> l) - (jl[2] >> l) > 1) continue;
+    const int e1 = l == 0 ? s.c1 + 2 : egx_sdf_mip_dim(s.c1, l), e2 = l == 0 ? s.c2 + 2 : egx_sdf_mip_dim(s.c2, l);
+    const float* mp = l == 0 ? nullptr : mips + egx_sdf_mip_offset(s.c0, s.c1, s.c2, l);
+    float mx = -3.4e38f;
+    for (int x = jl[0] >> l; x <= jh[0] >> l; ++x)
+      for (int y = jl[1] >> l; y <= jh[1] >> l; ++y)
+        for (int z = jl[2] >> l; z <= jh[2] >> l; ++z) {
+          const size_t idx = ((size_t)x * e1 + y) * e2 + z;
+          mx = fmaxf(mx, l == 0 ? s.coarse[idx].y : mp[idx]);
+        }
+    return mx < 0.f;
+  }
+  return false;   // larger than two cells of the coarsest level
+}
+
+// canonical frame -> raw voxel coordinates of an agent: r = Mw x + tw (the affine map of the SDF epilogue)
+__device__ __forceinline__ void cull_agent_map(const SdfDev& s, const float* R0, const float* T0, int ag, float (&Mw)[9], float (&tw)[3], float (&kk)[3]) {
+  kk[0] = s.scale * (float)s.d0 * 0.5f; kk[1] = s.scale * (float)s.d1 * 0.5f; kk[2] = s.scale * (float)s.d2 * 0.5f;
+  const float cc[3] = {s.cx, s.cy, s.cz};
+  const float dd[3] = {(float)s.d0, (float)s.d1, (float)s.d2};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) Mw[a * 3 + e] = kk[a] * (R0 ? R0[(size_t)ag * 9 + a * 3 + e] : ((a == e) ? 1.f : 0.f));
+    tw[a] = kk[a] * ((T0 ? T0[(size_t)ag * 3 + a] : 0.f) - cc[a]) + (dd[a] - 1.f) * 0.5f;
+  }
+}
+
+// One block.  (1) clears the item flags and counters of this launch; (2) classifies every agent: "far" = the 1 m cube around
+// the pelvis of its first and last frame is free space; (3) slot order = far agents, then near agents (stable).
+__global__ __launch_bounds__(256) void egx_lbs_agent_order_kernel(const float* __restrict__ xb, const float* __restrict__ R0,
+                                                                  const float* __restrict__ T0, SdfDev sdf, const float* __restrict__ mips,
+                                                                  int A, int fpa, float px, float py, float pz,
+                                                                  int* __restrict__ agent_of_slot, int* __restrict__ flags, int n_flags,
+                                                                  int* __restrict__ counts) {
+  extern __shared__ int s_key[];   // [A]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n_flags; i += 256) flags[i] = 0;
+  if (tid < 16) counts[tid] = 0;
+  for (int a = tid; a < A; a += 256) {
+    float Mw[9], tw[3], kk[3];
+    cull_agent_map(sdf, R0, T0, a, Mw, tw, kk);
+    bool far = true;
+    for (int f = 0; f < fpa; f += max(1, fpa - 1)) {   // first and last frame
+      const float* x = xb + ((size_t)a * fpa + f) * EGX_XB_DIM;
+      const float c[3] = {x[0] + px, x[1] + py, x[2] + pz};
+      float lo[3], hi[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const float r = fmaf(Mw[ax * 3 + 0], c[0], fmaf(Mw[ax * 3 + 1], c[1], fmaf(Mw[ax * 3 + 2], c[2], tw[ax])));
+        lo[ax] = r - 1.0f * kk[ax]; hi[ax] = r + 1.0f * kk[ax];
+      }
+      far = far && cull_box_free(sdf, mips, lo, hi);
+    }
+    s_key[a] = far ? 0 : 1;
+  }
+  __syncthreads();
+  if (tid < 64) {   // stable partition by one wave: 64 agents per step
+    int base = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int a0 = 0; a0 < A; a0 += 64) {
+        const int a = a0 + tid;
+        const bool mine = a < A && s_key[a] == pass;
+        const unsigned long long bm = __ballot(mine);
+        if (mine) agent_of_slot[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u))] = a;
+        base += __popcll(bm);
+      }
+  }
+}
+
+// grid (nbg, tile chunks), 256 threads = the 256 slots of a body group.  flags[ti * nbg + bg] = 1 where some body of the
+// group cannot be proven clear of geometry for tile ti of the launch's tile list (ti >= first_tile: the picked tiles in
+// front are always evaluated).
+__global__ __launch_bounds__(256) void egx_lbs_cull_kernel(const int* __restrict__ tiles, int first_tile, int n_tiles,
+                                                           const int* __restrict__ tj_off, const int* __restrict__ tj_idx,
+                                                           const float* __restrict__ D0, const float* __restrict__ E,
+                                                           const float* __restrict__ fvec, const float* __restrict__ jpos, int Bp,
+                                                           const int* __restrict__ agent_of_slot, int B, int fpa, int nbg,
+                                                           const float* __restrict__ R0, const float* __restrict__ T0, SdfDev sdf,
+                                                           const float* __restrict__ mips, int* __restrict__ flags) {
+  const int bg = blockIdx.x, tid = threadIdx.x;
+  const int slot = bg * 256 + tid;
+  const bool valid = slot < B;
+  const int ss = valid ? slot : B - 1;
+  const int body = agent_of_slot ? agent_of_slot[ss / fpa] * fpa + ss % fpa : ss;
+  float Mw[9], tw[3], kk[3];
+  cull_agent_map(sdf, R0, T0, body / fpa, Mw, tw, kk);
+  float f[61];
+#pragma unroll
+  for (int i = 0; i < 61; ++i) f[i] = fvec[(size_t)i * Bp + ss];
+  const int t_lo = first_tile + blockIdx.y * CULL_TILES_PER_BLOCK, t_hi = min(n_tiles, t_lo + CULL_TILES_PER_BLOCK);
+  for (int ti = t_lo; ti < t_hi; ++ti) {
+    const int vt = __builtin_amdgcn_readfirstlane(tiles ? tiles[ti] : ti);   // uniform: the tables below are read with scalar loads
+    const float* Et = E + (size_t)vt * 64;
+    float margin = CULL_SLACK_M;
+#pragma unroll
+    for (int i = 0; i < 61; ++i) margin = fmaf(f[i], Et[i], margin);
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    const int jj_lo = __builtin_amdgcn_readfirstlane(tj_off[vt]), jj_hi = __builtin_amdgcn_readfirstlane(tj_off[vt + 1]);
+    for (int jj = jj_lo; jj < jj_hi; ++jj) {
+      const int j = __builtin_amdgcn_readfirstlane(tj_idx[jj]);
+      const float rho = (D0[jj] + margin) * 1.0001f;
+      const float c0 = jpos[(size_t)(j * 3 + 0) * Bp + ss], c1 = jpos[(size_t)(j * 3 + 1) * Bp + ss], c2 = jpos[(size_t)(j * 3 + 2) * Bp + ss];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float r = fmaf(Mw[a * 3 + 0], c0, fmaf(Mw[a * 3 + 1], c1, fmaf(Mw[a * 3 + 2], c2, tw[a])));
+        const float ext = rho * kk[a] + CULL_SLACK_VOX + 1e-5f * fabsf(r);
+        lo[a] = fminf(lo[a], r - ext); hi[a] = fmaxf(hi[a], r + ext);
+      }
+    }
+    const bool active = valid && !cull_box_free(sdf, mips, lo, hi);
+    if (__ballot(active) != 0ull && (tid & 63) == 0) flags[(size_t)ti * nbg + bg] = 1;
+  }
+}
+
+// 8 blocks of one wave: block x builds the item list of XCD x.  Picked tiles (ti < first_tile, always active) go to XCD
+// bg % 8; the other tiles are dealt in eighths of the tile list (an XCD streams only its chunk of the bases), in the order
+// "block of bg_block body groups, tile, group of the block" so that the features of a block stay in the XCD's L2.
+__global__ __launch_bounds__(64) void egx_lbs_compact_kernel(const int* __restrict__ flags, int first_tile, int n_tiles, int nbg, int bg_block,
+                                                             int* __restrict__ items, int items_stride, int* __restrict__ counts) {
+  const int x = blockIdx.x, lane = threadIdx.x;
+  int* list = items + (size_t)x * items_stride;
+  int n = 0;
+  auto append = [&](bool on, int code) {
+    const unsigned long long bm = __ballot(on);
+    if (on) list[n + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u))] = code;
+    n += __popcll(bm);
+  };
+  const int n_mine = (nbg - x + 7) / 8;   // body groups x, x + 8, ...
+  for (int i0 = 0; i0 < n_mine * first_tile; i0 += 64) {
+    const int i = i0 + lane;
+    const bool on = i < n_mine * first_tile;
+    const int bg = x + 8 * (on ? i / first_tile : 0), ti = on ? i % first_tile : 0;
+    append(on, ti * nbg + bg);
+  }
+  const int n_np = n_tiles - first_tile, per_t = (n_np + 7) / 8;
+  const int t_lo = first_tile + x * per_t, t_n = max(0, min(per_t, n_tiles - t_lo));
+  const int PB = max(1, bg_block), n_blk = (nbg + PB - 1) / PB;
+  const int total = n_blk * t_n * PB;
+  for (int i0 = 0; i0 < total; i0 += 64) {
+    const int i = i0 + lane;
+    bool on = i < total;
+    const int blk = on ? i / (t_n * PB) : 0, r = on ? i % (t_n * PB) : 0;
+    const int ti = t_lo + r / PB, bg = blk * PB + r % PB;
+    on = on && bg < nbg && flags[(size_t)ti * nbg + bg] != 0;
+    append(on, ti * nbg + bg);
+  }
+  if (lane == 0) { counts[x] = n; atomicAdd(&counts[8], n); }
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // kernel 3: assemble joints[55..126] and markers from the picked vertices
@@ -1151,7 +1388,66 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
   std::memcpy(pc.hand_mean, d->hand_mean_l_host, 45 * sizeof(float));
   std::memcpy(pc.hand_mean + 45, d->hand_mean_r_host, 45 * sizeof(float));
 
+  // ---- bounds for the free-space culling of SDF work items.  A posed vertex is a convex combination over its joints j of
+  // R_j (v~ - J_j) + p_j (p_j: posed joint, J_j: shaped rest joint, v~: template + shape and pose offsets), so it lies in the
+  // convex hull of the balls B(p_j, |v~ - J_j|), and
+  //   |v~ - J_j| <= |v_t - J_t,j| + sum_k |beta_k| |S_k,v - JS_k,j| + sum_j' ||R_j' - I||_F ||P_j',v||_F
+  // (Cauchy-Schwarz per joint block of the pose blend shapes).  Per tile: D0 = max of the first term over the vertices bound
+  // to the joint, E = the maxima of the coefficient norms over the tile's vertices (and its joints, for the shape term).
+  std::vector<float> cull_E((size_t)NVT * 64, 0.f), cull_D0(tj_idx.size(), 0.f);
+  bool convex = true;
+  for (int v = 0; v < V && convex; ++v) {
+    double sum = 0.0;
+    for (int j = 0; j < NJ; ++j) {
+      const float wv = d->lbs_weights_host[(size_t)v * NJ + j];
+      if (wv < 0.f) convex = false;
+      sum += wv;
+    }
+    if (std::fabs(sum - 1.0) > 1e-4) convex = false;
+  }
+  // the culled launch treats the first n_pick_tiles entries of the SDF tile list as "always evaluated"
+  for (size_t i = 0; i < pick_tiles.size() && convex; ++i) convex = i < sdf_tiles.size() && sdf_tiles[i] == pick_tiles[i];
+  m->cull_ok = convex ? 1 : 0;
+  for (int c = 0; c < 3; ++c) m->rest_pelvis[c] = pc.J_template[c];
+  for (int vt = 0; vt < NVT && convex; ++vt) {
+    float* E = &cull_E[(size_t)vt * 64];
+    for (int r = 0; r < 32; ++r) {
+      const int v = perm[vt * 32 + r];
+      if (v < 0) continue;
+      for (int jj = tj_off[vt]; jj < tj_off[vt + 1]; ++jj) {
+        const int j = tj_idx[jj];
+        if (d->lbs_weights_host[(size_t)v * NJ + j] != 0.f) {
+          double q = 0.0;
+          for (int c = 0; c < 3; ++c) {
+            const double e = (double)d->v_template_host[(size_t)v * 3 + c] - (double)pc.J_template[j * 3 + c];
+            q += e * e;
+          }
+          cull_D0[jj] = std::max(cull_D0[jj], (float)(std::sqrt(q) * (1.0 + 1e-6)));
+        }
+        for (int k = 0; k < 10; ++k) {   // shape term, over every joint of the tile's list (a superset of the vertex's own)
+          double q = 0.0;
+          for (int c = 0; c < 3; ++c) {
+            const double e = (double)d->shapedirs_host[((size_t)v * 3 + c) * 10 + k] - (double)pc.J_shapedirs[(j * 3 + c) * 10 + k];
+            q += e * e;
+          }
+          E[k] = std::max(E[k], (float)(std::sqrt(q) * (1.0 + 1e-6)));
+        }
+      }
+      for (int jc = 0; jc < 51; ++jc) {
+        const int j = jc + 1 + (jc >= 21 ? 3 : 0);
+        double q = 0.0;
+        for (int e9 = 0; e9 < 9; ++e9)
+          for (int c = 0; c < 3; ++c) {
+            const double e = d->posedirs_host[(size_t)((j - 1) * 9 + e9) * 3 * V + (size_t)v * 3 + c];
+            q += e * e;
+          }
+        E[10 + jc] = std::max(E[10 + jc], (float)(std::sqrt(q) * (1.0 + 1e-6)));
+      }
+    }
+  }
+
   int rc = EGX_OK;
+  if ((rc = upload(&m->cull_E, cull_E)) || (rc = upload(&m->cull_D0, cull_D0))) { egx_body_model_destroy(m); return rc; }
   {
     unsigned short* d3 = nullptr;
     if ((rc = upload(&d3, dirs3))) { egx_body_model_destroy(m); return rc; }
@@ -1175,6 +1471,7 @@ extern "C" void egx_body_model_destroy(egx_body_model* m) {
   (void)hipFree(m->dirs); (void)hipFree(m->dirs3); (void)hipFree(m->tj_off); (void)hipFree(m->tj_idx); (void)hipFree(m->tj_w);
   (void)hipFree(m->pick_slot); (void)hipFree(m->pick_tiles); (void)hipFree(m->sdf_tiles); (void)hipFree(m->vflags); (void)hipFree(m->vorig); (void)hipFree(m->pc); (void)hipFree(m->marker_slot);
   (void)hipFree(m->extra_slot); (void)hipFree(m->lmk_slot); (void)hipFree(m->lmk_bary);
+  (void)hipFree(m->cull_E); (void)hipFree(m->cull_D0);
   delete m;
 }
 
@@ -1207,17 +1504,58 @@ int blend_mode() {
 }
 struct WsLayout {
   size_t feat, A4, picked, total;
+  // culled SDF launches
+  size_t fvec, jpos, order, flags, items, counts;
+  size_t Bp;
+  int items_stride;
 };
 WsLayout ws_layout(const egx_body_model* m, int B) {
   const size_t Bp = egx_align_up((size_t)B, BODY_PAD);
   WsLayout w;
+  w.Bp = Bp;
   w.feat = 0;
   w.A4 = egx_align_up(w.feat + Bp * std::max<size_t>(KDIM * sizeof(float), (size_t)KS3 * 16 * 3 * 2), 256);
   w.picked = egx_align_up(w.A4 + Bp * NJ * 12 * sizeof(float), 256);
-  w.total = egx_align_up(w.picked + (size_t)B * m->NP * 3 * sizeof(float), 256);
+  w.fvec = egx_align_up(w.picked + (size_t)B * m->NP * 3 * sizeof(float), 256);
+  w.jpos = egx_align_up(w.fvec + 64 * Bp * sizeof(float), 256);
+  w.order = egx_align_up(w.jpos + (size_t)NJ * 3 * Bp * sizeof(float), 256);
+  w.flags = egx_align_up(w.order + (size_t)B * sizeof(int), 256);
+  const size_t n_items = (size_t)m->n_sdf_tiles * (Bp / BODY_PAD);
+  w.items_stride = (int)n_items;
+  w.items = egx_align_up(w.flags + n_items * sizeof(int), 256);
+  w.counts = egx_align_up(w.items + 8 * n_items * sizeof(int), 256);
+  w.total = egx_align_up(w.counts + 16 * sizeof(int), 256);
   return w;
 }
+// free-space culling of SDF work items: on by default, EGX_LBS_CULL=0 / egx_lbs_set_culling(0) walks every item
+std::atomic<int> g_cull{-1};
+int culling_on() {
+  int c = g_cull.load();
+  if (c < 0) {
+    const char* e = getenv("EGX_LBS_CULL");
+    c = (e && std::string(e) == "0") ? 0 : 1;
+    g_cull.store(c);
+  }
+  return c;
+}
 }  // namespace
+
+extern "C" int egx_lbs_set_culling(int on) {
+  g_cull.store(on ? 1 : 0);
+  return EGX_OK;
+}
+extern "C" int egx_lbs_get_culling(void) { return culling_on(); }
+
+extern "C" int egx_lbs_cull_stats(const egx_body_model* m, const void* workspace, int num_bodies, int32_t* out_active_items,
+                                  int32_t* out_total_items) {
+  EGX_REQUIRE(m && workspace && num_bodies > 0 && out_active_items && out_total_items, "bad arguments");
+  const WsLayout wl = ws_layout(m, num_bodies);
+  int c[16];
+  EGX_HIP_CHECK(hipMemcpy(c, static_cast<const char*>(workspace) + wl.counts, sizeof(c), hipMemcpyDeviceToHost));
+  *out_active_items = c[8];
+  *out_total_items = wl.items_stride;
+  return EGX_OK;
+}
 
 #ifdef EGX_LBS_TIMING
 extern "C" int egx_lbs_timing_read(unsigned long long* out16, int reset) {
@@ -1254,7 +1592,8 @@ extern "C" int egx_lbs_joints(const egx_body_model* m, const float* xb, const fl
   char* ws = static_cast<char*>(workspace);
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream_), m->pc, xb,
                      betas, B, fpa, static_cast<float*>(nullptr), static_cast<unsigned short*>(nullptr),
-                     reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ, 0.f, static_cast<int*>(nullptr));
+                     reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ, 0.f, static_cast<int*>(nullptr),
+                     static_cast<const int*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
@@ -1282,9 +1621,45 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
 
   const int mode = blend_mode();   // read ONCE per call: the feature flag of column 470 and the kernel choice must agree
   const bool split3 = mode >= 1 && !out_verts;
+  const int nbg_all = egx_ceil_div(B, BODY_PAD);
+  // free-space culling: SDF counts on the split kernels, a convex-weight model, whole agents, enough items to deal to 8 XCDs
+  const bool cull = split3 && sdf && m->cull_ok && culling_on() && B % fpa == 0 && m->n_sdf_tiles > m->n_pick_tiles &&
+                    (size_t)m->n_sdf_tiles * nbg_all >= 64;
+  SdfDev sd;
+  std::memset(&sd, 0, sizeof(sd));
+  const float* mips = nullptr;
+  if (sdf) {
+    sd.grid = sdf->grid; sd.d0 = sdf->d0; sd.d1 = sdf->d1; sd.d2 = sdf->d2;
+    sd.cx = sdf->center[0]; sd.cy = sdf->center[1]; sd.cz = sdf->center[2]; sd.scale = sdf->scale;
+    sd.coarse = static_cast<const float2*>(sdf->coarse_minmax);
+    sd.c0 = egx_ceil_div(sdf->d0, 4); sd.c1 = egx_ceil_div(sdf->d1, 4); sd.c2 = egx_ceil_div(sdf->d2, 4);
+    mips = reinterpret_cast<const float*>(static_cast<const char*>(sdf->coarse_minmax) + egx_sdf_table_bytes(sd.c0, sd.c1, sd.c2));
+  }
+  int* order = cull ? reinterpret_cast<int*>(ws + wl.order) : nullptr;
+  int* flags = reinterpret_cast<int*>(ws + wl.flags);
+  int* items = reinterpret_cast<int*>(ws + wl.items);
+  int* counts = reinterpret_cast<int*>(ws + wl.counts);
+  float* fvec = cull ? reinterpret_cast<float*>(ws + wl.fvec) : nullptr;
+  float* jpos = cull ? reinterpret_cast<float*>(ws + wl.jpos) : nullptr;
+  if (cull) {
+    const int A = B / fpa;
+    // rest pelvis of the mean shape: the classification of an agent only steers the slot order, it decides nothing
+    const float* pel = m->rest_pelvis;
+    hipLaunchKernelGGL(egx_lbs_agent_order_kernel, dim3(1), dim3(256), (size_t)A * sizeof(int), stream, xb, R0, T0, sd, mips, A, fpa,
+                       pel[0], pel[1], pel[2], order, flags, m->n_sdf_tiles * nbg_all, counts);
+  }
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, stream, m->pc, xb, betas, B, fpa,
                      split3 ? nullptr : feat, split3 ? reinterpret_cast<unsigned short*>(feat) : nullptr, A4, out_joints,
-                     EGX_NUM_JOINTS_OUT, (split3 && mode == 2) ? 1.f : 0.f, sdf ? out_pene_count : nullptr);
+                     EGX_NUM_JOINTS_OUT, (split3 && mode == 2) ? 1.f : 0.f, sdf ? out_pene_count : nullptr,
+                     static_cast<const int*>(order), fvec, jpos, (int)wl.Bp);
+  if (cull) {
+    const int n_np = m->n_sdf_tiles - m->n_pick_tiles;
+    hipLaunchKernelGGL(egx_lbs_cull_kernel, dim3(nbg_all, egx_ceil_div(n_np, CULL_TILES_PER_BLOCK)), dim3(256), 0, stream, m->sdf_tiles,
+                       m->n_pick_tiles, m->n_sdf_tiles, m->tj_off, m->tj_idx, m->cull_D0, m->cull_E, fvec, jpos, (int)wl.Bp,
+                       static_cast<const int*>(order), B, fpa, nbg_all, R0, T0, sd, mips, flags);
+    hipLaunchKernelGGL(egx_lbs_compact_kernel, dim3(8), dim3(64), 0, stream, flags, m->n_pick_tiles, m->n_sdf_tiles, nbg_all, 2, items,
+                       wl.items_stride, counts);
+  }
   if (out_verts || need_picks || sdf) {
     LbsParams p;
     p.dirs = m->dirs; p.tj_off = m->tj_off; p.tj_idx = m->tj_idx; p.tj_w = m->tj_w; p.pick_slot = m->pick_slot;
@@ -1302,18 +1677,12 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     p.dbg = 0;
 #endif
     p.verts = out_verts; p.picked = picked; p.R0 = R0; p.T0 = T0; p.pene = out_pene_count;
+    p.agent_of_slot = order; p.items = cull ? items : nullptr; p.item_counts = counts; p.items_stride = wl.items_stride;
     // markers and joints only: the vertex tiles without a picked vertex are never looked at
     // (with SDF counts: nor the tiles made of feet vertices only, which the count excludes)
     p.tiles = out_verts ? nullptr : (sdf ? m->sdf_tiles : m->pick_tiles);
     p.n_tiles = out_verts ? m->NVT : (sdf ? m->n_sdf_tiles : m->n_pick_tiles);
-    std::memset(&p.sdf, 0, sizeof(p.sdf));
-    if (sdf) {
-      p.sdf.grid = sdf->grid; p.sdf.d0 = sdf->d0; p.sdf.d1 = sdf->d1; p.sdf.d2 = sdf->d2;
-      p.sdf.cx = sdf->center[0]; p.sdf.cy = sdf->center[1]; p.sdf.cz = sdf->center[2]; p.sdf.scale = sdf->scale;
-      p.sdf.coarse = static_cast<const float2*>(sdf->coarse_minmax);
-      p.sdf.c0 = egx_ceil_div(sdf->d0, 4); p.sdf.c1 = egx_ceil_div(sdf->d1, 4); p.sdf.c2 = egx_ceil_div(sdf->d2, 4);
-      // out_pene_count was cleared by the pose kernel above
-    }
+    p.sdf = sd;   // out_pene_count was cleared by the pose kernel above
     // one persistent workgroup per CU; per-device launch facts (CU count, raised dynamic-LDS caps) are set up once per device
     constexpr size_t lds_meta = (size_t)8 * LBS_META_BYTES, lds_verts = (size_t)8 * (LBS_META_BYTES + LBS_VERT_BYTES),
                      lds_sdf = (size_t)8 * (LBS_META_BYTES + LBS_QCAP * 16);

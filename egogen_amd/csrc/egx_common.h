@@ -56,6 +56,21 @@ struct SdfDev {
   int c0, c1, c2;
 };
 
+// Free-space pyramid behind the bracket table (same buffer, after the float2 entries, 256-byte aligned): level l = 1..4 holds,
+// per block of 2^l x 2^l x 2^l PADDED bracket cells, the maximum of their `max` entries.  A box of padded cells whose pyramid
+// entries are all < 0 contains only points whose interpolated value is < 0 (convexity of the interpolation), i.e. free space
+// under the count's sign convention (a vertex counts when -trilinear < 0).  Used by the LBS work-item culling (body_model.hip).
+constexpr int EGX_SDF_MIP_LEVELS = 4;
+__host__ __device__ inline int egx_sdf_mip_dim(int c, int l) { return ((c + 2) + (1 << l) - 1) >> l; }
+__host__ __device__ inline size_t egx_sdf_mip_offset(int c0, int c1, int c2, int l) {   // in floats, from the start of the pyramid
+  size_t off = 0;
+  for (int k = 1; k < l; ++k) off += (size_t)egx_sdf_mip_dim(c0, k) * egx_sdf_mip_dim(c1, k) * egx_sdf_mip_dim(c2, k);
+  return off;
+}
+__host__ __device__ inline size_t egx_sdf_table_bytes(int c0, int c1, int c2) {       // bracket table, padded to 256 bytes
+  return ((size_t)(c0 + 2) * (c1 + 2) * (c2 + 2) * 8 + 255) / 256 * 256;
+}
+
 inline bool egx_sdf_dims_ok(int d0, int d1, int d2) {
   return d2 >= 2 && (unsigned long long)d0 * (unsigned long long)d1 * (unsigned long long)d2 < (1ull << 32);
 }

@@ -39,10 +39,24 @@ __global__ void egx_sdf_build_coarse_kernel(const float* __restrict__ grid, int 
   out[idx] = make_float2(mn, mx);
 }
 
+// free-space pyramid (egx_common.h): level l entry = max over its 2^l-cubed block of padded bracket cells of their `max`
+__global__ void egx_sdf_build_mip_kernel(const float2* __restrict__ table, int c0, int c1, int c2, int l, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e0 = egx_sdf_mip_dim(c0, l), e1 = egx_sdf_mip_dim(c1, l), e2 = egx_sdf_mip_dim(c2, l);
+  if (idx >= e0 * e1 * e2) return;
+  const int iz = idx % e2, iy = (idx / e2) % e1, ix = idx / (e1 * e2);
+  const int n = 1 << l;
+  float mx = -3.4e38f;
+  for (int x = ix * n; x < min((ix + 1) * n, c0 + 2); ++x)
+    for (int y = iy * n; y < min((iy + 1) * n, c1 + 2); ++y)
+      for (int z = iz * n; z < min((iz + 1) * n, c2 + 2); ++z) mx = fmaxf(mx, table[((size_t)x * (c1 + 2) + y) * (c2 + 2) + z].y);
+  out[idx] = mx;
+}
+
 extern "C" size_t egx_sdf_coarse_bytes(int d0, int d1, int d2) {
   if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
-  const size_t c0 = egx_ceil_div(d0, 4), c1 = egx_ceil_div(d1, 4), c2 = egx_ceil_div(d2, 4);
-  return (c0 + 2) * (c1 + 2) * (c2 + 2) * sizeof(float2);
+  const int c0 = egx_ceil_div(d0, 4), c1 = egx_ceil_div(d1, 4), c2 = egx_ceil_div(d2, 4);
+  return egx_sdf_table_bytes(c0, c1, c2) + egx_sdf_mip_offset(c0, c1, c2, EGX_SDF_MIP_LEVELS + 1) * sizeof(float);
 }
 
 extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream_) {
@@ -51,6 +65,12 @@ extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, v
   const int n = (c0 + 2) * (c1 + 2) * (c2 + 2);
   hipLaunchKernelGGL(egx_sdf_build_coarse_kernel, dim3(egx_ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      sdf->grid, sdf->d0, sdf->d1, sdf->d2, c0, c1, c2, static_cast<float2*>(coarse_out));
+  float* mips = reinterpret_cast<float*>(static_cast<char*>(coarse_out) + egx_sdf_table_bytes(c0, c1, c2));
+  for (int l = 1; l <= EGX_SDF_MIP_LEVELS; ++l) {
+    const int ne = egx_sdf_mip_dim(c0, l) * egx_sdf_mip_dim(c1, l) * egx_sdf_mip_dim(c2, l);
+    hipLaunchKernelGGL(egx_sdf_build_mip_kernel, dim3(egx_ceil_div(ne, 128)), dim3(128), 0, static_cast<hipStream_t>(stream_),
+                       static_cast<const float2*>(coarse_out), c0, c1, c2, l, mips + egx_sdf_mip_offset(c0, c1, c2, l));
+  }
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

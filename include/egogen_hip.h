@@ -83,14 +83,26 @@ typedef struct egx_sdf_grid {
   const void* coarse_minmax; /* device table from egx_sdf_build_coarse: required by egx_lbs_forward, optional (NULL = fine grid only) elsewhere */
 } egx_sdf_grid;
 
-/* Acceleration table for the penetration COUNT of egx_lbs_forward: {min,max} of the fine samples each 4x4x4 block's
- * interpolation footprint can touch.  Trilinear interpolation is a convex combination, so a block whose bracket does not
+/* Acceleration tables for the penetration COUNT of egx_lbs_forward: {min,max} of the fine samples each 4x4x4 block's
+ * interpolation footprint can touch, followed (same buffer) by a four-level pyramid of the block maxima (free-space tests of
+ * whole boxes: the work-item culling).  Trilinear interpolation is a convex combination, so a block whose bracket does not
  * contain 0 decides `calc_sdf < 0` exactly without gathering from the 64 MiB grid.  Six face tables follow the block table:
  * a point that border clamping (grid_sample padding_mode="border", utils.py:75-81) puts onto the first / last sample plane
  * of an axis only touches samples of that plane, so it is bracketed over the plane alone - bodies outside the cube are
  * decided without gathers as well. */
 size_t egx_sdf_coarse_bytes(int d0, int d1, int d2);
 int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream);
+
+/* Free-space culling of the work items of an SDF-counting egx_lbs_forward call (split blend modes, no vertex output): a
+ * (vertex tile x 256 bodies) item all of whose bodies are provably clear of geometry for that tile - bounding box of the balls
+ * around the posed joints the tile's vertices are bound to, tested against a max-pyramid of the bracket table - is skipped
+ * unless the tile holds picked vertices.  Counts, joints and markers are bit-identical with and without it.  On by default
+ * (EGX_LBS_CULL=0 in the environment or egx_lbs_set_culling(0) walks every item); egx_lbs_cull_stats reads, with a host
+ * synchronisation, how many items the LAST culled call on this workspace evaluated and how many an unculled call has. */
+int egx_lbs_set_culling(int on);
+int egx_lbs_get_culling(void);
+int egx_lbs_cull_stats(const egx_body_model* m, const void* workspace, int num_bodies, int32_t* out_active_items,
+                       int32_t* out_total_items);
 
 /* Bytes of scratch egx_lbs_forward needs for `num_bodies` bodies. */
 /* Blend-GEMM arithmetic of egx_lbs_forward calls that do not write full vertices (process-wide switch; the environment

@@ -400,3 +400,123 @@ def test_lbs_tile_lists_skip_only_what_contributes_nothing(blend_mode):
     near = (s.abs() < 2e-5).sum(-1).cpu()
     assert ((with_sdf["pene_count"].cpu().long() - ref).abs() <= near).all()
     assert int(with_sdf["pene_count"].max()) > 20
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Free-space culling of SDF work items (csrc/body_model.hip: egx_lbs_cull_kernel): results must be BIT-identical to the launch
+# that walks every item.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _culling(on):
+    from egogen_amd import _lib
+    _lib.check(_lib.load().egx_lbs_set_culling(1 if on else 0), "egx_lbs_set_culling")
+
+
+def _random_rotations(n, g, yaw_only=False):
+    if yaw_only:
+        yaw = torch.rand(n, generator=g) * 6.28
+        R = torch.zeros(n, 3, 3)
+        R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = yaw.cos(), -yaw.sin(), yaw.sin(), yaw.cos(), 1.0
+        return R
+    q = torch.randn(n, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(n, 3, 3)
+
+
+@pytest.mark.parametrize("V,A,T", [(2048, 12, 20), (2048, 60, 20), (10475, 26, 20)])
+@pytest.mark.parametrize("layout", ["in_room", "around_obstacle", "walls_and_outside", "tumbling"])
+def test_lbs_culling_is_exact(V, A, T, layout):
+    """Culled vs unculled launch on the same inputs: penetration counts, joints and markers equal to the last bit, for bodies
+    standing in the room (upper-body tiles provably free: items ARE skipped), bodies placed around / inside the obstacle, bodies
+    at the walls, the grid border and far outside (border clamping), and bodies tumbling with arbitrary 3-D frames, extreme
+    shapes (betas up to +-4) and large joint rotations (the bound's shape / pose terms)."""
+    from egogen_amd.body_model import SdfScene
+    bm, mk, feet, h, ob = _setup(V)
+    g = torch.Generator().manual_seed(V + A)
+    xb, betas = _poses(A, T, seed=V + 3 * A)
+    scene = synth.make_sdf_scene(64)
+    sdf = SdfScene(scene)
+    R0 = _random_rotations(A, g, yaw_only=True)
+    if layout == "in_room":
+        xb[:, 0:2] *= 0.1
+        xb[:, 3:6] *= 0.2                                      # roughly upright, pelvis ~0.95 m above the floor
+        T0 = torch.cat([torch.rand(A, 2, generator=g) * 5 - 2.5, torch.zeros(A, 1)], -1)
+        T0[T0[:, 0] > 0.3, 0] -= 3.0                           # away from the obstacle
+    elif layout == "around_obstacle":
+        xb[:, 0:2] *= 0.1
+        T0 = torch.cat([1.5 + (torch.rand(A, 1, generator=g) - 0.5) * 2.4, (torch.rand(A, 1, generator=g) - 0.5) * 2.4,
+                        torch.rand(A, 1, generator=g) * 0.4], -1)
+    elif layout == "walls_and_outside":
+        T0 = (torch.rand(A, 3, generator=g) - 0.5) * torch.tensor([9.0, 9.0, 8.0]) + torch.tensor([0.0, 0.0, 1.0])
+        T0[::5] *= 3.0                                          # some far outside the grid
+    else:
+        R0 = _random_rotations(A, g)
+        betas = betas * 4.0 / betas.abs().max()
+        xb[:, 6:69] *= 4.0
+        xb[:, 69:] *= 3.0
+        T0 = (torch.rand(A, 3, generator=g) - 0.5) * torch.tensor([6.0, 6.0, 3.0]) + torch.tensor([0.0, 0.0, 1.5])
+    args = (xb.cuda(), betas.cuda(), T)
+    kw = dict(sdf=sdf, R0=R0.cuda(), T0=T0.cuda())
+    try:
+        _culling(False)
+        ref = {k: v.clone() for k, v in h.forward(*args, **kw).items()}
+        _culling(True)
+        out = h.forward(*args, **kw)
+        act, tot = h.cull_stats(A * T)
+    finally:
+        _culling(True)
+    assert torch.equal(out["pene_count"], ref["pene_count"]), (out["pene_count"].long() - ref["pene_count"].long()).abs().max()
+    assert torch.equal(out["joints"], ref["joints"]) and torch.equal(out["markers"], ref["markers"])
+    assert 0 < act <= tot
+    if layout == "in_room":
+        assert act < 0.7 * tot, (act, tot)                     # standing bodies: the tiles above the knees are skipped
+    if layout == "around_obstacle":
+        assert int(ref["pene_count"].max()) > 100              # the exact path is exercised
+    print(f"culling {layout} V={V} A={A}: {act} of {tot} items evaluated, max count {int(ref['pene_count'].max())}")
+
+
+def test_lbs_culling_thin_wall_between_joints():
+    """A one-voxel-thick plate through the middle of standing bodies (between pelvis and chest, between the legs): the hull of
+    the balls around two joints spans the plate although neither ball touches it - the box test must keep those items."""
+    from egogen_amd.body_model import SdfScene
+    from oracle.sdf import calc_sdf
+    from oracle.smplx_lbs import smplx_forward
+    V, A, T = 2048, 13, 20
+    bm, mk, feet, h, ob = _setup(V)
+    xb, betas = _poses(A, T, seed=77)
+    xb[:, 0:2] *= 0.05
+    xb[:, 3:6] *= 0.1
+    res = 64
+    grid = np.full((res, res, res), -0.5, np.float32)           # free space everywhere ...
+    zi = int((1.15 - (1.0 - 4.0)) / 8.0 * res)                  # ... except the sample layer nearest to z = 1.15 m (chest height)
+    grid[:, :, zi] = 0.3
+    xi = int((0.0 + 4.0) / 8.0 * res)
+    grid[xi, :, :] = np.maximum(grid[xi, :, :], 0.2)            # and a vertical plate at x ~ 0 (between the legs of some bodies)
+    scene = {"sdf": grid, "center": np.array([0, 0, 1.0], np.float32), "scale": np.float32(0.25)}
+    sdf = SdfScene(scene)
+    g = torch.Generator().manual_seed(5)
+    R0 = _random_rotations(A, g, yaw_only=True)
+    T0 = torch.cat([(torch.rand(A, 1, generator=g) - 0.5) * 1.0, (torch.rand(A, 1, generator=g) - 0.5) * 4, torch.zeros(A, 1)], -1)
+    args = (xb.cuda(), betas.cuda(), T)
+    kw = dict(sdf=sdf, R0=R0.cuda(), T0=T0.cuda())
+    try:
+        _culling(False)
+        ref = {k: v.clone() for k, v in h.forward(*args, **kw).items()}
+        _culling(True)
+        out = h.forward(*args, **kw)
+        act, tot = h.cull_stats(A * T)
+    finally:
+        _culling(True)
+    assert torch.equal(out["pene_count"], ref["pene_count"])
+    assert int(ref["pene_count"].min()) > 0, "every body crosses the horizontal plate"
+    # and both equal the oracle's count
+    v, _ = smplx_forward(ob, xb, betas.repeat_interleave(T, 0))
+    vw = torch.einsum("bij,btpj->btpi", R0, v.reshape(A, T, V, 3)) + T0[:, None, None, :]
+    sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
+    s = calc_sdf(vw.reshape(A * T, V, 3), sd)
+    s[:, torch.as_tensor(feet).long()] = 1.0
+    near = (s.abs() < 2e-5).sum(-1)
+    assert ((out["pene_count"].cpu().long() - s.lt(0).sum(-1)).abs() <= near).all()
+    print(f"thin walls: {act} of {tot} items evaluated")
