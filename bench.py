@@ -70,6 +70,10 @@ def get_args():
     p.add_argument("--also-weak", type=int, default=1, help="N > 1 with --scaling strong: time the weak-scaling shape as well")
     p.add_argument("--num-verts", type=int, default=10475)
     p.add_argument("--skin-weights", type=int, default=4, help="non-zero skinning weights per vertex of the synthetic body (4..16)")
+    p.add_argument("--body", type=str, default="iid", choices=["iid", "structured"],
+                   help="synthetic body: iid = SURVEY 8(d)'s (i.i.d. noise blend shapes; the headline), structured = blend shapes with "
+                        "the structure of a learned model (smooth shape fields, local pose correctives): SDF work items can be culled")
+    p.add_argument("--lbs-cull", type=int, default=1, help="free-space culling of SDF work items (models that allow it)")
     p.add_argument("--lbs-blend", type=str, default="", choices=["", "f32", "bf16x3", "bf16x2"],
                    help="arithmetic of the LBS blend GEMM (default: the library's default, two bf16 planes)")
     p.add_argument("--update-prec", type=str, default="bf16x2", choices=["f32", "bf16x2", "bf16"],
@@ -515,8 +519,9 @@ def main():
         A, bs_local = args.agents // world, args.batch_size // world
     else:
         A, bs_local = args.agents, args.batch_size
-    if args.skin_weights != 4:
-        bm = synth.make_body_model(0, num_verts=args.num_verts, nnz_weights=args.skin_weights)
+    _lib.check(lib.egx_lbs_set_culling(int(args.lbs_cull)), "egx_lbs_set_culling")
+    if args.skin_weights != 4 or args.body == "structured":
+        bm = synth.make_body_model(0, num_verts=args.num_verts, nnz_weights=args.skin_weights, structured=args.body == "structured")
     else:
         bm, _ = sw.load_body_model("male", seed=0, num_verts=args.num_verts)
     body = BodyModelHandle(bm, synth.marker_ids(args.num_verts), synth.feet_vids(args.num_verts))
@@ -564,8 +569,18 @@ def main():
         executed = npr * 2.0 * 480 * (328 * 32 * 3) * bodies / (lbs_ms * 1e-3) / 1e12 if args.num_verts == 10475 else None
     else:
         kernel_name, peak, peak_note, executed = "egx_lbs_fused_kernel", PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA peak", None
+    def _cull_stats():
+        if not (bm_handle.culls and args.lbs_cull and m["env"].sdf is not None and blend in (1, 2)):
+            return None
+        act, tot = bm_handle.cull_stats(bodies)
+        return {"items_evaluated": act, "items_total": tot, "fraction_evaluated": act / max(1, tot)}
+    cull_loop = _cull_stats()          # the last launch of the timed loop
     in_scene = _lbs_in_scene_ms(m["env"], lib)
+    if in_scene is not None:
+        in_scene["culling"] = _cull_stats()
     penetrating = _lbs_penetrating_ms(m["env"], lib) if args.scene == "single_box" else None
+    if penetrating is not None:
+        penetrating["culling"] = _cull_stats()
     if penetrating is not None:
         penetrating["achieved"] = FLOP_PER_BODY * bodies / (penetrating["avg_launch_ms"] * 1e-3) / 1e12
         penetrating["frac"] = penetrating["achieved"] / peak
@@ -624,6 +639,8 @@ def main():
                      "flop_per_body": FLOP_PER_BODY, "vertices_evaluated": verts_eval, "vertices_total": bm_handle.V,
                      "peak_note": peak_note, "executed_bf16_tflops": executed,
                      "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene, "in_scene_penetrating": penetrating,
+                     "culling": {"model_allows": bool(bm_handle.culls), "reference_margin_m": bm_handle.cull_reference_margin,
+                                 "enabled": bool(args.lbs_cull), "last_launch_of_loop": cull_loop},
                      "other_blend_mode": other_mode,
                      "sustained_matrix_rate_note": "72 back-to-back v_mfma_f32_32x32x16_bf16 take 46, not 32, cycles each on this part "
                                                    "(clock-limited: 1720 of 2500 TFLOP/s in a load-free micro-benchmark, profiles/r01_ubench.md "
@@ -655,7 +672,10 @@ def main():
                              ("headline workload with the policy's dense layers (rollout + update) on bf16 operands: north_star's 'bf16 MFMA' "
                               "(gradients ~1-4 % from float64, profiles/r04_p3_yardstick.txt)", ["--update-prec", "bf16", "--policy-prec", "bf16"]),
                              ("headline workload on a synthetic body with 12 skinning weights per vertex (real SMPL-X has 4..~12)",
-                              ["--skin-weights", "12"])):
+                              ["--skin-weights", "12"]),
+                             ("headline workload on the STRUCTURED synthetic body (smooth shape fields, local pose correctives - the statistics "
+                              "of a learned model): SDF work items in provably free space are culled, results bit-identical", ["--body", "structured"]),
+                             ("the same structured body with the culling switched off", ["--body", "structured", "--lbs-cull", "0"])):
             cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--extra-configs", "0", "--steps", str(args.steps),
                    "--warmup", str(args.warmup), "--num-verts", str(args.num_verts), "--sdf-res", str(args.sdf_res),
                    "--vec-steps", str(args.vec_steps), "--batch-size", str(args.batch_size)] + flags
@@ -666,7 +686,8 @@ def main():
                 others.append({"workload": label, "value": r2["value"], "unit": r2["unit"], "ms_per_step": r2["ms_per_step"],
                                "regions": r2.get("regions"), "lbs_avg_launch_ms": r2["roofline"]["avg_launch_ms"],
                                "lbs_frac": r2["roofline"]["frac"], "lbs_peak": r2["roofline"]["peak"], "steps": r2["steps"],
-                               "precision": r2.get("precision"), "command": " ".join(cmd[1:])})
+                               "precision": r2.get("precision"), "lbs_culling": r2["roofline"].get("culling"),
+                               "lbs_in_scene": r2["roofline"].get("in_scene"), "command": " ".join(cmd[1:])})
                 if "--scene" in flags and "box" in flags:   # BASELINE configs[2] verbatim: a first-class record, not a footnote
                     result["configs2"] = {k: r2[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "regions",
                                                              "dtype", "data", "config", "precision") if k in r2}

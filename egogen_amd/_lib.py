@@ -129,6 +129,7 @@ SIGNATURES = {
     "egx_body_model_nnz": (C.c_int, [C.c_void_p]),
     "egx_body_model_lbs_vertices": (C.c_int, [C.c_void_p, C.c_int]),
     "egx_lbs_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "egx_body_model_culls": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "egx_lbs_set_culling": (C.c_int, [C.c_int]),
     "egx_lbs_get_culling": (C.c_int, []),
     "egx_lbs_cull_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

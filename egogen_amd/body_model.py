@@ -93,6 +93,10 @@ class BodyModelHandle:
         self.nnz = lib.egx_body_model_nnz(h)
         # vertices a call without vertex output evaluates (tiles without picks / counted vertices are skipped)
         self.lbs_vertices = {"picks": lib.egx_body_model_lbs_vertices(h, 0), "sdf": lib.egx_body_model_lbs_vertices(h, 1)}
+        mg = C.c_float()
+        # SDF launches skip work items that are provably in free space when the model's blend shapes allow a tight bound
+        self.culls = bool(lib.egx_body_model_culls(h, C.byref(mg)))
+        self.cull_reference_margin = float(mg.value)
         self._ws: Dict[tuple, torch.Tensor] = {}
         del self._keep  # device copies are owned by the handle now
 

@@ -11,6 +11,7 @@
 //             step producing the gate gradients directly as packed images.
 // ~27 launches per minibatch instead of ~85.  Gradients are WRITTEN (not accumulated) into the flat gradient buffer - every
 // parameter is used exactly once per minibatch - so the buffer needs no zero fill.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include "egx_nets.h"
@@ -44,7 +45,7 @@ struct PackEntry {
   int frag_end;              // running fragment count (this entry owns [previous frag_end, frag_end))
 };
 
-__global__ __launch_bounds__(256) void egx_pack3_table_kernel(const PackEntry* __restrict__ tab, int n) {
+__global__ __launch_bounds__(256) void egx_pack3_table_kernel(const PackEntry* __restrict__ tab, int n, int nplanes) {
   int frag = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   int i = 0, base = 0;
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(256) void egx_pack3_table_kernel(const PackEntry* _
   u3_split(x, pl);
   bf16x8* o = e.dst + ((size_t)rt * e.S_total + e.s0 + s) * 3 * 64 + lane;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+  for (int p = 0; p < 3; ++p)
+    if (p < nplanes) o[p * 64] = pl[p];   // planes no consumer reads are not written (a third of the image bytes per plane)
 }
 
 inline int img_tiles(int rows) { return 2 * egx_ceil_div(rows, 32); }   // 16-row tiles, even count
@@ -244,9 +246,10 @@ int upload_table(std::vector<PackEntry>& v, PackEntry** dev, int* frags) {
   EGX_HIP_CHECK(hipMemcpy(*dev, v.data(), v.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
   return EGX_OK;
 }
-void run_table(hipStream_t st, const PackEntry* tab, int n, int frags) {
-  hipLaunchKernelGGL(egx_pack3_table_kernel, dim3(egx_ceil_div(frags, 4)), dim3(256), 0, st, tab, n);
+void run_table(hipStream_t st, const PackEntry* tab, int n, int frags, int nplanes = 3) {
+  hipLaunchKernelGGL(egx_pack3_table_kernel, dim3(egx_ceil_div(frags, 4)), dim3(256), 0, st, tab, n, nplanes);
 }
+inline int planes_of(int prec) { return prec == 0 ? 3 : (prec == 2 ? 2 : 1); }
 
 // carve every buffer of a handle; with ar.base == nullptr this only measures
 void layout(egx_policy_train* h) {
@@ -394,7 +397,10 @@ extern "C" void egx_policy_train_destroy(egx_policy_train* h) {
 
 extern "C" int egx_policy_train_refresh(egx_policy_train* h, void* stream) {
   EGX_REQUIRE(h, "null handle");
-  run_table(static_cast<hipStream_t>(stream), h->tab_weights, h->n_weights, h->frags_weights);
+  // the weight images are read by this chain (h->prec) and by the rollout forward (egx_policy_get_precision): only the planes
+  // one of them uses are written
+  const int planes = std::max(planes_of(h->prec), planes_of(egx_policy_get_precision()));
+  run_table(static_cast<hipStream_t>(stream), h->tab_weights, h->n_weights, h->frags_weights, planes);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
@@ -447,7 +453,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
   };
 
   // ================= forward =================
-  run_table(st, h->tab_inputs, h->n_inputs, h->frags_inputs);
+  run_table(st, h->tab_inputs, h->n_inputs, h->frags_inputs, planes_of(h->prec));
   egx_launch_posenc3(st, dist, time, n, h->catf + 2 * HD, CAT, h->cat_r, S_CAT, 2 * S_HD, h->catT, Sn, 2 * HD);
   {
     D3Gru g[2];
@@ -510,7 +516,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
   int rc = egx_ppo_loss_packed(h->br[0].head, h->br[1].head, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_logvar, max_logvar,
                                eps_clip, vf_coef, ent_coef, n, h->br[0].ghead, h->br[1].ghead, out_terms, st);
   if (rc) return rc;
-  run_table(st, h->tab_loss, h->n_loss, h->frags_loss);
+  run_table(st, h->tab_loss, h->n_loss, h->frags_loss, planes_of(h->prec));
   // ================= backward =================
   // Input-gradient products form the dependent chain (out_fc -> unit 2 -> unit 1 -> GRU cells); each layer's weight-gradient
   // product follows the launch that left its gradient image behind.  (Weight gradients on a second stream beside the chain,

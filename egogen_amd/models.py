@@ -631,6 +631,12 @@ class PolicyHipRunner:
             out["value"] = torch.empty(n, dtype=torch.float32, device=st.device)
         ws = self._ws.get(lib.egx_policy_workspace_bytes(n), st.device)
         w = self._weights()
+        # adopted weight images carry only the planes their consumers read at the time they were made
+        # (egx_policy_train_refresh): a switch of the rollout arithmetic re-makes them
+        prec = int(lib.egx_policy_get_precision())
+        if prec != getattr(self, "_last_prec", prec) and self._p3 is None and getattr(self, "_adopted_refresh", None) is not None:
+            self._adopted_refresh()
+        self._last_prec = prec
         self._refresh_packed()
         rc = lib.egx_policy_forward(C.byref(w), _lib.ptr(st), _lib.ptr(ego), _lib.ptr(dist), _lib.ptr(time), n,
                                     _lib.ptr(out["mu"]) if want_actor else None,

@@ -99,6 +99,10 @@ int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream
  * unless the tile holds picked vertices.  Counts, joints and markers are bit-identical with and without it.  On by default
  * (EGX_LBS_CULL=0 in the environment or egx_lbs_set_culling(0) walks every item); egx_lbs_cull_stats reads, with a host
  * synchronisation, how many items the LAST culled call on this workspace evaluated and how many an unculled call has. */
+/* 1 if SDF launches of this model are culled (convex skinning weights AND a tight bound: the blend-shape margin of the median
+ * vertex tile at a reference pose is below 15 cm - learned body models; the i.i.d.-noise benchmark body is not), else 0.
+ * *out_reference_margin_m (may be NULL) receives that margin in metres. */
+int egx_body_model_culls(const egx_body_model* m, float* out_reference_margin_m);
 int egx_lbs_set_culling(int on);
 int egx_lbs_get_culling(void);
 int egx_lbs_cull_stats(const egx_body_model* m, const void* workspace, int num_bodies, int32_t* out_active_items,

@@ -432,8 +432,11 @@ def test_lbs_culling_is_exact(V, A, T, layout):
     standing in the room (upper-body tiles provably free: items ARE skipped), bodies placed around / inside the obstacle, bodies
     at the walls, the grid border and far outside (border clamping), and bodies tumbling with arbitrary 3-D frames, extreme
     shapes (betas up to +-4) and large joint rotations (the bound's shape / pose terms)."""
-    from egogen_amd.body_model import SdfScene
-    bm, mk, feet, h, ob = _setup(V)
+    from egogen_amd.body_model import BodyModelHandle, SdfScene
+    bm = synth.make_body_model(0, num_verts=V, structured=True)   # blend shapes with the structure of a learned model: the bound is tight
+    mk, feet = synth.marker_ids(V), synth.feet_vids(V)
+    h = BodyModelHandle(bm, mk, feet)
+    assert h.culls and h.cull_reference_margin < 0.15, h.cull_reference_margin
     g = torch.Generator().manual_seed(V + A)
     xb, betas = _poses(A, T, seed=V + 3 * A)
     scene = synth.make_sdf_scene(64)
@@ -483,8 +486,13 @@ def test_lbs_culling_thin_wall_between_joints():
     from egogen_amd.body_model import SdfScene
     from oracle.sdf import calc_sdf
     from oracle.smplx_lbs import smplx_forward
+    from egogen_amd.body_model import BodyModelHandle
+    from oracle.smplx_lbs import BodyModel
     V, A, T = 2048, 13, 20
-    bm, mk, feet, h, ob = _setup(V)
+    bm = synth.make_body_model(0, num_verts=V, structured=True)
+    mk, feet = synth.marker_ids(V), synth.feet_vids(V)
+    h, ob = BodyModelHandle(bm, mk, feet), BodyModel(bm)
+    assert h.culls
     xb, betas = _poses(A, T, seed=77)
     xb[:, 0:2] *= 0.05
     xb[:, 3:6] *= 0.1
@@ -520,3 +528,17 @@ def test_lbs_culling_thin_wall_between_joints():
     near = (s.abs() < 2e-5).sum(-1)
     assert ((out["pene_count"].cpu().long() - s.lt(0).sum(-1)).abs() <= near).all()
     print(f"thin walls: {act} of {tot} items evaluated")
+
+
+def test_lbs_culling_is_off_for_the_iid_noise_benchmark_body():
+    """The benchmark body of SURVEY 8(d) has i.i.d. noise in every blend-shape entry: the a-priori bound on a vertex's offset
+    from its joints is ~0.56 m, nothing is ever provably free, so SDF launches of that model skip the culling kernels
+    (`egx_body_model_culls` = 0) - and say so when asked for statistics."""
+    from egogen_amd import _lib
+    from egogen_amd.body_model import SdfScene
+    bm, mk, feet, h, ob = _setup(2048)
+    assert not h.culls and h.cull_reference_margin > 0.3, h.cull_reference_margin
+    xb, betas = _poses(12, 20, seed=1)
+    h.forward(xb.cuda(), betas.cuda(), 20, sdf=SdfScene(synth.make_sdf_scene(32)), R0=torch.eye(3).repeat(12, 1, 1).cuda(), T0=torch.zeros(12, 3).cuda())
+    with pytest.raises(_lib.EgxError):
+        h.cull_stats(240)
