@@ -543,7 +543,7 @@ def main():
     # applies only to the configuration that pass was taken on
     traffic = None
     try:
-        for name in (f"r03_lbs_pmc_mode{blend}.json", f"r02_lbs_pmc_mode{blend}.json"):   # newest round first
+        for name in (f"r04_lbs_pmc_mode{blend}.json", f"r03_lbs_pmc_mode{blend}.json", f"r02_lbs_pmc_mode{blend}.json"):   # newest round first
             f = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(f):
                 continue

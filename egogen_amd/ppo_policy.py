@@ -107,6 +107,9 @@ class GAMMAPPOPolicy(nn.Module):
         self.use_flat_optimizer = bool(_ignored.get("use_flat_optimizer", os.environ.get("EGX_FLAT_OPTIMIZER", "1") != "0"))
         self._flat_opt_state = None
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # the data-parallel code path (global advantage moments, graph 1 | all-reduce | graph 2): taken with more than one
+        # rank - and, for testing the RCCL calls between graph replays on a one-GPU box, with ONE rank when asked for
+        self._dp = self.world_size > 1 or (os.environ.get("EGX_FORCE_DP_PATH") == "1" and dist.is_available() and dist.is_initialized())
         self.update_paths: dict = {}       # minibatches of learn() by formulation: "chain", "chain+graph", "autograd", "autograd+graph"
         self.allreduce_events: list = []   # [(start, stop)] torch.cuda.Event pairs, one consumed per gradient all-reduce
         self._allreduce_done: list = []
@@ -512,7 +515,7 @@ class GAMMAPPOPolicy(nn.Module):
             return g
         dev = batch.act.device
         st = {"idx": torch.zeros(local_bs, dtype=torch.long, device=dev), "log": torch.zeros(6, device=dev),
-              "gstats": torch.tensor([0.0, 1.0, float(local_bs * self.world_size)], device=dev), "use_gstats": self.world_size > 1}
+              "gstats": torch.tensor([0.0, 1.0, float(local_bs * self.world_size)], device=dev), "use_gstats": self._dp}
         gs = (lambda: (st["gstats"][0], st["gstats"][1], st["gstats"][2])) if st["use_gstats"] else (lambda: None)
         try:
             # warm-up on a side stream (lazy library init, allocator pools) - it performs real optimiser steps on a
@@ -530,7 +533,7 @@ class GAMMAPPOPolicy(nn.Module):
             torch.cuda.synchronize()
             g1 = torch.cuda.CUDAGraph()
             g2 = None
-            if self.world_size == 1:
+            if not self._dp:
                 with torch.cuda.graph(g1):
                     st["path"] = self._fwd_bwd(batch, st["idx"], gs(), st["log"])
                     self._clip_and_step()
@@ -607,6 +610,7 @@ class GAMMAPPOPolicy(nn.Module):
             self._flat_optimizer_ready()  # (re-)points parameters / optimiser state BEFORE anything is captured
         self._refresh_images()            # whatever changed the parameters since the last update (load_state_dict, ...)
         ws = self.world_size
+        dp = self._dp
         N = batch.n * batch.A
         dev = batch.act.device
         local_bs = max(1, batch_size // ws)
@@ -622,27 +626,27 @@ class GAMMAPPOPolicy(nn.Module):
                 bounds.pop()
             last_log = None
             spans = [(s, bounds[i + 1] if i + 1 < len(bounds) else N) for i, s in enumerate(bounds)]
-            gstats_all = self._global_adv_stats(batch, perm, spans) if ws > 1 else None
+            gstats_all = self._global_adv_stats(batch, perm, spans) if dp else None
             for i, (s, e) in enumerate(spans):
                 idx = perm[s:e]
                 st = self._graphs_for(batch, local_bs) if (use_graph and e - s == local_bs) else None
                 if st is not None and st.get("g1") is not None:
                     st["idx"].copy_(idx)
-                    if ws > 1:
+                    if dp:
                         st["gstats"].copy_(gstats_all[i])
                     st["g1"].replay()
-                    if ws > 1:
+                    if dp:
                         self._all_reduce_grad()
                         st["g2"].replay()
                     last_log = st["log"].clone()
                     self.update_paths[st["path"] + "+graph"] = self.update_paths.get(st["path"] + "+graph", 0) + 1
                 else:
                     gstats = None
-                    if ws > 1:
+                    if dp:
                         gstats = (gstats_all[i, 0], gstats_all[i, 1], gstats_all[i, 2])
                     log = torch.zeros(6, device=dev)
                     path = self._fwd_bwd(batch, idx, gstats, log)
-                    if ws > 1:
+                    if dp:
                         self._all_reduce_grad()
                     self._clip_and_step()
                     last_log = log
@@ -651,14 +655,14 @@ class GAMMAPPOPolicy(nn.Module):
             # early stop on the last minibatch's approximate KL (ppo_policy.py:252-257); inert at repeat=1
             if repeat > 1 and last_log is not None:
                 kl = last_log[5].clone()
-                if ws > 1:
+                if dp:
                     dist.all_reduce(kl)
                 if float(kl.item()) >= 0.02:
                     break
         self._runner.mark_dirty()   # replayed graphs update the parameters by address: re-pack before the next rollout forward
         if logs:
             L = torch.stack(logs)
-            if ws > 1:
+            if dp:
                 dist.all_reduce(L)
             for row in L.cpu().tolist():
                 for k, v in zip(names, row):

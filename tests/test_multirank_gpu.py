@@ -184,6 +184,55 @@ def test_two_rank_chain_two_passes_equal_single_process(tmp_path):
     assert float((o["mu"].cpu() - dp[0]["mu"]).abs().max()) <= 2e-4 and float((o["value"].cpu() - dp[0]["value"]).abs().max()) <= 2e-4
 
 
+def _rccl_worker(rank, port, n_local, n_steps, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", EGX_FORCE_DP_PATH="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from egogen_amd.ppo_policy import RolloutBatch
+    pol = _make_policy(True)
+    assert pol.world_size == 1 and pol._dp
+    b = RolloutBatch(n_steps, n_local, "cuda")
+    _fill(b, 100, pol)
+    pol._perm_gen.manual_seed(7)
+    losses = []
+    for _ in range(2):
+        losses += pol.learn(b, n_local, 1)["loss"]
+    assert pol.update_paths == {"chain+graph": 2 * n_steps}, pol.update_paths
+    assert all(v.get("g1") is not None and v.get("g2") is not None for v in pol._graph_cache.values())
+    torch.save({"loss": losses, "sd": {k: v.cpu() for k, v in pol.state_dict().items()}}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_between_graph_replays_single_rank(tmp_path):
+    """The collectives of the data-parallel update are RCCL calls issued between two replayed HIP graphs on the same stream
+    (moments of the advantages once per pass, the flat 52.7 MB gradient once per minibatch).  Two ranks cannot share one GPU
+    under RCCL, so the multi-rank tests above run over gloo; THIS test runs the same code path over RCCL itself with a world of
+    one rank (EGX_FORCE_DP_PATH=1): communicator set-up, all-reduce on the compute stream next to captured graphs, tear-down.
+    Result = the plain single-process update (a one-rank all-reduce is the identity; the advantage statistics come from the
+    float64 moments instead of the fp32 kernel)."""
+    n_local, n_steps = 64, 3
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(29500 + (os.getpid() + 77) % 2000, n_local, n_steps, out), nprocs=1, join=True)
+    got = torch.load(out)
+    from egogen_amd.ppo_policy import RolloutBatch
+    pol = _make_policy(False)
+    b = RolloutBatch(n_steps, n_local, "cuda")
+    _fill(b, 100, pol)
+    pol._perm_gen.manual_seed(7)
+    ref = []
+    for _ in range(2):
+        ref += pol.learn(b, n_local, 1)["loss"]
+    np.testing.assert_allclose(got["loss"], ref, rtol=2e-4, atol=2e-5)
+    moved = 0
+    for k, v in pol.state_dict().items():
+        d = (v.cpu() - got["sd"][k]).abs()
+        assert float(d.max()) <= 2 * 3e-4 * 2 * n_steps, (k, float(d.max()))
+        moved += int((d > 2e-5).sum())
+    assert moved < 20000, moved
+
+
 def _bench(extra_env, *flags, timeout=900):
     env = dict(os.environ, PYTHONPATH=ROOT, **extra_env)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
