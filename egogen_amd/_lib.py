@@ -59,7 +59,6 @@ class PriorWeights(C.Structure):
                [("d_mlp_w", C.c_void_p * 2), ("d_mlp_b", C.c_void_p * 2), ("d_out_w", C.c_void_p), ("d_out_b", C.c_void_p),
                 ("reg_in_w", C.c_void_p), ("reg_in_b", C.c_void_p), ("reg_blk_w", C.c_void_p * 20), ("reg_blk_b", C.c_void_p * 20),
                 ("reg_out_w", C.c_void_p), ("reg_out_b", C.c_void_p), ("d_comb_w", C.c_void_p), ("d_comb_b", C.c_void_p),
-                ("reg_packed_in", C.c_void_p), ("reg_packed_blk", C.c_void_p), ("reg_packed_out", C.c_void_p),
                 ("packed3", C.POINTER(PriorPacked3))]
 
 
@@ -199,8 +198,6 @@ SIGNATURES = {
     "egx_gemm3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "egx_gemm3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                             C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "egx_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
-    "egx_stream_destroy": (C.c_int, [C.c_void_p]),
     "egx_vposer_workspace_bytes": (C.c_size_t, [C.c_int]),
     "egx_vposer_encode": (C.c_int, [C.POINTER(VposerWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),

@@ -49,17 +49,6 @@ extern "C" int egx_event_elapsed_ms(void* start_event, void* stop_event, float* 
 }
 // Streams restricted to part of the device, for running a throughput-bound launch (the fused LBS kernel) beside a chain of
 // latency-bound launches of another shard of agents: bit i of `mask` (num_words x 32 bits) enables compute unit i.
-extern "C" int egx_stream_create_cu_mask(const uint32_t* mask, int num_words, void** out_stream) {
-  EGX_REQUIRE(mask && num_words > 0 && out_stream, "bad arguments");
-  hipStream_t s;
-  EGX_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)num_words, mask));
-  *out_stream = s;
-  return EGX_OK;
-}
-extern "C" int egx_stream_destroy(void* stream) {
-  if (stream) EGX_HIP_CHECK(hipStreamDestroy(static_cast<hipStream_t>(stream)));
-  return EGX_OK;
-}
 extern "C" int egx_profile_next_lbs(void* start_event, void* stop_event) {
   g_prof_start = static_cast<hipEvent_t>(start_event);
   g_prof_stop = static_cast<hipEvent_t>(stop_event);
@@ -1507,7 +1496,6 @@ constexpr int kMaxDevices = 64;
 struct LbsDeviceInfo {
   std::mutex mu;
   int num_cu = 0;
-  std::map<hipStream_t, int> stream_cus;   // CUs a stream may use (CU-masked streams), looked up on first use
 };
 LbsDeviceInfo g_lbs_dev[kMaxDevices];
 // blend mode of the fused kernel: 0 = fp32 MFMA, 1 = 3-term bf16 split, 2 = 2-term bf16 split (default); vertex-writing
@@ -1743,23 +1731,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
         di.num_cu = prop.multiProcessorCount;
       }
     }
-    // a stream created with a CU mask (hipExtStreamCreateWithCUMask / egx_stream_create_cu_mask) runs on part of the device:
-    // the persistent grid is sized for the CUs that stream may use (looked up once per stream)
-    int num_cu = di.num_cu;
-    if (stream) {
-      std::lock_guard<std::mutex> lk(di.mu);
-      auto it = di.stream_cus.find(stream);
-      if (it == di.stream_cus.end()) {
-        uint32_t mask[16] = {0};
-        int n = 0;
-        if (hipExtStreamGetCUMask(stream, 16, mask) == hipSuccess)
-          for (uint32_t m32 : mask) n += __builtin_popcount(m32);
-        else
-          (void)hipGetLastError();
-        it = di.stream_cus.emplace(stream, (n > 0 && n < di.num_cu) ? n : di.num_cu).first;
-      }
-      num_cu = it->second;
-    }
+    const int num_cu = di.num_cu;
     p.bg_block = 2;
 #ifdef EGX_LBS_DEVELOPMENT
     if (const char* e = getenv("EGX_LBS_BG_BLOCK")) p.bg_block = atoi(e);

@@ -27,7 +27,6 @@ struct LinArgs {
   int M, N, K;
   int act;      // 0 none, 1 tanh, 2 relu, 3 leaky relu
   float slope;
-  int bf16;     // operands rounded to bf16 (RNE), fp32 accumulate
 };
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -165,29 +164,13 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
 #pragma unroll
       for (int u = 0; u < TRIP; ++u) {
         if (u >= nbt) break;
-        if (a.bf16) {
-          // k sub-blocks of 16: lane (i, h) holds 8 consecutive k of its row as bf16 (A and B alike) = two of its fp32 quads
+        #pragma unroll
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int sb = 0; sb < 2; ++sb) {
-            bf16x8 xa;
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { xa[e] = (short)egx_bf16_rne(gx[u][2 * sb][e]); xa[4 + e] = (short)egx_bf16_rne(gx[u][2 * sb + 1][e]); }
-#pragma unroll
-            for (int t = 0; t < NW; ++t) {
-              bf16x8 wb;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { wb[e] = (short)egx_bf16_rne(gw[u][t][2 * sb][e]); wb[4 + e] = (short)egx_bf16_rne(gw[u][t][2 * sb + 1][e]); }
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wb, acc[t], 0, 0, 0);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-              for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gx[u][q][e], gw[u][t][q][e], acc[t], 0, 0, 0);
-        }
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gx[u][q][e], gw[u][t][q][e], acc[t], 0, 0, 0);
+      
       }
     }
   } else {
@@ -220,29 +203,14 @@ __global__ __launch_bounds__(256) void egx_linear_kernel(LinArgs2 two) {
           *reinterpret_cast<f32x4*>(xs + (q * 8 + lr) * 36 + lc) = gx[u][q];
           *reinterpret_cast<f32x4*>(ws + (q * 8 + lr) * 36 + lc) = gw[u][q];
         }
-        if (a.bf16) {
-          // two 16-wide k sub-blocks: lane (i, h) holds k = 16 s + 8 h + 0..7 of row i as 8 bf16 (A and B alike)
+        #pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
+          const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
 #pragma unroll
-          for (int sb = 0; sb < 2; ++sb) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h), x1 = *reinterpret_cast<const f32x4*>(xs + i * 36 + sb * 16 + 8 * h + 4);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h), w1 = *reinterpret_cast<const f32x4*>(ws + i * 36 + sb * 16 + 8 * h + 4);
-            bf16x8 xa, wb;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              xa[e] = (short)egx_bf16_rne(x0[e]); xa[4 + e] = (short)egx_bf16_rne(x1[e]);
-              wb[e] = (short)egx_bf16_rne(w0[e]); wb[4 + e] = (short)egx_bf16_rne(w1[e]);
-            }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wb, acc[0], 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 36 + c * 8 + 4 * h);
-            const f32x4 wb = *reinterpret_cast<const f32x4*>(ws + i * 36 + c * 8 + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc[0], 0, 0, 0);
-          }
+          for (int e = 0; e < 4; ++e) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc[0], 0, 0, 0);
         }
+      
       }
       if (b + 2 < b1) fetch(b + 2, gx, gw);
     }
@@ -353,203 +321,6 @@ __global__ void egx_cont6d_to_aa_kernel(const float* __restrict__ xb6, int n, fl
   egx_cont6d_item(xb6 + (size_t)row * 159, out + (size_t)row * ldo, j);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Fused body regressor: MoshRegressor.forward (models_GAMMA_primitive.py:222-301) for a tile of 32 rows per
-// workgroup, all 3 recurrences x (in_fc + 10 residual blocks + out_fc) = 66 dense layers in ONE launch.
-// Activations live in LDS (input [mk|xb|betas] 32x376, h and t 32x132 each); the 398 k weights (1.6 MB) are
-// read straight from L2 in MFMA B-operand order; each wave owns one 32x32 output tile per 128-wide layer and
-// prefetches the next layer's weight fragments into registers while the current layer's MFMAs run.
-// ---------------------------------------------------------------------------------------------------------
-namespace {
-constexpr int RG_RT = 32, RG_LDX = 376, RG_LDH = 132, RG_KIN = 370, RG_NOUT = 159;
-typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
-
-__device__ __forceinline__ void rg_load_w128(const float* W, int col, int h, f32x4 (&wf)[16]) {
-  const float* p = W + (size_t)col * 128 + 4 * h;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) wf[c] = *reinterpret_cast<const f32x4a*>(p + c * 8);
-}
-// the same fragments from a copy packed in lane order ([32-column group][chunk][lane] float4): one contiguous 1 KiB per load
-__device__ __forceinline__ void rg_load_w128_packed(const f32x4* P, int group, int lane, f32x4 (&wf)[16]) {
-  const f32x4* p = P + (size_t)group * 16 * 64 + lane;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) wf[c] = p[c * 64];
-}
-__device__ __forceinline__ f32x16 rg_mma128(const float* xs, int i, int h, const f32x4 (&wf)[16]) {
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const float* xr = xs + i * RG_LDH + 4 * h;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const f32x4 xa = *reinterpret_cast<const f32x4*>(xr + c * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wf[c][e], acc, 0, 0, 0);
-  }
-  return acc;
-}
-}  // namespace
-
-template <bool PACKED>
-__global__ __launch_bounds__(256, 2) void egx_regressor_fused_kernel(RegWeights w, const float* __restrict__ Y,
-                                                                     const float* __restrict__ betas, int A, int M,
-                                                                     float* __restrict__ out_Yb) {
-  extern __shared__ __attribute__((aligned(16))) float rg_smem[];
-  float* xin = rg_smem;                       // [32][376]: markers 201 | xb 159 | betas 10 | zero pad 6
-  float* hb = xin + RG_RT * RG_LDX;           // [32][132]
-  float* tb = hb + RG_RT * RG_LDH;            // [32][132]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * RG_RT;
-  // ---- load the input tile
-  for (int idx = tid; idx < RG_RT * RG_LDX; idx += 256) {
-    const int r = idx / RG_LDX, c = idx % RG_LDX;
-    const int m = min(m0 + r, M - 1);
-    float v = 0.f;
-    if (c < 201) v = Y[(size_t)m * 201 + c];
-    else if (c >= 360 && c < 370) v = betas[(size_t)(m % A) * 10 + (c - 360)];
-    xin[idx] = v;
-  }
-  __syncthreads();
-  const int n0 = wave * 32;
-  f32x4 wcur[16], wnext[16];
-  for (int rc = 0; rc < 3; ++rc) {
-    // prefetch the first block layer's weights; they are independent of the activations
-    if (PACKED) rg_load_w128_packed(w.pk_blk, wave, lane, wcur);
-    else rg_load_w128(w.blk_w[0], n0 + i, h, wcur);
-    // ---- in_fc: [32,370] x [128,370]^T, streamed in groups of 4 chunks
-    {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* xr = xin + i * RG_LDX + 4 * h;
-      if (PACKED) {
-        // 47 chunks of 8 k (370 padded with zeros to 376): four chunks per round trip
-        const f32x4* pw = w.pk_in + (size_t)wave * 47 * 64 + lane;
-        constexpr int NCHP = 47;
-        for (int c = 0; c < NCHP; c += 4) {
-          f32x4 wf4[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) wf4[u] = pw[(size_t)min(c + u, NCHP - 1) * 64];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (c + u >= NCHP) break;
-            const f32x4 xa = *reinterpret_cast<const f32x4*>(xr + (c + u) * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wf4[u][e], acc, 0, 0, 0);
-          }
-        }
-      } else {
-      const float* wrow = w.in_w + (size_t)(n0 + i) * RG_KIN + 4 * h;
-      constexpr int NCH = 46;  // full 8-wide chunks; k = 368,369 handled below
-      f32x4 wf[2][2];
-      wf[0][0] = *reinterpret_cast<const f32x4a*>(wrow);
-      wf[0][1] = *reinterpret_cast<const f32x4a*>(wrow + 8);
-      for (int c = 0; c < NCH; c += 2) {
-        const int cn = (c + 2 < NCH) ? c + 2 : c;
-        wf[1][0] = *reinterpret_cast<const f32x4a*>(wrow + cn * 8);
-        wf[1][1] = *reinterpret_cast<const f32x4a*>(wrow + (cn + 1) * 8);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const f32x4 xa = *reinterpret_cast<const f32x4*>(xr + (c + u) * 8);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wf[0][u][e], acc, 0, 0, 0);
-        }
-        wf[0][0] = wf[1][0];
-        wf[0][1] = wf[1][1];
-      }
-      {  // tail: k = 368 + 4h + e, valid only for h == 0, e < 2
-        const f32x4 xa = *reinterpret_cast<const f32x4*>(xr + NCH * 8);
-        f32x4 wt = {0.f, 0.f, 0.f, 0.f};
-        if (h == 0) { wt[0] = wrow[NCH * 8]; wt[1] = wrow[NCH * 8 + 1]; }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wt[e], acc, 0, 0, 0);
-      }
-      }
-      const float b = w.in_b[n0 + i];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hb[((r & 3) + 8 * (r >> 2) + 4 * h) * RG_LDH + n0 + i] = acc[r] + b;
-    }
-    __syncthreads();
-    // ---- 10 residual blocks
-    for (int l = 0; l < 20; ++l) {
-      // next layer's weights (or out_fc tile `wave`) while this layer computes
-      // The next layer's weights are requested AFTER this layer's MFMAs: a wave that issues MFMAs with its own loads in
-      // flight runs the matrix pipe at half rate on gfx950 (scripts/ubench/mfma_loads.hip), which cost more than the
-      // latency the prefetch hid.  The loads now fly during the LDS epilogue and the barrier.
-      const float* Wn = (l + 1 < 20) ? w.blk_w[l + 1] : w.out_w;
-      const float* src = (l & 1) ? tb : hb;
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16 acc = rg_mma128(src, i, h, wcur);
-      __builtin_amdgcn_sched_barrier(0);
-      if (PACKED) rg_load_w128_packed((l + 1 < 20) ? w.pk_blk + (size_t)(l + 1) * 4 * 16 * 64 : w.pk_out, wave, lane, wnext);
-      else rg_load_w128(Wn, n0 + i, h, wnext);
-      const float b = w.blk_b[l][n0 + i];
-      if ((l & 1) == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * h) * RG_LDH + n0 + i] = fmaxf(acc[r] + b, 0.f);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* hp = hb + ((r & 3) + 8 * (r >> 2) + 4 * h) * RG_LDH + n0 + i;
-          *hp = fmaxf(acc[r] + b, 0.f) + *hp;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) wcur[c] = wnext[c];
-      __syncthreads();
-    }
-    // ---- out_fc: N = 159 -> tiles 0..4; wave w owns tile w (weights already in wcur), wave 0 also tile 4
-    for (int tI = wave; tI < 5; tI += 4) {
-      const int nn = tI * 32 + i;
-      if (tI >= 4) {
-        if (PACKED) rg_load_w128_packed(w.pk_out, tI, lane, wcur);
-        else rg_load_w128(w.out_w, min(nn, RG_NOUT - 1), h, wcur);
-      }
-      f32x16 acc = rg_mma128(hb, i, h, wcur);
-      if (nn < RG_NOUT) {
-        const float b = w.out_b[nn];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* xp = xin + ((r & 3) + 8 * (r >> 2) + 4 * h) * RG_LDX + 201 + nn;
-          *xp = *xp + (acc[r] + b);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // ---- 6D -> axis-angle tail straight from LDS
-  for (int idx = tid; idx < RG_RT * 23; idx += 256) {
-    const int r = idx / 23, j = idx % 23;
-    if (m0 + r < M) egx_cont6d_item(xin + r * RG_LDX + 201, out_Yb + (size_t)(m0 + r) * 93, j);
-  }
-}
-
-int egx_launch_regressor_fused(hipStream_t st, const RegWeights& w, const float* Y, const float* betas, int A, int M,
-                               float* out_Yb) {
-  const size_t lds = (size_t)(RG_RT * RG_LDX + 2 * RG_RT * RG_LDH) * sizeof(float);
-  {  // 80 KiB of dynamic LDS: above the 64 KiB default cap; raised once per DEVICE (the attribute is per device)
-    static std::mutex mu;
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    EGX_HIP_CHECK(hipGetDevice(&dev));
-    EGX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
-    std::lock_guard<std::mutex> lk(mu);
-    if (!attr_set[dev]) {
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor_fused_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set[dev] = true;
-    }
-  }
-  if (w.pk_in && w.pk_blk && w.pk_out)
-    hipLaunchKernelGGL(egx_regressor_fused_kernel<true>, dim3(egx_ceil_div(M, RG_RT)), dim3(256), lds, st, w, Y, betas, A, M, out_Yb);
-  else
-    hipLaunchKernelGGL(egx_regressor_fused_kernel<false>, dim3(egx_ceil_div(M, RG_RT)), dim3(256), lds, st, w, Y, betas, A, M, out_Yb);
-  return EGX_OK;
-}
-
 // positional_encoding (models_policy_ppo.py:276-285) of dist and time: out[b, 0:64] / out[b, 64:128]
 __global__ void egx_posenc_kernel(const float* __restrict__ dist, const float* __restrict__ time, int A,
                                   float* __restrict__ out) {
@@ -609,9 +380,8 @@ __global__ void egx_gae_kernel(const float* __restrict__ v, const float* __restr
 
 // ---- internal launchers ---------------------------------------------------------------------------
 static LinArgs make_lin_args(int M, int N, const EgxSeg* segs, int nseg, const float* W, int ldw, const float* b, int act,
-                             float slope, const float* res, int ldr, float* out, int ldo, int bf16 = 0) {
+                             float slope, const float* res, int ldr, float* out, int ldo) {
   LinArgs a;
-  a.bf16 = bf16;
   const float* ps[4] = {nullptr, nullptr, nullptr, nullptr};
   int ws[4] = {0, 0, 0, 0}, ls[4] = {0, 0, 0, 0};
   int K = 0;
@@ -660,33 +430,9 @@ int egx_launch_linear(hipStream_t st, int M, int N, const EgxSeg* segs, int nseg
   return EGX_OK;
 }
 
-int egx_launch_linear_one(hipStream_t st, const EgxLin& A) {
-  LinArgs2 two;
-  two.p0 = make_lin_args(A.M, A.N, A.segs, A.nseg, A.W, A.ldw, A.b, A.act, A.slope, A.res, A.ldr, A.out, A.ldo, A.bf16);
-  two.p1 = two.p0;
-  launch_linear2(st, two, false);
-  return EGX_OK;
-}
-
-// two independent GEMMs in one launch (e.g. the x-side and h-side products of a GRU cell)
-int egx_launch_linear_pair(hipStream_t st, const EgxLin& A, const EgxLin& B) {
-  LinArgs2 two;
-  two.p0 = make_lin_args(A.M, A.N, A.segs, A.nseg, A.W, A.ldw, A.b, A.act, A.slope, A.res, A.ldr, A.out, A.ldo, A.bf16);
-  two.p1 = make_lin_args(B.M, B.N, B.segs, B.nseg, B.W, B.ldw, B.b, B.act, B.slope, B.res, B.ldr, B.out, B.ldo, B.bf16);
-  launch_linear2(st, two, true);
-  return EGX_OK;
-}
-
 int egx_launch_gru_pointwise(hipStream_t st, const float* gi, const float* gh, const float* hprev, int ldh, float* hout,
                              int ldo, int M, int H) {
   hipLaunchKernelGGL(egx_gru_pointwise_kernel, dim3(egx_ceil_div(M * H, 256)), dim3(256), 0, st, gi, gh, nullptr, hprev, ldh,
-                     hout, ldo, M, H);
-  return EGX_OK;
-}
-
-// first step of a sequence: zero previous state, so gh is just the bias b_hh (no GEMM, no state tensor)
-int egx_launch_gru_pointwise_first(hipStream_t st, const float* gi, const float* b_hh, float* hout, int ldo, int M, int H) {
-  hipLaunchKernelGGL(egx_gru_pointwise_kernel, dim3(egx_ceil_div(M * H, 256)), dim3(256), 0, st, gi, nullptr, b_hh, nullptr, 0,
                      hout, ldo, M, H);
   return EGX_OK;
 }

@@ -31,19 +31,16 @@ constexpr int S_MK = 7, S_H = 8, S_HZ = 12, S_512 = 16;   // k-steps of 201 / 25
 
 extern "C" size_t egx_sample_prior_workspace_bytes(int A) {
   if (A <= 0) return 0;
-  const size_t a = A, m = (size_t)A * T_PRED;
-  const size_t fp32_path = carve_bytes({a * H, a * H, a * H, a * 3 * H, a * 3 * H, a * 3 * H, a * 512, a * H, m * H});
+  const size_t a = A;
   const size_t rt = rt16(A);
-  const size_t packed_path = carve_bytes({rt * S_MK * FRAG_FLOATS, rt * S_MK * FRAG_FLOATS, rt * S_HZ * FRAG_FLOATS,
-                                          rt * S_H * FRAG_FLOATS, rt * S_512 * FRAG_FLOATS, rt * S_H * FRAG_FLOATS,
-                                          rt * S_H * FRAG_FLOATS, rt * S_H * FRAG_FLOATS, T_PRED * rt * S_H * FRAG_FLOATS,
-                                          a * 3 * H, a * 3 * H, a * H, a * H, a * H});
-  return std::max(fp32_path, packed_path);
+  return carve_bytes({rt * S_MK * FRAG_FLOATS, rt * S_MK * FRAG_FLOATS, rt * S_HZ * FRAG_FLOATS,
+                      rt * S_H * FRAG_FLOATS, rt * S_512 * FRAG_FLOATS, rt * S_H * FRAG_FLOATS,
+                      rt * S_H * FRAG_FLOATS, rt * S_H * FRAG_FLOATS, T_PRED * rt * S_H * FRAG_FLOATS,
+                      a * 3 * H, a * 3 * H, a * H, a * H, a * H});
 }
 
 // The decoder on packed operands (dense3.hip): every activation between two products lives as three bf16 planes in MFMA
-// fragment order, written by its producer; the GRU cell is one launch.  Same arithmetic as the fp32 path below up to the
-// 2^-24 of the split products.
+// fragment order, written by its producer; the GRU cell is one launch.
 static int sample_prior_packed(const egx_prior_weights* w, const float* x0, const float* x1, int x_ld, const float* z, int A,
                                float* out_Y, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const egx_prior_packed3& P = *w->packed3;
@@ -145,115 +142,20 @@ extern "C" int egx_sample_prior(const egx_prior_weights* w, const float* x0, con
   }
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int M = A * T_PRED;
-  auto regress = [&]() -> int {
-    // regressor on all 18*A frames (rows ordered [t][a] like Y_gen.view(nt*nb,-1); betas row = a): one fused launch,
-    // 66 dense layers + the 6D -> axis-angle tail
-    RegWeights rw;
-    rw.in_w = w->reg_in_w; rw.in_b = w->reg_in_b; rw.out_w = w->reg_out_w; rw.out_b = w->reg_out_b;
-    for (int l = 0; l < 20; ++l) { rw.blk_w[l] = w->reg_blk_w[l]; rw.blk_b[l] = w->reg_blk_b[l]; }
-    const bool packed = w->reg_packed_in && w->reg_packed_blk && w->reg_packed_out;
-    rw.pk_in = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_in) : nullptr;
-    rw.pk_blk = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_blk) : nullptr;
-    rw.pk_out = packed ? reinterpret_cast<const f32x4*>(w->reg_packed_out) : nullptr;
-    return egx_launch_regressor_fused(st, rw, out_Y, betas, A, M, out_Yb);
-  };
-  if (w->packed3) {
-    EGX_REQUIRE(w->d_comb_w && w->d_comb_b, "the packed decoder path needs the folded output layer (d_comb_w / d_comb_b)");
-    int rc = sample_prior_packed(w, x0, x1, x_ld, z, A, out_Y, workspace, workspace_bytes, st);
-    if (rc) return rc;
-    const egx_prior_packed3& P = *w->packed3;
-    if (P.reg_in_m && P.reg_in_xb && P.reg_in_betas && P.reg_blk && P.reg_out && P.reg_blk_b) {
-      RegWeights3 r3;
-      r3.in_m = static_cast<const bf16x8*>(P.reg_in_m); r3.in_xb = static_cast<const bf16x8*>(P.reg_in_xb);
-      r3.in_b3 = static_cast<const bf16x8*>(P.reg_in_betas); r3.in_b = w->reg_in_b;
-      r3.blk = static_cast<const bf16x8*>(P.reg_blk); r3.blk_b = P.reg_blk_b;
-      r3.out = static_cast<const bf16x8*>(P.reg_out); r3.out_b = w->reg_out_b;
-      rc = egx_launch_regressor3(st, r3, out_Y, betas, A, M, out_Yb);
-    } else {
-      rc = regress();
-    }
-    if (rc) return rc;
-    EGX_HIP_CHECK(hipGetLastError());
-    return EGX_OK;
-  }
-  Carver cv(workspace, workspace_bytes);
-  float* hx = cv.take((size_t)A * H);
-  float* hA = cv.take((size_t)A * H);
-  float* hB = cv.take((size_t)A * H);
-  float* gi = cv.take((size_t)A * 3 * H);
-  float* gh = cv.take((size_t)A * 3 * H);
-  float* gconst = cv.take((size_t)A * 3 * H);
-  float* t512 = cv.take((size_t)A * 512);
-  float* t256 = cv.take((size_t)A * H);
-  float* hfc_all = cv.take((size_t)M * H);  // d_mlp outputs of all 18 steps (folded-output path)
-
-  auto lin = [](int M, int N, std::initializer_list<EgxSeg> segs, const float* W, int ldw, const float* b, int act,
-                const float* res, int ldr, float* out, int ldo) {
-    EgxLin l;
-    l.M = M; l.N = N; l.nseg = 0;
-    for (const EgxSeg& sg : segs) l.segs[l.nseg++] = sg;
-    l.W = W; l.ldw = ldw; l.b = b; l.act = act; l.slope = 0.f; l.res = res; l.ldr = ldr; l.out = out; l.ldo = ldo;
-    return l;
-  };
-  // ---- x_enc GRU over the 2 history frames (zero initial state) -> hx
-  {
-    EgxSeg s0{x0, MK, x_ld};
-    egx_launch_linear(st, A, 3 * H, &s0, 1, w->x_enc_w_ih, w->x_enc_b_ih, 0, 0.f, nullptr, 0, gi, 3 * H);
-    egx_launch_gru_pointwise_first(st, gi, w->x_enc_b_hh, hB, H, A, H);
-    egx_launch_linear_pair(st, lin(A, 3 * H, {{x1, MK, x_ld}}, w->x_enc_w_ih, 0, w->x_enc_b_ih, 0, nullptr, 0, gi, 3 * H),
-                           lin(A, 3 * H, {{hB, H, H}}, w->x_enc_w_hh, 0, w->x_enc_b_hh, 0, nullptr, 0, gh, 3 * H));
-    egx_launch_gru_pointwise(st, gi, gh, hB, H, hx, H, A, H);
-  }
-  // ---- h_rnn = drnn_mlp(hx)  (tanh after every layer); in the same launches: the part of the decoder GRU's input
-  // product that does not change over the 18 steps, gconst = [hx | z] W_ih[:, :384]^T + b_ih   (rnn_in = [hx, z, y_p])
-  float* hcur = hA;
-  float* hnext = hB;
-  const int KIN = H + ZD + MK;  // 585
-  {
-    egx_launch_linear_pair(st, lin(A, 512, {{hx, H, H}}, w->drnn_w[0], 0, w->drnn_b[0], 1, nullptr, 0, t512, 512),
-                           lin(A, 3 * H, {{hx, H, H}, {z, ZD, ZD}}, w->d_rnn_w_ih, KIN, w->d_rnn_b_ih, 0, nullptr, 0, gconst, 3 * H));
-    EgxSeg s2{t512, 512, 512};
-    egx_launch_linear(st, A, H, &s2, 1, w->drnn_w[1], w->drnn_b[1], 1, 0.f, nullptr, 0, t256, H);
-    EgxSeg s3{t256, H, H};
-    egx_launch_linear(st, A, H, &s3, 1, w->drnn_w[2], w->drnn_b[2], 1, 0.f, nullptr, 0, hcur, H);
-  }
-  // ---- 18 decode steps: one paired launch for the two GRU products, gate math, two MLP layers, output + residual
-  const bool fold = w->d_comb_w && w->d_comb_b;
-  for (int i = 0; i < T_PRED; ++i) {
-    const float* yp = (i == 0) ? x1 : out_Y + (size_t)(i - 1) * A * MK;
-    const int yp_ld = (i == 0) ? x_ld : MK;
-    float* hfc = fold ? hfc_all + (size_t)i * A * H : t256;
-    if (!fold || i == 0) {
-      egx_launch_linear_pair(st, lin(A, 3 * H, {{yp, MK, yp_ld}}, w->d_rnn_w_ih + (H + ZD), KIN, nullptr, 0, gconst, 3 * H, gi, 3 * H),
-                             lin(A, 3 * H, {{hcur, H, H}}, w->d_rnn_w_hh, 0, w->d_rnn_b_hh, 0, nullptr, 0, gh, 3 * H));
-    } else {
-      // y_(i-1) = d_out(hfc_(i-1)) + y_(i-2)  =>  gi_i = gi_(i-1) + hfc_(i-1) d_comb_w^T + d_comb_b (in place: every
-      // element of gi is read once, as the residual, by the thread that then writes it)
-      egx_launch_linear_pair(st, lin(A, 3 * H, {{hfc_all + (size_t)(i - 1) * A * H, H, H}}, w->d_comb_w, 0, w->d_comb_b, 0, gi, 3 * H, gi, 3 * H),
-                             lin(A, 3 * H, {{hcur, H, H}}, w->d_rnn_w_hh, 0, w->d_rnn_b_hh, 0, nullptr, 0, gh, 3 * H));
-    }
-    egx_launch_gru_pointwise(st, gi, gh, hcur, H, hnext, H, A, H);
-    EgxSeg s1{hnext, H, H};
-    egx_launch_linear(st, A, 512, &s1, 1, w->d_mlp_w[0], w->d_mlp_b[0], 1, 0.f, nullptr, 0, t512, 512);
-    EgxSeg s2{t512, 512, 512};
-    egx_launch_linear(st, A, H, &s2, 1, w->d_mlp_w[1], w->d_mlp_b[1], 1, 0.f, nullptr, 0, hfc, H);
-    if (!fold) {
-      EgxSeg s3{hfc, H, H};
-      // y_i = d_out(hfc) + y_p   (residual)
-      egx_launch_linear(st, A, MK, &s3, 1, w->d_out_w, w->d_out_b, 0, 0.f, yp, yp_ld, out_Y + (size_t)i * A * MK, MK);
-    }
-    float* tmp = hcur; hcur = hnext; hnext = tmp;
-  }
-  if (fold) {
-    // all 18 output layers as one product over M = 18 A rows, then the residual chain y_i = d_i + y_(i-1) as a scan
-    EgxSeg sa{hfc_all, H, H};
-    egx_launch_linear(st, M, MK, &sa, 1, w->d_out_w, w->d_out_b, 0, 0.f, nullptr, 0, out_Y, MK);
-    egx_launch_frame_scan(st, out_Y, x1, x_ld, A, MK, T_PRED);
-  }
-  {
-    int rc = regress();
-    if (rc) return rc;
-  }
+  EGX_REQUIRE(w->packed3, "egx_sample_prior needs the packed weight images (egx_prior_weights.packed3, built with egx_pack3)");
+  EGX_REQUIRE(w->d_comb_w && w->d_comb_b, "egx_sample_prior needs the folded output layer (d_comb_w / d_comb_b)");
+  const egx_prior_packed3& P = *w->packed3;
+  EGX_REQUIRE(P.reg_in_m && P.reg_in_xb && P.reg_in_betas && P.reg_blk && P.reg_out && P.reg_blk_b, "packed regressor weights missing");
+  int rc = sample_prior_packed(w, x0, x1, x_ld, z, A, out_Y, workspace, workspace_bytes, st);
+  if (rc) return rc;
+  // regressor on all 18*A frames (rows ordered [t][a] like Y_gen.view(nt*nb,-1); betas row = a): one fused launch,
+  // 66 dense layers + the 6D -> axis-angle tail
+  RegWeights3 r3;
+  r3.in_m = static_cast<const bf16x8*>(P.reg_in_m); r3.in_xb = static_cast<const bf16x8*>(P.reg_in_xb);
+  r3.in_b3 = static_cast<const bf16x8*>(P.reg_in_betas); r3.in_b = w->reg_in_b;
+  r3.blk = static_cast<const bf16x8*>(P.reg_blk); r3.blk_b = P.reg_blk_b;
+  r3.out = static_cast<const bf16x8*>(P.reg_out); r3.out_b = w->reg_out_b;
+  if ((rc = egx_launch_regressor3(st, r3, out_Y, betas, A, M, out_Yb))) return rc;
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
@@ -267,15 +169,12 @@ constexpr int PS_ST = 13, PS_EGO = 1, PS_HD = 16, PS_CAT = 36;   // k-steps of 4
 extern "C" size_t egx_policy_workspace_bytes(int n) {
   if (n <= 0) return 0;
   const size_t m = n;
-  const size_t fp32_path = carve_bytes({m * 1536, m * 1536, m * 512, m * 512, m * 512, m * 128, m * 1152, m * 1152, m * 256,
-                                        m * 1536, m * 1536, m * 512, m * 1152, m * 1152, m * 1152});
   const size_t rt = rt16(n);
-  const size_t packed_path = carve_bytes({rt * PS_ST * FRAG_FLOATS, rt * PS_ST * FRAG_FLOATS, rt * PS_EGO * FRAG_FLOATS,
+  return carve_bytes({rt * PS_ST * FRAG_FLOATS, rt * PS_ST * FRAG_FLOATS, rt * PS_EGO * FRAG_FLOATS,
                                           rt * PS_EGO * FRAG_FLOATS, rt * PS_HD * FRAG_FLOATS, rt * PS_HD * FRAG_FLOATS,
                                           rt * PS_CAT * FRAG_FLOATS, rt * PS_CAT * FRAG_FLOATS, rt * PS_CAT * FRAG_FLOATS,
                                           rt * PS_CAT * FRAG_FLOATS, rt * PS_CAT * FRAG_FLOATS, m * 512, m * 512, m * 1152,
                                           m * 1152, m * 1152});
-  return std::max(fp32_path, packed_path);
 }
 
 extern "C" int egx_policy_set_precision(int bf16) {
@@ -383,79 +282,9 @@ extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* stat
     return EGX_ERR_WORKSPACE;
   }
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  if (w->packed3) {
-    int rc = policy_forward_packed(w, state, ego, dist, time, n, out_mu, out_logvar, out_value, workspace, workspace_bytes, st);
-    if (rc) return rc;
-    EGX_HIP_CHECK(hipGetLastError());
-    return EGX_OK;
-  }
-  Carver cv(workspace, workspace_bytes);
-  const size_t m = n;
-  float* gi = cv.take(m * 1536);
-  float* gh = cv.take(m * 1536);
-  float* h0 = cv.take(m * 512);
-  float* hxs = cv.take(m * 512);
-  float* hes = cv.take(m * 512);
-  float* pe = cv.take(m * 128);
-  float* a1 = cv.take(m * 1152);
-  float* a2 = cv.take(m * 1152);
-  float* zp = cv.take(m * 256);
-  constexpr int HD = 512;
-  const int bf = g_policy_bf16.load();
-  auto lin = [bf](int M, int N, std::initializer_list<EgxSeg> segs, const float* W, const float* b, int act, float slope,
-                  const float* res, int ldr, float* out, int ldo) {
-    EgxLin l;
-    l.M = M; l.N = N; l.nseg = 0;
-    for (const EgxSeg& sg : segs) l.segs[l.nseg++] = sg;
-    l.W = W; l.ldw = 0; l.b = b; l.act = act; l.slope = slope; l.res = res; l.ldr = ldr; l.out = out; l.ldo = ldo;
-    l.bf16 = bf;
-    return l;
-  };
-  // two independent 2-step GRUs (markers+features 402 -> 512, egosensing 32 -> 512): their products share launches
-  float* hx1 = h0;              // first-step hidden state of the marker encoder
-  float* egi = cv.take(m * 1536);
-  float* egh = cv.take(m * 1536);
-  float* eh1 = cv.take(m * 512);
-  egx_launch_linear_pair(st, lin(n, 3 * HD, {{state, 402, 804}}, w->x_enc_w_ih, w->x_enc_b_ih, 0, 0.f, nullptr, 0, gi, 3 * HD),
-                         lin(n, 3 * HD, {{ego, 32, 64}}, w->ego_enc_w_ih, w->ego_enc_b_ih, 0, 0.f, nullptr, 0, egi, 3 * HD));
-  egx_launch_gru_pointwise_first(st, gi, w->x_enc_b_hh, hx1, HD, n, HD);
-  egx_launch_gru_pointwise_first(st, egi, w->ego_enc_b_hh, eh1, HD, n, HD);
-  egx_launch_linear_pair(st, lin(n, 3 * HD, {{state + 402, 402, 804}}, w->x_enc_w_ih, w->x_enc_b_ih, 0, 0.f, nullptr, 0, gi, 3 * HD),
-                         lin(n, 3 * HD, {{ego + 32, 32, 64}}, w->ego_enc_w_ih, w->ego_enc_b_ih, 0, 0.f, nullptr, 0, egi, 3 * HD));
-  egx_launch_linear_pair(st, lin(n, 3 * HD, {{hx1, HD, HD}}, w->x_enc_w_hh, w->x_enc_b_hh, 0, 0.f, nullptr, 0, gh, 3 * HD),
-                         lin(n, 3 * HD, {{eh1, HD, HD}}, w->ego_enc_w_hh, w->ego_enc_b_hh, 0, 0.f, nullptr, 0, egh, 3 * HD));
-  egx_launch_gru_pointwise(st, gi, gh, hx1, HD, hxs, HD, n, HD);
-  egx_launch_gru_pointwise(st, egi, egh, eh1, HD, hes, HD, n, HD);
-  egx_launch_posenc(st, dist, time, n, pe);
-  const float slope = 0.01f;  // torch.nn.LeakyReLU() default (baseops.py:627-628)
-  // hx as one [n,1152] buffer: residual of the first block of both heads
-  float* hxcat = cv.take(m * 1152);
-  EGX_HIP_CHECK(hipMemcpy2DAsync(hxcat, 1152 * sizeof(float), hxs, HD * sizeof(float), HD * sizeof(float), n, hipMemcpyDeviceToDevice, st));
-  EGX_HIP_CHECK(hipMemcpy2DAsync(hxcat + HD, 1152 * sizeof(float), hes, HD * sizeof(float), HD * sizeof(float), n, hipMemcpyDeviceToDevice, st));
-  EGX_HIP_CHECK(hipMemcpy2DAsync(hxcat + 2 * HD, 1152 * sizeof(float), pe, 128 * sizeof(float), 128 * sizeof(float), n, hipMemcpyDeviceToDevice, st));
-  float* c1 = cv.take(m * 1152);  // critic activations (actor uses a1 / a2)
-  float* c2 = cv.take(m * 1152);
-  const bool do_a = out_mu != nullptr, do_c = out_value != nullptr;
-  auto layer = [&](const float* xin, const float* W, const float* B, int N, int act, const float* res, float* out, int ldo) {
-    return lin(n, N, {{xin, 1152, 1152}}, W, B, act, slope, res, res ? 1152 : 0, out, ldo);
-  };
-  // h = hx; for blk: h = lrelu(fc2(lrelu(fc1(h)))) + h ; y = out_fc(h)   - actor and critic layer i share a launch
-  auto run = [&](const EgxLin& la, const EgxLin& lc) {
-    if (do_a && do_c) egx_launch_linear_pair(st, la, lc);
-    else if (do_a) egx_launch_linear_one(st, la);
-    else egx_launch_linear_one(st, lc);
-  };
-  run(layer(hxcat, w->actor_w[0], w->actor_b[0], 1152, 3, nullptr, a1, 1152), layer(hxcat, w->critic_w[0], w->critic_b[0], 1152, 3, nullptr, c1, 1152));
-  run(layer(a1, w->actor_w[1], w->actor_b[1], 1152, 3, hxcat, a2, 1152), layer(c1, w->critic_w[1], w->critic_b[1], 1152, 3, hxcat, c2, 1152));
-  run(layer(a2, w->actor_w[2], w->actor_b[2], 1152, 3, nullptr, a1, 1152), layer(c2, w->critic_w[2], w->critic_b[2], 1152, 3, nullptr, c1, 1152));
-  run(layer(a1, w->actor_w[3], w->actor_b[3], 1152, 3, a2, a2, 1152), layer(c1, w->critic_w[3], w->critic_b[3], 1152, 3, c2, c2, 1152));
-  run(layer(a2, w->actor_out_w, w->actor_out_b, 256, 0, nullptr, zp, 256), layer(c2, w->critic_out_w, w->critic_out_b, 1, 0, nullptr, out_value, 1));
-  if (do_a) {
-    EGX_HIP_CHECK(hipMemcpy2DAsync(out_mu, 128 * sizeof(float), zp, 256 * sizeof(float), 128 * sizeof(float), n,
-                                   hipMemcpyDeviceToDevice, st));
-    EGX_HIP_CHECK(hipMemcpy2DAsync(out_logvar, 128 * sizeof(float), zp + 128, 256 * sizeof(float), 128 * sizeof(float), n,
-                                   hipMemcpyDeviceToDevice, st));
-  }
+  EGX_REQUIRE(w->packed3, "egx_policy_forward needs the packed weight images (egx_policy_weights.packed3: egx_pack3 or egx_policy_train_packed)");
+  const int rc = policy_forward_packed(w, state, ego, dist, time, n, out_mu, out_logvar, out_value, workspace, workspace_bytes, st);
+  if (rc) return rc;
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

@@ -169,12 +169,6 @@ class MoshRegressor(nn.Module):
         self.pnet = ResNetBlock(self.in_dim + self.body_dim + 10, 128, self.body_dim, 10, "relu")
 
 
-PACK_DECODER_WEIGHTS = os.environ.get("EGX_DECODER_PACKED", "1") != "0"   # development switches: 0 = fp32-MFMA layer kernels
-PACK_POLICY_WEIGHTS = os.environ.get("EGX_POLICY_PACKED", "1") != "0"
-PACK_REGRESSOR3 = os.environ.get("EGX_REGRESSOR_PACKED", "1") != "0"
-PACK_REGRESSOR_WEIGHTS = os.environ.get("EGX_PACK_REGRESSOR", "1") == "1"
-FOLD_DECODER_OUTPUT = os.environ.get("EGX_FOLD_DECODER_OUTPUT", "1") == "1"
-
 
 class GAMMAPrimitiveCombo(nn.Module):
     def __init__(self, markercfg, bparamscfg):
@@ -234,23 +228,10 @@ class GAMMAPrimitiveCombo(nn.Module):
             wy = p.d_rnn.weight_ih[:, p.d_rnn.weight_ih.shape[1] - p.d_out.weight.shape[0]:].double()
             self._comb_w = (wy @ p.d_out.weight.double()).float().contiguous()
             self._comb_b = (wy @ p.d_out.bias.double()).float().contiguous()
-        w.d_comb_w, w.d_comb_b = (_p(self._comb_w), _p(self._comb_b)) if FOLD_DECODER_OUTPUT else (None, None)
-        # the regressor's weights once more in the lane order of the MFMA B operand (egx_prior_weights.reg_packed_*):
-        # P[g][c][32 h + i][e] = W[32 g + i][8 c + 4 h + e], so that each weight load of the fused kernel is one contiguous KiB
-        if PACK_REGRESSOR_WEIGHTS and r.in_fc.weight.is_cuda:
-            with torch.no_grad():
-                def pack(W, groups, chunks):
-                    Wp = torch.zeros(groups * 32, chunks * 8, dtype=torch.float32, device=W.device)
-                    Wp[:W.shape[0], :W.shape[1]] = W
-                    if W.shape[0] < groups * 32:
-                        Wp[W.shape[0]:, :W.shape[1]] = W[-1]
-                    return Wp.view(groups, 32, chunks, 2, 4).permute(0, 2, 3, 1, 4).contiguous()
-                self._pk_in = pack(r.in_fc.weight, 4, 47)
-                self._pk_blk = torch.stack([pack(r.layers[b].layers[k].weight, 4, 16) for b in range(10) for k in range(2)]).contiguous()
-                self._pk_out = pack(r.out_fc.weight, 5, 16)
-            w.reg_packed_in, w.reg_packed_blk, w.reg_packed_out = _p(self._pk_in), _p(self._pk_blk), _p(self._pk_out)
-        # the decoder's dense weights as three bf16 planes in MFMA fragment order (egx_prior_packed3, csrc/dense3.hip)
-        if PACK_DECODER_WEIGHTS and FOLD_DECODER_OUTPUT and p.x_enc.weight_ih_l0.is_cuda:
+        w.d_comb_w, w.d_comb_b = _p(self._comb_w), _p(self._comb_b)
+        # the decoder's and the regressor's dense weights as three bf16 planes in MFMA fragment order (egx_prior_packed3,
+        # csrc/dense3.hip): what egx_sample_prior computes from
+        if p.x_enc.weight_ih_l0.is_cuda:
             self._p3_bufs = {}
             p3 = _lib.PriorPacked3()
             wih = p.d_rnn.weight_ih
@@ -269,22 +250,21 @@ class GAMMAPrimitiveCombo(nn.Module):
                 p3.drnn_w[i] = self._p3_bufs[f"drnn_w{i}"].data_ptr()
             for i in range(2):
                 p3.d_mlp_w[i] = self._p3_bufs[f"d_mlp_w{i}"].data_ptr()
-            if PACK_REGRESSOR3:
-                lib = _lib.load()
-                win = r.in_fc.weight.detach()
-                self._p3_bufs["reg_in_m"] = pack3(win, 0, 201)
-                self._p3_bufs["reg_in_xb"] = pack3(win, 201, 159)
-                self._p3_bufs["reg_in_betas"] = pack3(win, 360, 10)
-                self._p3_bufs["reg_out"] = pack3(r.out_fc.weight.detach())
-                blk = [r.layers[b].layers[k] for b in range(10) for k in range(2)]
-                per = lib.egx_pack3_bytes(128, 128)
-                allb = torch.zeros(20 * per, dtype=torch.uint8, device=win.device)
-                for i, fc in enumerate(blk):
-                    allb[i * per:(i + 1) * per].copy_(pack3(fc.weight.detach()))
-                self._p3_bufs["reg_blk"] = allb
-                self._p3_bufs["reg_blk_b"] = torch.stack([fc.bias.detach().float() for fc in blk]).contiguous()
-                for name in ("reg_in_m", "reg_in_xb", "reg_in_betas", "reg_blk", "reg_out", "reg_blk_b"):
-                    setattr(p3, name, self._p3_bufs[name].data_ptr())
+            lib = _lib.load()
+            win = r.in_fc.weight.detach()
+            self._p3_bufs["reg_in_m"] = pack3(win, 0, 201)
+            self._p3_bufs["reg_in_xb"] = pack3(win, 201, 159)
+            self._p3_bufs["reg_in_betas"] = pack3(win, 360, 10)
+            self._p3_bufs["reg_out"] = pack3(r.out_fc.weight.detach())
+            blk = [r.layers[b].layers[k] for b in range(10) for k in range(2)]
+            per = lib.egx_pack3_bytes(128, 128)
+            allb = torch.zeros(20 * per, dtype=torch.uint8, device=win.device)
+            for i, fc in enumerate(blk):
+                allb[i * per:(i + 1) * per].copy_(pack3(fc.weight.detach()))
+            self._p3_bufs["reg_blk"] = allb
+            self._p3_bufs["reg_blk_b"] = torch.stack([fc.bias.detach().float() for fc in blk]).contiguous()
+            for name in ("reg_in_m", "reg_in_xb", "reg_in_betas", "reg_blk", "reg_out", "reg_blk_b"):
+                setattr(p3, name, self._p3_bufs[name].data_ptr())
             self._p3 = p3
             w.packed3 = C.pointer(p3)
         self._wstruct, self._wkey = w, key
@@ -554,7 +534,7 @@ class PolicyHipRunner:
         w.actor_out_w, w.actor_out_b = _p(a.out_fc.weight), _p(a.out_fc.bias)
         w.critic_out_w, w.critic_out_b = _p(c.out_fc.weight), _p(c.out_fc.bias)
         self._p3 = None
-        if PACK_POLICY_WEIGHTS and s.x_enc.weight_ih_l0.is_cuda:
+        if s.x_enc.weight_ih_l0.is_cuda:
             self._p3_src = [("x_enc_w_ih", None, s.x_enc.weight_ih_l0), ("x_enc_w_hh", None, s.x_enc.weight_hh_l0),
                             ("ego_enc_w_ih", None, s.ego_enc.weight_ih_l0), ("ego_enc_w_hh", None, s.ego_enc.weight_hh_l0),
                             ("actor_out_w", None, a.out_fc.weight), ("critic_out_w", None, c.out_fc.weight)]

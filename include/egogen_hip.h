@@ -294,22 +294,15 @@ typedef struct egx_prior_weights {
   const float *reg_in_w, *reg_in_b;                               /* regressor.pnet.in_fc 370-128        */
   const float *reg_blk_w[20], *reg_blk_b[20];                     /* regressor.pnet.layers.{0..9}.layers.{0,1} */
   const float *reg_out_w, *reg_out_b;                             /* regressor.pnet.out_fc 128-159       */
-  /* Optional (NULL = evaluate as written in the reference): d_comb_w [768,256] = d_rnn_w_ih[:, 384:585] . d_out_w and
-   * d_comb_b [768] = d_rnn_w_ih[:, 384:585] . d_out_b.  The residual decoder feeds y_i = d_out(h_i) + y_(i-1) back into the
-   * GRU cell (models_GAMMA_primitive.py:95-103), so the cell's input product obeys
-   * gi_(i+1) = gi_i + h_i . d_comb_w^T + d_comb_b: with the two folded tensors the output layer leaves the 18-step
-   * critical path and is evaluated for all steps at once afterwards. */
+  /* d_comb_w [768,256] = d_rnn_w_ih[:, 384:585] . d_out_w and d_comb_b [768] = d_rnn_w_ih[:, 384:585] . d_out_b (folded by the
+   * caller, in float64).  The residual decoder feeds y_i = d_out(h_i) + y_(i-1) back into the GRU cell
+   * (models_GAMMA_primitive.py:95-103), so the cell's input product obeys gi_(i+1) = gi_i + h_i . d_comb_w^T + d_comb_b: with
+   * the two folded tensors the output layer leaves the 18-step critical path and is evaluated for all steps at once
+   * afterwards. */
   const float *d_comb_w, *d_comb_b;
-  /* Optional (all three or none; NULL = read the torch-layout weights above): the regressor's weights repacked in the lane
-   * order of the matrix instruction's B operand, so that every weight load of the fused kernel is one contiguous 1 KiB:
-   *   P[group g][chunk c][lane l = 32 h + i][e] = W[32 g + i][8 c + 4 h + e]
-   * reg_packed_in  [4][47][64][4] (in_fc, K 370 zero-padded to 376), reg_packed_blk [20][4][16][64][4] (the 20 block
-   * layers), reg_packed_out [5][16][64][4] (out_fc, rows past 158 repeat row 158). */
-  const float *reg_packed_in, *reg_packed_blk, *reg_packed_out;
-  /* Optional (needs d_comb_*): packed images of the decoder's weights.  With them egx_sample_prior runs the decoder on the
-   * bf16 matrix pipe (three-term splits, fp32-equivalent) with the GRU cell as one launch (3 launches per decode step
-   * instead of 4) and the fused body regressor on the same arithmetic (48-row workgroups, one per compute unit).
-   * NULL = the fp32-MFMA kernels on the torch-layout weights above. */
+  /* Packed images (egx_pack3) of the decoder's and the regressor's weights: egx_sample_prior runs on the bf16 matrix pipe
+   * (three-term splits, fp32-equivalent) with the GRU cell as one launch and the fused body regressor as another (48-row
+   * workgroups, one per compute unit).  Required - the torch-layout matrices above are only read for the biases. */
   const egx_prior_packed3* packed3;
 } egx_prior_weights;
 
@@ -345,9 +338,9 @@ typedef struct egx_policy_weights {
   const float *actor_out_w, *actor_out_b; /* actor.pnet.out_fc   256x1152                    */
   const float *critic_w[4], *critic_b[4]; /* critic.vnet.layers.{0,1}.layers.{0,1}           */
   const float *critic_out_w, *critic_out_b; /* critic.vnet.out_fc 1x1152                     */
-  /* Optional: with the packed images egx_policy_forward runs on the bf16 matrix pipe with three-term splits
-   * (fp32-equivalent; precision 1 of egx_policy_set_precision keeps the leading product only), each GRU cell as one
-   * launch, [hx | he | posenc] assembled in place.  NULL = the fp32-MFMA layer kernels. */
+  /* Packed images of the weights (egx_pack3, or the update's own: egx_policy_train_packed): egx_policy_forward runs on the
+   * bf16 matrix pipe (arithmetic: egx_policy_set_precision), each GRU cell as one launch, [hx | he | posenc] assembled in
+   * place.  Required. */
   const egx_policy_packed3* packed3;
 } egx_policy_weights;
 
@@ -563,13 +556,6 @@ int egx_event_create(void** out_event);
 int egx_event_destroy(void* event);
 int egx_event_elapsed_ms(void* start_event, void* stop_event, float* out_ms); /* synchronises on stop_event */
 
-/* Streams restricted to part of the device (bit i of `mask`, num_words x 32 bits, enables compute unit i): the collector
- * steps two shards of agents on separate streams and launches the throughput-bound SMPL-X kernel of one shard on such a
- * stream, so that the other shard's chain of small dependent launches keeps the remaining compute units (the reference
- * steps its environments one after the other on the default stream, crowd_ppo/main_ppo.py:97,177-183).  egx_lbs_forward
- * sizes its persistent grid for the compute units of the stream it is given. */
-int egx_stream_create_cu_mask(const uint32_t* mask, int num_words, void** out_stream);
-int egx_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PPO update: fused loss + gradient of one minibatch (crowd_ppo/ppo_policy.py:189-241) and the backward of the

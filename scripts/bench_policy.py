@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development aid: egx_policy_forward wall time on the GPU (EGX_POLICY_PACKED=0: the fp32-MFMA layer kernels)."""
+"""Development aid: egx_policy_forward wall time on the GPU."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
