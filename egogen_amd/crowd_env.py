@@ -237,6 +237,7 @@ class VecCrowdEnv:
         self._graph = None
         self._injected = False
         self._cand_pool, self._cand_pool_pos, self._cand_step = None, 0, None
+        self._box_pool = None
         self._z_in = self.z
         self.profile_events = []  # [(start_event, stop_event)] consumed one pair per step (bench.py)
 
@@ -352,16 +353,28 @@ class VecCrowdEnv:
             u = torch.rand(A, K, generator=g, device=self.dev) * 2 - 1
             self.cand_yaw.copy_(u * (2 * np.pi * 0.2))           # environments.py:1100-1101 (CrowdMotion.gen_init_body)
         else:
-            # the draws of ALL rounds in one go (the same four RNG launches whatever the number of rounds); the retry rounds
-            # only read theirs for agents that are still pending
+            # the draws of ALL rounds of CAND_POOL steps in one go (the same handful of RNG / gather launches whatever the number
+            # of rounds and steps; a step's draws are a slice of the pool, handed to the reset kernel by address); the retry
+            # rounds only read theirs for agents that are still pending
             R = self.R
-            sc = torch.randint(0, self.num_scenes, (R * A * K,), generator=g, device=self.dev)
-            pi = torch.randint(0, self.box_pairs.shape[1], (R * A * K,), generator=g, device=self.dev)
-            self._cand_pairs_all.copy_(self.box_pairs[sc, pi].reshape(R, A, K, 2, 3))
-            self._cand_scene_all.copy_(sc.reshape(R, A, K).to(torch.int32))
-            self._cand_variant_all.copy_(torch.randint(0, len(self.variant_starts), (R, A, K), generator=g, device=self.dev).to(torch.int32))
-            u = torch.rand(R, A, K, generator=g, device=self.dev) * 2 - 1
-            self._cand_yaw_all.copy_(u * (2 * np.pi * 0.1))      # environments.py:529
+            if self._box_pool is None or self._cand_pool_pos >= CAND_POOL:
+                P = CAND_POOL
+                sc = torch.randint(0, self.num_scenes, (P * R * A * K,), generator=g, device=self.dev)
+                pi = torch.randint(0, self.box_pairs.shape[1], (P * R * A * K,), generator=g, device=self.dev)
+                u = torch.rand(P, R, A, K, generator=g, device=self.dev) * 2 - 1
+                self._box_pool = {
+                    "pairs": self.box_pairs[sc, pi].reshape(P, R, A, K, 2, 3),
+                    "scene": sc.reshape(P, R, A, K).to(torch.int32),
+                    "variant": torch.randint(0, len(self.variant_starts), (P, R, A, K), generator=g, device=self.dev).to(torch.int32),
+                    "yaw": u * (2 * np.pi * 0.1)}                # environments.py:529
+                self._cand_pool_pos = 0
+            k = self._cand_pool_pos
+            self._cand_pool_pos += 1
+            bp = self._box_pool
+            self._cand_pairs_all, self._cand_scene_all = bp["pairs"][k], bp["scene"][k]
+            self._cand_variant_all, self._cand_yaw_all = bp["variant"][k], bp["yaw"][k]
+            self.cand_pairs, self.cand_yaw = self._cand_pairs_all[0], self._cand_yaw_all[0]
+            self.cand_variant, self.cand_scene = self._cand_variant_all[0], self._cand_scene_all[0]
             self._rounds_ready = R
 
     def set_candidates(self, pairs, yaw=None, variant=None, scene=None):
@@ -373,6 +386,11 @@ class VecCrowdEnv:
         if r < 1 or r > self.R or pairs.shape[1] != r * K:
             raise ValueError(f"candidates per agent must be a multiple of K={K} up to {self.R * K}, got {pairs.shape[1]}")
         rm = lambda t, *tail: t.reshape(A, r, K, *tail).transpose(0, 1)   # [A, r*K, ...] -> round-major [r, A, K, ...]
+        if self._box_pool is not None:   # the buffers may be views of the sampler's pool: injected draws get their own
+            self._cand_pairs_all, self._cand_yaw_all = self._cand_pairs_all.clone(), self._cand_yaw_all.clone()
+            self._cand_variant_all, self._cand_scene_all = self._cand_variant_all.clone(), self._cand_scene_all.clone()
+            self.cand_pairs, self.cand_yaw = self._cand_pairs_all[0], self._cand_yaw_all[0]
+            self.cand_variant, self.cand_scene = self._cand_variant_all[0], self._cand_scene_all[0]
         self._cand_pairs_all[:r].copy_(rm(pairs, 2, 3))
         self._cand_step = None
         if yaw is not None:
