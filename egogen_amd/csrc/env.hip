@@ -609,20 +609,21 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
     const float* TM = p.tab_markers + (size_t)v * 2 * NM * 3;
     const float* start = p.cand_pairs + ((size_t)a * p.K + k) * 6;
     const float* target = start + 3;
+    // world placement of the mocap seed: x_w = Rg (x_loc - J0) + J0 + t   (J0 = rest root = tab joint 0 of frame f)
+    float Rg[2][9], tg[2][3];   // live in thread 0 only
+    auto world_joint = [&](int f, int j, float* o) {
+      const float* J0 = TJ;
+      const float* q = TJ + ((size_t)f * NJO + j) * 3;
+      const float d[3] = {q[0] - J0[0], q[1] - J0[1], q[2] - J0[2]};
+      mat3_vec(Rg[f], d, o);
+      o[0] += J0[0] + tg[f][0]; o[1] += J0[1] + tg[f][1]; o[2] += J0[2] + tg[f][2];
+    };
     if (tid == 0) {
-      // world placement of the mocap seed: x_w = Rg (x_loc - J0) + J0 + t   (J0 = rest root = tab joint 0 of frame f)
       const float* J0 = TJ;  // root of frame 0 (identical for both frames: betas only)
-      float Rg[2][9], tg[2][3];
       for (int f = 0; f < 2; ++f) {
         for (int e = 0; e < 9; ++e) Rg[f][e] = p.tab_glorot[((size_t)v * 2 + f) * 9 + e];
         for (int e = 0; e < 3; ++e) tg[f][e] = p.tab_transl[((size_t)v * 2 + f) * 3 + e];
       }
-      auto world_joint = [&](int f, int j, float* o) {
-        const float* q = TJ + ((size_t)f * NJO + j) * 3;
-        const float d[3] = {q[0] - J0[0], q[1] - J0[1], q[2] - J0[2]};
-        mat3_vec(Rg[f], d, o);
-        o[0] += J0[0] + tg[f][0]; o[1] += J0[1] + tg[f][1]; o[2] += J0[2] + tg[f][2];
-      };
       auto apply_rot = [&](const float* Rm) {  // environments.py:233-237: rotate orient, rotate about the pelvis
         for (int f = 0; f < 2; ++f) {
           float nr[9];
@@ -661,14 +662,29 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
         const float Rz[9] = {cosf(th), -sinf(th), 0.f, sinf(th), cosf(th), 0.f, 0.f, 0.f, 1.f};
         apply_rot(Rz);
       }
-      // pelvis over the start, lowest joint of frame 0 on the floor (environments.py:240-247)
-      float jr[3], zmin = 3.4e38f;
-      world_joint(0, 0, jr);
-      for (int j = 0; j < NJO; ++j) {
+      // frame 0's placement for the whole block: the lowest of its 127 joints is found one joint per thread
+      for (int e = 0; e < 9; ++e) s_f[42 + e] = Rg[0][e];
+      for (int e = 0; e < 3; ++e) s_f[51 + e] = tg[0][e];
+    }
+    __syncthreads();
+    float zmin;
+    {
+      float zl = 3.4e38f;
+      if (tid != 0) {
+        for (int e = 0; e < 9; ++e) Rg[0][e] = s_f[42 + e];
+        for (int e = 0; e < 3; ++e) tg[0][e] = s_f[51 + e];
+      }
+      for (int j = tid; j < NJO; j += BLK) {
         float q[3];
         world_joint(0, j, q);
-        zmin = fminf(zmin, q[2]);
+        zl = fminf(zl, q[2]);
       }
+      zmin = block_reduce(zl, s_red, 1);
+    }
+    if (tid == 0) {
+      // pelvis over the start, lowest joint of frame 0 on the floor (environments.py:240-247)
+      float jr[3];
+      world_joint(0, 0, jr);
       for (int f = 0; f < 2; ++f) {
         tg[f][0] += -jr[0] + start[0]; tg[f][1] += -jr[1] + start[1]; tg[f][2] += -zmin + start[2];
       }
@@ -691,7 +707,7 @@ __global__ __launch_bounds__(BLK) void egx_env_reset_kernel(ResetArgs p) {
       s_f[39] = target[0]; s_f[40] = target[1]; s_f[41] = w0[2];
     }
     __syncthreads();
-    float R0n[9], T0n[3], Rg[2][9], tg[2][3];
+    float R0n[9], T0n[3];   // Rg / tg: every thread now takes the final placement of both frames
     for (int e = 0; e < 9; ++e) R0n[e] = s_f[e];
     for (int e = 0; e < 3; ++e) T0n[e] = s_f[9 + e];
     for (int f = 0; f < 2; ++f) {
