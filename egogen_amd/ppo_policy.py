@@ -28,6 +28,23 @@ _LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
 _UPDATE_PREC = {"f32": 0, "bf16x2": 2, "bf16": 1}
 
 
+class RunningMeanStd:
+    """tianshou.utils.RunningMeanStd [upstream]: running mean / variance of a data stream, merged batch by batch
+    (Chan's parallel algorithm), as `BasePolicy.ret_rms` uses it for `reward_normalization` (ppo_policy.py:121-135)."""
+
+    def __init__(self):
+        self.mean, self.var, self.count = 0.0, 1.0, 0
+
+    def update(self, x) -> None:
+        x = np.asarray(x, np.float64).reshape(-1)
+        bm, bv, bc = float(x.mean()), float(x.var()), x.size
+        delta = bm - self.mean
+        tot = self.count + bc
+        new_mean = self.mean + delta * bc / tot
+        m2 = self.var * self.count + bv * bc + delta ** 2 * self.count * bc / tot
+        self.mean, self.var, self.count = new_mean, m2 / tot, tot
+
+
 class RolloutBatch:
     """Time-major storage of one collect: n vector steps of A agents (+ the observation after the last step)."""
 
@@ -68,8 +85,16 @@ class GAMMAPPOPolicy(nn.Module):
                  advantage_normalization: bool = True, recompute_advantage: bool = False,
                  deterministic_eval: bool = False, max_batchsize: int = 256, seed: int = 0, **_ignored):
         super().__init__()
-        if dual_clip is not None or value_clip or reward_normalization or recompute_advantage:
-            raise NotImplementedError("main_ppo.py runs with dual_clip=None, value_clip=0, rew_norm=False, recompute_adv=0")
+        # ppo_policy.py:80-86 / tianshou A2CPolicy: the options main_ppo.py exposes as --dual-clip / --value-clip / --rew-norm /
+        # --recompute-adv (all off by default).  With any of the loss options on, the minibatch runs through the torch
+        # expression of `minibatch_loss` (autograd nodes on the HIP products): the hand-written chain and the fused loss
+        # kernel implement the default loss only.
+        assert dual_clip is None or dual_clip > 1.0, "Dual-clip PPO parameter should greater than 1.0."
+        self._dual_clip = dual_clip
+        self._value_clip = bool(value_clip)
+        self._rew_norm = bool(reward_normalization)
+        self._recompute_adv = bool(recompute_advantage)
+        self.ret_rms = RunningMeanStd()      # tianshou BasePolicy.ret_rms (returns' running variance, rew_norm only)
         self.actor, self.critic, self.shared_net = actor, critic, shared_net
         # tianshou's A2CPolicy builds ActorCritic(actor, critic); ppo_policy.py:90 is a bare annotation, so the
         # parent's object (WITHOUT shared_net) is what clip_grad_norm_ sees
@@ -150,7 +175,7 @@ class GAMMAPPOPolicy(nn.Module):
         """ppo_policy.py:93-140: values of obs / obs_next, GAE returns and advantages."""
         lib = _lib.load()
         n, A = batch.n, batch.A
-        if getattr(batch, "rollout_values_valid", False):
+        if getattr(batch, "rollout_values_valid", False) and not getattr(self, "_recomputing", False):
             # V(obs_0..n-1) were produced by the rollout forward passes with the same weights (the reference re-evaluates
             # them, ppo_policy.py:110-112, and gets the same numbers); only the observation after the last step is new
             last = {k: v[n * A:(n + 1) * A] for k, v in batch.obs_flat(n + 1).items()}
@@ -158,9 +183,18 @@ class GAMMAPPOPolicy(nn.Module):
         else:
             v = self.values(batch.obs_flat(n + 1))
             batch.values.copy_(v.reshape(n + 1, A))
-        rc = lib.egx_gae(_lib.ptr(batch.values), _lib.ptr(batch.rew), _lib.ptr(batch.term), n, A, float(self._gamma),
+        values = batch.values
+        scale = 1.0
+        if self._rew_norm:   # ppo_policy.py:121-123: the critic predicts NORMALISED returns: un-normalise v_s / v_s_ for the scan
+            scale = float(np.sqrt(self.ret_rms.var + _EPS))
+            values = (batch.values * scale).contiguous()
+        rc = lib.egx_gae(_lib.ptr(values), _lib.ptr(batch.rew), _lib.ptr(batch.term), n, A, float(self._gamma),
                          float(self._lambda), _lib.ptr(batch.returns), _lib.ptr(batch.adv), _lib.current_stream_ptr())
         _lib.check(rc, "egx_gae")
+        if self._rew_norm:   # :131-133 (one host round trip per collect, like the reference's numpy statistics)
+            unnorm = batch.returns.detach().double().cpu().numpy()
+            batch.returns.div_(scale)
+            self.ret_rms.update(unnorm)
         return batch
 
     # ---- update side (autograd) ---------------------------------------------------------------------
@@ -202,11 +236,14 @@ class GAMMAPPOPolicy(nn.Module):
             if p.grad is None or p.grad.data_ptr() != base + 4 * off:
                 p.grad = self._flat_grad[off:off + n].view_as(p)
 
-    def minibatch_loss(self, obs, act, adv, returns, logp_old, global_stats=None):
+    def _loss_options(self) -> bool:
+        return self._dual_clip is not None or self._value_clip
+
+    def minibatch_loss(self, obs, act, adv, returns, logp_old, global_stats=None, v_s=None):
         """ppo_policy.py:189-241 for one minibatch.  With data parallelism `global_stats` = (mean, std, n_global):
         the advantage statistics and the loss normaliser of the GLOBAL minibatch."""
         n_local = adv.shape[0]
-        if adv.is_cuda and self.use_fused_loss:
+        if adv.is_cuda and self.use_fused_loss and not self._loss_options():
             return self._minibatch_loss_fused(obs, act, adv, returns, logp_old, global_stats)
         hx, mu, sigma = self._dist_params(obs)
         if self._norm_adv:
@@ -220,9 +257,20 @@ class GAMMAPPOPolicy(nn.Module):
         ratio = (lp - logp_old).exp().float()
         surr1 = ratio * adv
         surr2 = ratio.clamp(1.0 - self._eps_clip, 1.0 + self._eps_clip) * adv
-        clip_loss = -torch.min(surr1, surr2).sum() * scale
+        if self._dual_clip:      # ppo_policy.py:204-207
+            clip1 = torch.min(surr1, surr2)
+            clip2 = torch.max(clip1, self._dual_clip * adv)
+            clip_loss = -torch.where(adv < 0, clip2, clip1).sum() * scale
+        else:
+            clip_loss = -torch.min(surr1, surr2).sum() * scale
         value = self.critic(hx).flatten()
-        vf_loss = (returns - value).pow(2).sum() * scale
+        if self._value_clip:     # :216-221
+            if v_s is None:
+                raise ValueError("value_clip needs the old values v_s of the minibatch")
+            v_clip = v_s + (value - v_s).clamp(-self._eps_clip, self._eps_clip)
+            vf_loss = torch.max((returns - value).pow(2), (returns - v_clip).pow(2)).sum() * scale
+        else:
+            vf_loss = (returns - value).pow(2).sum() * scale
         ent_loss = self.entropy(sigma).sum() * scale
         kld_loss = 0.5 * mu.pow(2).sum() * scale / mu.shape[1]
         loss = clip_loss + self._weight_vf * vf_loss - self._weight_ent * ent_loss
@@ -252,7 +300,7 @@ class GAMMAPPOPolicy(nn.Module):
         minibatch that is not a multiple of 32 rows, an optimiser the flat AdamW kernel does not cover, ablation switches)."""
         if not (self.use_train_step and self.use_fused_loss and self.use_fused_linear and n % 32 == 0 and self.actor.z_dim == 128
                 and self._flat_opt_state == "ready" and self._flat_grad is not None and self._flat_grad.is_cuda and self._norm_adv
-                and self._chain_shapes_ok()):
+                and self._chain_shapes_ok() and not self._loss_options()):
             return None
         hs = self._train_handles.get(n)
         if hs is not None:
@@ -368,7 +416,8 @@ class GAMMAPPOPolicy(nn.Module):
             self._fwd_bwd_train_step(hs, batch, idx, gstats, log_out)
             return "chain"
         obs, act, adv, ret, lpo = self._gather(batch, idx)
-        loss, terms = self.minibatch_loss(obs, act, adv, ret, lpo, gstats)
+        v_s = batch.values[:batch.n].reshape(-1).index_select(0, idx) if self._value_clip else None
+        loss, terms = self.minibatch_loss(obs, act, adv, ret, lpo, gstats, v_s=v_s)
         self._flat_grad.zero_()
         loss.backward()
         if adv.is_cuda and self.use_fused_loss and self.use_fused_linear:
@@ -618,7 +667,13 @@ class GAMMAPPOPolicy(nn.Module):
         stats = {k: [] for k in names}
         logs = []
         use_graph = self.use_update_graph and dev.type == "cuda"
-        for _ in range(repeat):
+        for step in range(repeat):
+            if self._recompute_adv and step > 0:    # ppo_policy.py:185-186: values of ALL observations with the current weights
+                self._recomputing = True
+                try:
+                    self.process_fn(batch)
+                finally:
+                    self._recomputing = False
             perm = torch.randperm(N, generator=self._perm_gen).to(dev)
             # Batch.split(size, shuffle=True, merge_last=True)
             bounds = list(range(0, N, local_bs))

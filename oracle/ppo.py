@@ -53,16 +53,28 @@ def entropy(sigma):
     return (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(sigma)).sum(-1)
 
 
-def ppo_loss(mu, logvar, value, act, adv, returns, logp_old, eps_clip=0.1, vf_coef=1.0, ent_coef=0.01, norm_adv=True):
+def ppo_loss(mu, logvar, value, act, adv, returns, logp_old, eps_clip=0.1, vf_coef=1.0, ent_coef=0.01, norm_adv=True,
+             dual_clip=None, value_clip=False, v_s=None):
+    """ppo_policy.py:189-241; `dual_clip` :204-207, `value_clip` with the old values `v_s` :216-221 (both off in main_ppo.py)."""
     mu_, sigma = action_dist(mu, logvar)
     if norm_adv:
         adv = (adv - adv.mean()) / (adv.std() + _EPS)
     lp = log_prob(mu_, sigma, act)
-    ratio = (lp - logp_old).exp().float()
+    ratio = (lp - logp_old).exp().to(lp.dtype)   # reference: .float() - the same in fp32; a float64 evaluation stays float64
     surr1 = ratio * adv
     surr2 = ratio.clamp(1.0 - eps_clip, 1.0 + eps_clip) * adv
-    clip_loss = -torch.min(surr1, surr2).mean()
-    vf_loss = (returns - value.flatten()).pow(2).mean()
+    if dual_clip:
+        clip1 = torch.min(surr1, surr2)
+        clip2 = torch.max(clip1, dual_clip * adv)
+        clip_loss = -torch.where(adv < 0, clip2, clip1).mean()
+    else:
+        clip_loss = -torch.min(surr1, surr2).mean()
+    value = value.flatten()
+    if value_clip:
+        v_clip = v_s + (value - v_s).clamp(-eps_clip, eps_clip)
+        vf_loss = torch.max((returns - value).pow(2), (returns - v_clip).pow(2)).mean()
+    else:
+        vf_loss = (returns - value).pow(2).mean()
     ent = entropy(sigma).mean()
     loss = clip_loss + vf_coef * vf_loss - ent_coef * ent
     return loss, {"loss/clip": clip_loss, "loss/vf": vf_loss, "loss/ent": ent, "loss/kld": 0.5 * torch.mean(mu.pow(2))}

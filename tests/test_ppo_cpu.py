@@ -77,6 +77,45 @@ def test_minibatch_loss_matches_oracle_restatement():
         assert abs(float(terms[k]) - float(rterms[k])) <= 1e-5 * max(1.0, abs(float(rterms[k]))), k
 
 
+@pytest.mark.parametrize("dual_clip,value_clip", [(2.0, False), (None, True), (3.0, True)])
+def test_minibatch_loss_options_match_oracle_restatement(dual_clip, value_clip):
+    """--dual-clip / --value-clip of main_ppo.py (ppo_policy.py:204-207, 216-221): the policy's loss against the oracle's
+    restatement, on data where both clips bite (ratios far from 1, values far from the old values)."""
+    pol = _policy()
+    pol._dual_clip, pol._value_clip = dual_clip, value_clip
+    b = RolloutBatch(2, 8, "cpu")
+    _fill(b, 5)
+    _set_logp(pol, b, 6)
+    b.logp_old.add_(torch.randn(b.logp_old.shape, generator=torch.Generator().manual_seed(1)) * 0.5)   # ratios 0.3 .. 3
+    obs, N = b.obs_flat(), 16
+    v_s = torch.randn(N, generator=torch.Generator().manual_seed(2))
+    args = (b.act.reshape(N, 128), b.adv.reshape(N), b.returns.reshape(N), b.logp_old.reshape(N))
+    loss, terms = pol.minibatch_loss(obs, *args, v_s=v_s)
+    hx = pol.shared_net(obs)
+    (mu, lv), _ = pol.actor(hx)
+    ref, rterms = oppo.ppo_loss(mu, lv, pol.critic(hx), *args, dual_clip=dual_clip, value_clip=value_clip, v_s=v_s)
+    plain, _ = oppo.ppo_loss(mu, lv, pol.critic(hx), *args)
+    assert abs(float(ref) - float(plain)) > 1e-3, "the options must change the loss on this data"
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    for k in ("loss/clip", "loss/vf", "loss/ent", "loss/kld"):
+        assert abs(float(terms[k]) - float(rterms[k])) <= 1e-5 * max(1.0, abs(float(rterms[k]))), k
+    if value_clip:
+        with pytest.raises(ValueError):
+            pol.minibatch_loss(obs, *args)
+
+
+def test_running_mean_std_matches_a_single_pass():
+    """`ret_rms` of --rew-norm (tianshou RunningMeanStd [upstream]): batch-wise merging equals mean / variance of everything seen."""
+    from egogen_amd.ppo_policy import RunningMeanStd
+    rng = np.random.default_rng(0)
+    chunks = [rng.normal(3.0, 2.0, n) for n in (7, 100, 1, 33)]
+    r = RunningMeanStd()
+    for c in chunks:
+        r.update(c)
+    allx = np.concatenate(chunks)
+    assert r.count == allx.size and abs(r.mean - allx.mean()) < 1e-12 and abs(r.var - allx.var()) < 1e-12
+
+
 def test_grad_clip_covers_actor_and_critic_only():
     """clip_grad_norm_(max 0.1) sees actor+critic, NOT shared_net."""
     pol = _policy()

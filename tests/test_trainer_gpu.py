@@ -690,6 +690,37 @@ def test_learn_matches_oracle_fp64_parameters():
     assert frac["bf16"][1] <= 0.5, frac
 
 
+def test_ppo_options_of_main_ppo_run_through_the_policy():
+    """--rew-norm / --value-clip / --dual-clip / --recompute-adv (main_ppo.py:54-67 -> ppo_policy.py:80-86,118-135,185-186,
+    204-221): accepted like the reference class accepts them; the loss options route the minibatch through the torch expression
+    (the hand-written chain implements the default loss only), reward normalisation rescales the critic's values for the GAE
+    scan and the returns by the running standard deviation of the un-normalised returns."""
+    from egogen_amd import setup_world as sw
+    from oracle import ppo as oppo
+
+    class A(_Args):
+        rew_norm = True; value_clip = 1; dual_clip = 2.0; recompute_adv = 1
+        update_graph = False
+    pol = sw.build_policy(A())
+    assert pol._rew_norm and pol._value_clip and pol._dual_clip == 2.0 and pol._recompute_adv
+    b = _filled_batch(3, 32, 9, pol)
+    b.term.copy_((torch.rand(3, 32, generator=torch.Generator().manual_seed(1)) < 0.2).int())
+    b.rew.copy_(torch.randn(3, 32, generator=torch.Generator().manual_seed(2)))
+    pol.ret_rms.update(np.array([0.0, 4.0, -4.0, 8.0]))          # some history: var = 19
+    var0 = pol.ret_rms.var
+    pol.process_fn(b)
+    v = b.values.cpu().double().numpy() * np.sqrt(var0 + np.finfo(np.float32).eps)
+    ret, adv = oppo.gae_returns(v[:3].T, v[1:].T, b.rew.cpu().numpy().T, b.term.cpu().numpy().T.astype(bool), np.zeros((32, 3), bool), 0.99, 0.95)
+    np.testing.assert_allclose(b.adv.cpu().numpy().T, adv, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b.returns.cpu().numpy().T, ret / np.sqrt(var0 + np.finfo(np.float32).eps), rtol=1e-5, atol=1e-5)
+    assert pol.ret_rms.count == 4 + 96 and pol.ret_rms.var != var0
+    before = torch.cat([q.detach().flatten() for q in pol.parameters()]).clone()
+    out = pol.learn(b, 32, 2)                                      # repeat 2: the second pass recomputes the advantages
+    assert len(out["loss"]) in (3, 6) and np.isfinite(out["loss"]).all()
+    assert set(pol.update_paths) == {"autograd"} and not pol._train_handles, pol.update_paths
+    assert float((torch.cat([q.detach().flatten() for q in pol.parameters()]) - before).abs().max()) > 0
+
+
 def test_merged_last_minibatch_reads_current_weight_images():
     """Batch.split(merge_last=True): 160 transitions at batch size 64 = minibatches of 64 and 96 rows -> TWO train handles, the
     second created after the graphs of the first size were captured.  A captured (clip + AdamW + image refresh) graph refreshes
