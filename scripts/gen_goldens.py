@@ -14,6 +14,8 @@ imported, never called, on these code paths - SURVEY.md section 8(c)):
   crowd_ppo/crowd_env_2f_box.py::CrowdEnv._get_feature (with the walkability map) and
   exp_GAMMAPrimitive/utils/batch_gen_amass.py::get_map                   -> getmap_ref.npz
   crowd_ppo/utils.py::save_rollout_results                               -> rollout_ref.npz + rollout_ref.pkl
+  experiments/HOOD/utils/lbs.py::pose_garment (`python scripts/gen_goldens.py lbs_skin`) -> lbs_skin_ref.npz (pose correctives +
+      skinning of the SMPL-X oracle against in-tree code; its Rodrigues formula and rigid chain stay restated)
   experiments/HMR/prohmr/utils/konia_transform.py::rotation_matrix_to_angle_axis (`python scripts/gen_goldens.py rot2aa`)
       -> rot2aa_ref.npz (value-level pin of the oracle's torchgeometry R -> axis-angle restatement)
   exp_GAMMAPrimitive/utils/utils_canonicalize_samp.py::canonicalize_subsequence (`python scripts/gen_goldens.py canonicalize`)
@@ -567,7 +569,52 @@ def gen_rot2aa():
     np.savez_compressed(os.path.join(OUT, "rot2aa_ref.npz"), R=R.numpy(), aa_out=out.numpy(), aa_in=aa.numpy(), branch=branch.numpy())
 
 
+def gen_lbs_skin():
+    """Pose correctives + linear blend skinning: the reference tree's own restatement, experiments/HOOD/utils/lbs.py::pose_garment
+    (:85-124: pose_feature = (R[:, 1:] - I) flattened, pose_offsets = pose_feature @ posedirs, T = W @ A, homogeneous apply), run
+    on a small synthetic SMPL-X-shaped model -> lbs_skin_ref.npz.  The file imports blend_shapes / vertices2joints /
+    batch_rodrigues / batch_rigid_transform from the absent pip package smplx; `pose_garment` itself only calls batch_rodrigues,
+    which is supplied by oracle.rot (the others are stand-ins that are never called).  Joint transforms A and the shaped
+    template come from oracle.smplx_lbs - so the fixture pins the oracle's pose-feature layout, corrective product and skinning
+    against in-tree code, NOT its Rodrigues formula or rigid chain (those stay restated from smplx 0.1.28)."""
+    import importlib.util
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from egogen_amd import synth
+    from oracle import rot as orot
+    from oracle.smplx_lbs import BodyModel, smplx_forward
+    never = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("stand-in must not be called"))
+    lbs_stub = _stub("smplx.lbs", blend_shapes=never, vertices2joints=never, batch_rigid_transform=never,
+                     batch_rodrigues=lambda aa: orot.smplx_batch_rodrigues(aa))
+    sm = _stub("smplx", lbs=lbs_stub)
+    sm.utils = _stub("smplx.utils", Tensor=torch.Tensor)
+    spec = importlib.util.spec_from_file_location("hood_lbs", os.path.join(REF, "..", "experiments", "HOOD", "utils", "lbs.py"))
+    hood = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hood)
+    V, B = 192, 5
+    bm = synth.make_body_model(3, num_verts=V)
+    ob = BodyModel(bm)
+    g = torch.Generator().manual_seed(31)
+    xb = torch.zeros(B, 93)
+    xb[:, 3:6] = torch.randn(B, 3, generator=g) * 0.8
+    xb[:, 6:69] = torch.randn(B, 63, generator=g) * 0.4
+    xb[:, 69:] = torch.randn(B, 24, generator=g) * 0.5
+    betas = torch.randn(B, 10, generator=g)
+    verts, joints, mid = smplx_forward(ob, xb, betas, return_intermediate=True)
+    # the full 165-vector pose smplx would see (hand PCA expanded, jaw / eyes zero), as oracle.smplx_lbs assembles it
+    lh = torch.einsum("bi,ij->bj", xb[:, 69:81], ob.hand_comps_l) + ob.hand_mean_l
+    rh = torch.einsum("bi,ij->bj", xb[:, 81:93], ob.hand_comps_r) + ob.hand_mean_r
+    full_pose = torch.cat([xb[:, 3:6], xb[:, 6:69], torch.zeros(B, 9), lh, rh], dim=1)
+    ref_verts, _ = hood.pose_garment(betas, full_pose, mid["v_shaped"], ob.shapedirs, ob.posedirs, ob.lbs_weights,
+                                     joints[:, :55], mid["A"], pose2rot=True, A_POSE=torch.zeros(B, 165),
+                                     A_joint_transforms=torch.eye(4).repeat(B, 55, 1, 1))
+    print("lbs_skin_ref", ref_verts.shape, "max |hood - oracle|", float((ref_verts - verts).abs().max()))
+    np.savez_compressed(os.path.join(OUT, "lbs_skin_ref.npz"), body_seed=3, num_verts=V, xb=xb.numpy(), betas=betas.numpy(),
+                        verts=ref_verts.numpy())
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["lbs_skin"]:
+        sys.exit(gen_lbs_skin())
     if sys.argv[1:] == ["rot2aa"]:
         sys.exit(gen_rot2aa())
     if sys.argv[1:] == ["canonicalize"]:

@@ -63,6 +63,22 @@ def test_lbs_matches_oracle(V, A, T, blend_mode):
         assert max_abs(out2["markers"].cpu(), out["markers"].cpu()) < 3e-6
 
 
+def test_lbs_vertices_match_in_tree_skinning_golden(blend_mode):
+    """The HIP kernels against tests/golden/lbs_skin_ref.npz = vertices produced by the reference tree's own skinning
+    restatement (experiments/HOOD/utils/lbs.py::pose_garment) - not by the oracle."""
+    from egogen_amd.body_model import BodyModelHandle
+    g = load_golden("lbs_skin_ref.npz")
+    V = int(g["num_verts"])
+    bm = synth.make_body_model(int(g["body_seed"]), num_verts=V)
+    h = BodyModelHandle(bm, synth.marker_ids(V), synth.feet_vids(V))
+    xb, betas = torch.from_numpy(g["xb"]).cuda(), torch.from_numpy(g["betas"]).cuda()
+    out = h.forward(xb, betas, 1, want_verts=True)
+    assert max_abs(out["vertices"].cpu(), g["verts"]) < 2e-5
+    mk = torch.as_tensor(synth.marker_ids(V)).long()
+    picks = h.forward(xb, betas, 1)      # the hot path (selected blend mode): markers are rows of the same vertices
+    assert max_abs(picks["markers"].cpu(), g["verts"][:, mk.numpy()]) < 2e-5
+
+
 @pytest.mark.parametrize("A,T", [(1, 1), (257, 1), (105, 20)])
 def test_lbs_ragged_batches(A, T, blend_mode):
     """Single body, one body past a 256-body group, and 2100 bodies (>= 8 body groups: the XCD-partitioned item list with

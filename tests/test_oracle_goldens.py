@@ -95,6 +95,19 @@ def test_rotation_matrix_to_angle_axis_matches_in_tree_copy_values():
     assert np.abs(out64 - g["aa_in"]).max() < 3e-6
 
 
+def test_smplx_skinning_matches_in_tree_restatement():
+    """oracle.smplx_lbs: pose-feature layout, pose-corrective product and linear blend skinning against the reference tree's
+    own restatement of that tail, experiments/HOOD/utils/lbs.py::pose_garment (:85-124), run on the oracle's joint transforms
+    (scripts/gen_goldens.py lbs_skin).  What stays restated from smplx 0.1.28: batch_rodrigues, batch_rigid_transform, the
+    landmark path."""
+    from egogen_amd import synth
+    from oracle.smplx_lbs import BodyModel, smplx_forward
+    g = load_golden("lbs_skin_ref.npz")
+    ob = BodyModel(synth.make_body_model(int(g["body_seed"]), num_verts=int(g["num_verts"])))
+    verts, _ = smplx_forward(ob, torch.from_numpy(g["xb"]), torch.from_numpy(g["betas"]))
+    assert max_abs(verts.numpy(), g["verts"]) == 0.0
+
+
 def test_get_feature_and_blend_params_match_reference():
     """oracle.env.get_feature / blend_params against crowd_env_2f.CrowdEnv._get_feature / _blend_params run unbound
     (scripts/gen_goldens.py); the fixture holds a marker and a pelvis exactly on the target (the clip(min=1e-12) branch)."""
