@@ -95,6 +95,28 @@ def test_rotation_matrix_to_angle_axis_matches_in_tree_copy_values():
     assert np.abs(out64 - g["aa_in"]).max() < 3e-6
 
 
+def test_other_rotation_restatements_agree_with_in_tree_values():
+    """smplx's batch_rodrigues (angle = ||aa + 1e-8||, full Rodrigues formula) and pytorch3d's axis_angle_to_matrix /
+    matrix_to_axis_angle (through quaternions) are restated from packages that are absent; each computes the same mathematical
+    function as the reference tree's kornia-derived pair (experiments/HMR/prohmr/utils/konia_transform.py), whose VALUES the
+    fixtures aa2rot_ref.npz / rot2aa_ref.npz hold (angles from 1e-5 to 3 rad; the small-angle branches differ by O(theta^2)
+    <= 1e-10 where they apply)."""
+    from oracle import rot
+    g = load_golden("aa2rot_ref.npz")
+    aa = torch.from_numpy(g["aa"])
+    # the kornia copy divides by (theta + 1e-6): 1e-6 off the exact matrix around theta ~ 1e-3, which bounds the agreement
+    assert max_abs(rot.smplx_batch_rodrigues(aa).numpy(), g["R"]) < 2e-6
+    assert max_abs(rot.p3d_axis_angle_to_matrix(aa).numpy(), g["R"]) < 2e-6
+    g2 = load_golden("rot2aa_ref.npz")
+    # pytorch3d 0.7.4 does not standardise the quaternion's sign: where the selected candidate has a negative real part the
+    # rotation vector comes out with an angle in (pi, 2 pi) - the same rotation, another representative - so the comparison is
+    # between the rotations, not the vectors
+    out = rot.p3d_matrix_to_axis_angle(torch.from_numpy(g2["R"]))
+    Ra, Rb = rot.p3d_axis_angle_to_matrix(out), rot.p3d_axis_angle_to_matrix(torch.from_numpy(g2["aa_out"]))
+    assert max_abs(Ra.numpy(), Rb.numpy()) < 2e-6
+    assert max_abs(Ra.numpy(), g2["R"]) < 2e-6
+
+
 def test_smplx_skinning_matches_in_tree_restatement():
     """oracle.smplx_lbs: pose-feature layout, pose-corrective product and linear blend skinning against the reference tree's
     own restatement of that tail, experiments/HOOD/utils/lbs.py::pose_garment (:85-124), run on the oracle's joint transforms
