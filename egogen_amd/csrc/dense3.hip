@@ -358,32 +358,32 @@ struct D3Gru2 {
   int blocks0;   // blocks [0, blocks0) work on g0, the rest on g1 (the policy's two encoders)
 };
 template <int TRIP, int NPL>
-__global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
+__global__ __launch_bounds__(512) void egx_gru3_kernel(D3Gru2 two) {
+  // eight waves: waves 0-3 split the reduction of the x side (x W_ih^T), waves 4-7 that of the h side (h W_hh^T) - the two
+  // products are independent, so their operand bursts are in flight together and a cell whose sides are each <= 4 TRIP
+  // k-steps deep (the decoder cell: 8 + 8) is ONE memory round trip instead of two
   const bool second = (int)blockIdx.x >= two.blocks0;
   const D3Gru& a = second ? two.g1 : two.g0;
   const int gru_bid = second ? (int)blockIdx.x - two.blocks0 : (int)blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) float gsm[];
-  float* red = gsm;                  // [4 waves][48][64]
-  float* tile = gsm + 4 * 48 * 64;   // [32][20]: h of this workgroup's 32 x 16 block
+  float* red = gsm;                  // [8 waves][24][64]
+  float* tile = gsm + 8 * 24 * 64;   // [32][20]: h of this workgroup's 32 x 16 block
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int MT = (a.M + 31) >> 5, CT = a.H >> 4;
   int mt, ct;
   if (!d3_tile(gru_bid, MT, CT, mt, ct)) return;
-  f32x4 acc[2][2][3];   // [side][row half][gate]
+  const int sd = wave >> 2, w4 = wave & 3;
+  f32x4 acc[2][3];   // [row half][gate] of this wave's side
 #pragma unroll
-  for (int sd = 0; sd < 2; ++sd)
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int g = 0; g < 3; ++g) acc[sd][mi][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int sd = 0; sd < 2; ++sd) {
+    for (int g = 0; g < 3; ++g) acc[mi][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
     const bf16x8* A = sd ? a.Ah : a.Ai;
-    if (!A) continue;
     const bf16x8* B = sd ? a.Bh : a.Bi;
-    const int S = sd ? a.Sh : a.Si, SA = sd ? a.SAh : a.SAi, sa0 = sd ? a.sah0 : a.sai0;
+    const int S = A ? (sd ? a.Sh : a.Si) : 0, SA = sd ? a.SAh : a.SAi, sa0 = sd ? a.sah0 : a.sai0;
     const int per = (S + 3) >> 2;
-    const int s_lo = wave * per, s_hi = min(S, s_lo + per);
+    const int s_lo = w4 * per, s_hi = min(S, s_lo + per);
     const bf16x8* pa[2];
     const bf16x8* pb[3];
 #pragma unroll
@@ -409,58 +409,51 @@ __global__ __launch_bounds__(256) void egx_gru3_kernel(D3Gru2 two) {
 #pragma unroll
       for (int u = 0; u < TRIP; ++u) {
         if (s + u >= s_hi) break;
-        d3_mma_tiles<2, 3, NPL>(fa[u], fb[u], acc[sd]);
+        d3_mma_tiles<2, 3, NPL>(fa[u], fb[u], acc);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
-  for (int sd = 0; sd < 2; ++sd)
+  for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[(wave * 48 + ((sd * 3 + g) * 2 + mi) * 4 + r) * 64 + lane] = acc[sd][mi][g][r];
+      for (int r = 0; r < 4; ++r) red[(wave * 24 + (g * 2 + mi) * 4 + r) * 64 + lane] = acc[mi][g][r];
   __syncthreads();
-  // wave w finishes positions (mi, r) = (w >> 1, 2 (w & 1) + {0, 1}) of every lane: all six gate values of an element in
-  // one thread
+  // wave w finishes position (mi, r) = (w >> 2, w & 3) of every lane: all six gate values of an element in one thread
   {
-    const int mi = wave >> 1;
+    const int mi = wave >> 2, r = wave & 3;
     const int col = lane & 15, c = ct * 16 + col;
+    const int row = 16 * mi + 4 * (lane >> 4) + r, m = mt * 32 + row;
+    float gv[2][3];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int r = 2 * (wave & 1) + rr;
-      const int row = 16 * mi + 4 * (lane >> 4) + r, m = mt * 32 + row;
-      float gv[2][3];
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int sd = 0; sd < 2; ++sd)
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const int q = ((sd * 3 + g) * 2 + mi) * 4 + r;
-          gv[sd][g] = ((red[(0 * 48 + q) * 64 + lane] + red[(1 * 48 + q) * 64 + lane]) + red[(2 * 48 + q) * 64 + lane]) +
-                      red[(3 * 48 + q) * 64 + lane];
-        }
-      float hv = 0.f;
-      if (m < a.M) {
-        float gi[3], gh[3];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const int n = g * a.H + c;
-          gi[g] = (a.gi_in ? a.gi_in[(size_t)m * 3 * a.H + n] : 0.f) + gv[0][g] + (a.bias_i ? a.bias_i[n] : 0.f);
-          gh[g] = gv[1][g] + a.bias_h[n];
-          if (a.gi_out) a.gi_out[(size_t)m * 3 * a.H + n] = gi[g];
-          if (a.gh_out) a.gh_out[(size_t)m * 3 * a.H + n] = gh[g];
-        }
-        const float rg = 1.f / (1.f + expf(-(gi[0] + gh[0])));
-        const float zg = 1.f / (1.f + expf(-(gi[1] + gh[1])));
-        const float ng = tanhf(gi[2] + rg * gh[2]);
-        const float hp = a.h_prev ? a.h_prev[(size_t)m * a.ldh + c] : 0.f;
-        hv = (1.f - zg) * ng + zg * hp;
-        if (a.h_out) a.h_out[(size_t)m * a.ldo + c] = hv;
+      for (int g = 0; g < 3; ++g) {
+        const int q = (g * 2 + mi) * 4 + r;
+        gv[s2][g] = ((red[((s2 * 4 + 0) * 24 + q) * 64 + lane] + red[((s2 * 4 + 1) * 24 + q) * 64 + lane]) +
+                     red[((s2 * 4 + 2) * 24 + q) * 64 + lane]) + red[((s2 * 4 + 3) * 24 + q) * 64 + lane];
       }
-      tile[row * 20 + col] = hv;
+    float hv = 0.f;
+    if (m < a.M) {
+      float gi[3], gh[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const int n = g * a.H + c;
+        gi[g] = (a.gi_in ? a.gi_in[(size_t)m * 3 * a.H + n] : 0.f) + gv[0][g] + (a.bias_i ? a.bias_i[n] : 0.f);
+        gh[g] = gv[1][g] + a.bias_h[n];
+        if (a.gi_out) a.gi_out[(size_t)m * 3 * a.H + n] = gi[g];
+        if (a.gh_out) a.gh_out[(size_t)m * 3 * a.H + n] = gh[g];
+      }
+      const float rg = 1.f / (1.f + expf(-(gi[0] + gh[0])));
+      const float zg = 1.f / (1.f + expf(-(gi[1] + gh[1])));
+      const float ng = tanhf(gi[2] + rg * gh[2]);
+      const float hp = a.h_prev ? a.h_prev[(size_t)m * a.ldh + c] : 0.f;
+      hv = (1.f - zg) * ng + zg * hp;
+      if (a.h_out) a.h_out[(size_t)m * a.ldo + c] = hv;
     }
+    tile[row * 20 + col] = hv;
   }
   if (a.h_out3 || a.h_out3T) __syncthreads();
   if (a.h_out3T && wave == 2) {
@@ -867,15 +860,15 @@ void egx_launch_dense3_triple(hipStream_t st, const D3Plain& p, const D3Plain& q
   egx_launch_dense3_n(st, ps, 3);
 }
 static void d3_launch_gru(hipStream_t st, const D3Gru& g0, const D3Gru* g1) {
-  constexpr size_t lds = (size_t)(4 * 48 * 64 + 32 * 20) * sizeof(float);   // 50.5 KiB: within the default dynamic-LDS cap
+  constexpr size_t lds = (size_t)(8 * 24 * 64 + 32 * 20) * sizeof(float);   // 50.5 KiB: within the default dynamic-LDS cap
   D3Gru2 two;
   two.g0 = g0; two.g1 = g1 ? *g1 : g0;
   two.blocks0 = d3_blocks((g0.M + 31) >> 5, g0.H >> 4);
   const int total = two.blocks0 + (g1 ? d3_blocks((g1->M + 31) >> 5, g1->H >> 4) : 0);
   switch (g0.prec) {
-    case 2: hipLaunchKernelGGL((egx_gru3_kernel<2, 2>), dim3(total), dim3(256), lds, st, two); break;
-    case 1: hipLaunchKernelGGL((egx_gru3_kernel<4, 1>), dim3(total), dim3(256), lds, st, two); break;
-    default: hipLaunchKernelGGL((egx_gru3_kernel<2, 3>), dim3(total), dim3(256), lds, st, two);
+    case 2: hipLaunchKernelGGL((egx_gru3_kernel<2, 2>), dim3(total), dim3(512), lds, st, two); break;
+    case 1: hipLaunchKernelGGL((egx_gru3_kernel<4, 1>), dim3(total), dim3(512), lds, st, two); break;
+    default: hipLaunchKernelGGL((egx_gru3_kernel<2, 3>), dim3(total), dim3(512), lds, st, two);
   }
 }
 int egx_launch_gru3(hipStream_t st, const D3Gru& g) {
