@@ -96,14 +96,27 @@ __device__ __forceinline__ float d3_act_grad(float a, int act, float slope) {
 
 // XCD-aware tile map (blocks are dealt round-robin to the 8 XCDs, each with a private L2): every XCD owns a contiguous chunk
 // of column tiles - i.e. of the weights - and sweeps the row tiles.
-__device__ __forceinline__ bool d3_tile(int bid, int MT, int NT, int& mt, int& nt) {
+// With rowmap every XCD owns a chunk of ROW tiles - of the activations - and sweeps the weights instead.  An XCD's L2 is filled
+// with all of the operand it sweeps and an eighth of the one it owns, so the map follows the larger operand: rows when M >= N
+// (the decoder's 512-row layers: 8.1 -> 6.9 us), columns otherwise (the policy's 256 x 1152 layers: 18.4 against 19.8 us with
+// rows).  mode < 0: that rule; 0 / 1: columns / rows always (EGX_D3_ROWMAP, development).
+__host__ __device__ inline int d3_rowmap(int mode, int M, int N) { return mode < 0 ? (M >= N ? 1 : 0) : mode; }
+__device__ __forceinline__ bool d3_tile(int bid, int MT, int NT, int& mt, int& nt, int rowmap = 0) {
   const int xcd = bid & 7, local = bid >> 3;
+  if (rowmap) {
+    const int per = (MT + 7) >> 3;
+    mt = xcd * per + local / NT;
+    nt = local % NT;
+    return local < per * NT && mt < MT;
+  }
   const int per = (NT + 7) >> 3;
   nt = xcd * per + local / MT;
   mt = local % MT;
   return local < per * MT && nt < NT;
 }
-__host__ __device__ inline int d3_blocks(int MT, int NT) { return 8 * ((NT + 7) / 8) * MT; }
+__host__ __device__ inline int d3_blocks(int MT, int NT, int rowmap = 0) {
+  return rowmap ? 8 * ((MT + 7) / 8) * NT : 8 * ((NT + 7) / 8) * MT;
+}
 
 }  // namespace
 
@@ -232,6 +245,7 @@ __device__ __forceinline__ void d3_write_packed(const D3Plain& a, const float* t
 struct D3Args4 {
   D3Plain p0, p1, p2, p3;
   int end0, end1, end2;   // blocks [0, end0) work on p0, [end0, end1) on p1, [end1, end2) on p2, the rest on p3
+  int rowmap;
 };
 
 // The layer a block works on.  Picking one of the four structs by reference (`which == 0 ? four.p0 : ...`) makes the
@@ -268,10 +282,11 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
   float* tile = d3_smem + NW * NACC * 64;    // [TM][PITCH]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int MT = (a.M + TM - 1) / TM, NT = (a.N + TN - 1) / TN;
-  const int per_batch = d3_blocks(MT, NT);
+  const int rowmap = d3_rowmap(four.rowmap, a.M, a.N);
+  const int per_batch = d3_blocks(MT, NT, rowmap);
   const int batch = bid / per_batch;
   int mt, nt;
-  if (!d3_tile(bid - batch * per_batch, MT, NT, mt, nt)) return;
+  if (!d3_tile(bid - batch * per_batch, MT, NT, mt, nt, rowmap)) return;
   const bf16x8* Ab = a.A + (size_t)batch * a.batch_strideA;
   const int per = (a.S + NW - 1) / NW;
   const int s_lo = wave * per, s_hi = min(a.S, s_lo + per);
@@ -308,10 +323,8 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < TRIP; ++u) {
-      if (s + u >= s_hi) break;
-      d3_mma_tiles<MI, NI, NPL>(fa[u], fb[u], acc);
-    }
+    for (int u = 0; u < TRIP; ++u)
+      if (s + u < s_hi) d3_mma_tiles<MI, NI, NPL>(fa[u], fb[u], acc);
     __builtin_amdgcn_sched_barrier(0);
   }
   // split-K reduction through LDS; wave w then finishes MFMA tiles w, w + NW, ...: bias, activation, residual
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
 #pragma unroll
   for (int t0 = 0; t0 < MI * NI; t0 += NW) {
     const int t = t0 + wave;
-    if (t >= MI * NI) break;
+    if (t >= MI * NI) continue;
     const int mi = t / NI, ni = t % NI;
     const int col = 16 * ni + (lane & 15), n = nt * TN + col;
     const float bsv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
@@ -356,6 +369,7 @@ __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
 struct D3Gru2 {
   D3Gru g0, g1;
   int blocks0;   // blocks [0, blocks0) work on g0, the rest on g1 (the policy's two encoders)
+  int rowmap;
 };
 template <int TRIP, int NPL>
 __global__ __launch_bounds__(512) void egx_gru3_kernel(D3Gru2 two) {
@@ -371,7 +385,7 @@ __global__ __launch_bounds__(512) void egx_gru3_kernel(D3Gru2 two) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int MT = (a.M + 31) >> 5, CT = a.H >> 4;
   int mt, ct;
-  if (!d3_tile(gru_bid, MT, CT, mt, ct)) return;
+  if (!d3_tile(gru_bid, MT, CT, mt, ct, d3_rowmap(two.rowmap, a.M, 3 * a.H))) return;
   const int sd = wave >> 2, w4 = wave & 3;
   f32x4 acc[2][3];   // [row half][gate] of this wave's side
 #pragma unroll
@@ -549,8 +563,13 @@ void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, in
 //   * 48 rows: 18 x 512 = 9216 rows give 192 workgroups, one per CU and all equally loaded (the fp32 kernel's 288 32-row
 //     workgroups put two on 32 of the 256 CUs, which then set the launch time);
 //   * eight waves, wave w owns output columns 16 w .. 16 w + 15 of every 128-wide layer for all three 16-row tiles; the
-//     activations live in LDS as packed planes (A-operand fragments), written by the producing layer's epilogue through a
-//     wave-private transposition strip; the residual stream h stays in registers (a lane owns the same elements in every layer);
+//     activations live in LDS as packed planes (operand fragments: 16 rows x 32 reduction indices, eight consecutive indices per
+//     lane).  Every product is taken TRANSPOSED, out^T = W act^T (the weight fragment is the MFMA's first operand, the
+//     activation fragment its second): a lane's four accumulator registers are then FOUR CONSECUTIVE COLUMNS of ONE row - half
+//     of the eight-index group of a fragment lane of the next layer - so the epilogue splits its own values and stores them
+//     with one 8-byte LDS write per plane and row tile: no transposition buffer, no cross-lane traffic, all 64 lanes at work
+//     (the row-major form needed a strip round trip through LDS and split on half the lanes);
+//   * the residual stream h stays in registers (a lane owns the same elements in every layer);
 //   * in_fc([markers | xb | betas]) = W_m markers + W_b betas + b (the same in all three recurrences: computed once, kept
 //     in registers) + W_xb xb (159 of the 370 columns, zero in the first recurrence);
 //   * weights are read from packed images (one contiguous KiB per fragment), the next layer's prefetched under the epilogue.
@@ -558,8 +577,7 @@ void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, in
 namespace {
 constexpr int R3_ROWS = 48, R3_XBP = 164, R3_NOUT = 159;
 constexpr int R3_ACT_FRAGS = 3 * 4 * 3 * 64;            // one 48 x 128 activation buffer, in bf16x8 fragments-lanes
-constexpr int R3_STRIP = R3_ROWS * 20;                  // floats per wave: 48 rows x 16 columns, pitch 20
-constexpr size_t R3_LDS = (size_t)R3_ROWS * R3_XBP * 4 + 2 * (size_t)R3_ACT_FRAGS * 16 + 8 * (size_t)R3_STRIP * 4;
+constexpr size_t R3_LDS = (size_t)R3_ROWS * R3_XBP * 4 + 2 * (size_t)R3_ACT_FRAGS * 16;   // 102.75 KiB
 
 // this wave's weight fragments of one 128-deep layer: column tile `tile`, 4 k-steps x 3 planes
 __device__ __forceinline__ void r3_load_w(const bf16x8* P, int tile, int S, int lane, bf16x8 (&wf)[4][3]) {
@@ -569,14 +587,15 @@ __device__ __forceinline__ void r3_load_w(const bf16x8* P, int tile, int S, int 
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) wf[s][pl] = p[(s * 3 + pl) * 64];
 }
-// acc[rt] += a[rt] . w for the three row tiles, product-major (no MFMA waits for the previous one's result)
+// acc[rt] += (a[rt] . w)^T for the three row tiles, product-major (no MFMA waits for the previous one's result): lane
+// (m = lane & 15, g = lane >> 4) holds row 16 rt + m, columns 4 g .. 4 g + 3 of the wave's 16-column tile
 __device__ __forceinline__ void r3_mma3(const bf16x8 (&a)[3][3], const bf16x8 (&wf)[3], f32x4 (&acc)[3]) {
 #pragma unroll
   for (int pr = 0; pr < 6; ++pr) {
     const int pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
     const int pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][pa], wf[pb], acc[rt], 0, 0, 0);
+    for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[pb], a[rt][pa], acc[rt], 0, 0, 0);
   }
 }
 // acc[rt] += act(48 x 128, packed in LDS) . w^T for the wave's 16 columns
@@ -591,44 +610,41 @@ __device__ __forceinline__ void r3_mma128(const bf16x8* act, int lane, const bf1
     r3_mma3(a, wf[s], acc);
   }
 }
-// v[rt][r] (C layout: column lane & 15 of the wave's tile, rows 16 rt + 4 (lane >> 4) + r) -> packed planes of k-group pair
-// (wave & 1) of k-step wave >> 1 of `dst`, through the wave's transposition strip
-__device__ __forceinline__ void r3_store_packed(const float (&v)[3][4], float* strip, bf16x8* dst, int wave, int lane) {
+// v[rt][r] = element (row 16 rt + (lane & 15), column 16 wave + 4 (lane >> 4) + r) -> the packed planes of `dst`: k-step
+// wave >> 1, fragment lane 16 (2 (wave & 1) + (g >> 1)) + m, elements 4 (g & 1) .. + 3 of its eight
+__device__ __forceinline__ void r3_store_packed(const float (&v)[3][4], bf16x8* dst, int wave, int lane) {
+  typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+  const int g = lane >> 4;
+  char* o = reinterpret_cast<char*>(dst + (size_t)((wave >> 1) * 3) * 64 + 16 * (2 * (wave & 1) + (g >> 1)) + (lane & 15)) + 8 * (g & 1);
 #pragma unroll
-  for (int rt = 0; rt < 3; ++rt)
+  for (int rt = 0; rt < 3; ++rt) {
+    float r[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) strip[(16 * rt + 4 * (lane >> 4) + r) * 20 + (lane & 15)] = v[rt][r];
-  __builtin_amdgcn_wave_barrier();
-  if (lane < 32) {
-    const int kg = lane >> 4;
+    for (int p = 0; p < 3; ++p) {
+      bf16v4 h;
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) {
-      const float* sp = strip + (16 * rt + (lane & 15)) * 20 + 8 * kg;
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(sp), x1 = *reinterpret_cast<const f32x4*>(sp + 4);
-      const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      bf16x8 pl[3];
-      d3_split(x, pl);
-      bf16x8* o = dst + ((rt * 4 + (wave >> 1)) * 3) * 64 + 32 * (wave & 1) + lane;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
+      for (int e = 0; e < 4; ++e) {
+        const float x = (p == 0) ? v[rt][e] : r[e];
+        h[e] = (__bf16)x;
+        r[e] = x - (float)h[e];
+      }
+      *reinterpret_cast<bf16v4*>(o + (size_t)((rt * 4) * 3 + p) * 64 * sizeof(bf16x8)) = h;
     }
   }
-  __builtin_amdgcn_wave_barrier();
 }
 }  // namespace
 
-__global__ __launch_bounds__(512, 2) void egx_regressor3_kernel(RegWeights3 w, const float* __restrict__ Y,
+template <bool EARLY>
+__global__ __launch_bounds__(512) void egx_regressor3_kernel(RegWeights3 w, const float* __restrict__ Y,
                                                                 const float* __restrict__ betas, int A, int M,
                                                                 float* __restrict__ out_Yb) {
   extern __shared__ __attribute__((aligned(16))) char r3_smem[];
   float* xb = reinterpret_cast<float*>(r3_smem);                                      // [48][164] fp32: the running 6D parameters
   bf16x8* hb3 = reinterpret_cast<bf16x8*>(r3_smem + (size_t)R3_ROWS * R3_XBP * 4);    // packed h (also: scratch of the prologue)
   bf16x8* tb3 = hb3 + R3_ACT_FRAGS;                                                   // packed t
-  float* strips = reinterpret_cast<float*>(tb3 + R3_ACT_FRAGS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* strip = strips + wave * R3_STRIP;
   const int m0 = blockIdx.x * R3_ROWS;
-  const int col = 16 * wave + (lane & 15);   // this lane's output column in every 128-wide layer
+  const int col4 = 16 * wave + 4 * (lane >> 4);   // this lane's four output columns in every 128-wide layer
   for (int i = tid; i < R3_ROWS * R3_XBP; i += 512) xb[i] = 0.f;
   // ---- prologue: [markers | betas] as packed planes in the (still unused) activation region: 3 row tiles x (7 + 1) k-steps
   bf16x8* in3 = hb3;
@@ -649,9 +665,9 @@ __global__ __launch_bounds__(512, 2) void egx_regressor3_kernel(RegWeights3 w, c
   __syncthreads();
   f32x4 base[3];   // W_m markers + W_b betas + b_in for this wave's columns
   {
-    const float b = w.in_b[col];
+    const f32x4 b = *reinterpret_cast<const f32x4a1*>(w.in_b + col4);
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) base[rt] = f32x4{b, b, b, b};
+    for (int rt = 0; rt < 3; ++rt) base[rt] = b;
     for (int s = 0; s < 8; ++s) {
       bf16x8 wf[3];
       const bf16x8* pw = (s < 7) ? w.in_m + ((size_t)(wave * 7 + s) * 3) * 64 + lane : w.in_b3 + ((size_t)wave * 3) * 64 + lane;
@@ -666,12 +682,43 @@ __global__ __launch_bounds__(512, 2) void egx_regressor3_kernel(RegWeights3 w, c
     }
   }
   __syncthreads();
-  bf16x8 wcur[4][3], wnext[4][3];
+  bf16x8 wA[4][3], wB[4][3];
   float hres[3][4];   // residual stream h of this lane's elements
+  f32x4 acc[3];
+  // one 128 -> 128 layer of a residual block with the weights in `cur`; the NEXT layer's weights (or out_fc's tile `wave`) are
+  // requested into `nxt` before the products start, so that their round trip to L2 runs under this layer's matrix work and
+  // epilogue instead of in front of the next layer's
+  auto layer = [&](int l, const bf16x8 (&cur)[4][3], bf16x8 (&nxt)[4][3]) __attribute__((always_inline)) {
+    const bf16x8* src = (l & 1) ? tb3 : hb3;
+    const f32x4 b = *reinterpret_cast<const f32x4a1*>(w.blk_b + l * 128 + col4);
+    if (EARLY) {
+      if (l + 1 < 20) r3_load_w(w.blk + (size_t)(l + 1) * 8 * 4 * 3 * 64, wave, 4, lane, nxt);
+      else r3_load_w(w.out, wave, 4, lane, nxt);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    r3_mma128(src, lane, cur, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!EARLY) {
+      if (l + 1 < 20) r3_load_w(w.blk + (size_t)(l + 1) * 8 * 4 * 3 * 64, wave, 4, lane, nxt);
+      else r3_load_w(w.out, wave, 4, lane, nxt);
+    }
+    float v[3][4];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float y = fmaxf(acc[rt][r] + b[r], 0.f);
+        if (l & 1) { y += hres[rt][r]; hres[rt][r] = y; }
+        v[rt][r] = y;
+      }
+    r3_store_packed(v, (l & 1) ? hb3 : tb3, wave, lane);
+    __syncthreads();
+  };
+  r3_load_w(w.blk, wave, 4, lane, wA);   // first block layer's weights: independent of the activations
   for (int rc = 0; rc < 3; ++rc) {
-    r3_load_w(w.blk, wave, 4, lane, wcur);   // first block layer's weights: independent of the activations
     // ---- in_fc: h = base + W_xb xb (xb is zero in the first recurrence)
-    f32x4 acc[3];
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) acc[rt] = base[rt];
     if (rc > 0) {
@@ -706,55 +753,38 @@ __global__ __launch_bounds__(512, 2) void egx_regressor3_kernel(RegWeights3 w, c
       for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[rt][r] = acc[rt][r]; hres[rt][r] = acc[rt][r]; }
-      r3_store_packed(v, strip, hb3, wave, lane);
+      r3_store_packed(v, hb3, wave, lane);
     }
     __syncthreads();
-    // ---- 10 residual blocks: t = relu(W1 h + b1); h = relu(W2 t + b2) + h
-    for (int l = 0; l < 20; ++l) {
-      const bf16x8* src = (l & 1) ? tb3 : hb3;
-#pragma unroll
-      for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      __builtin_amdgcn_sched_barrier(0);
-      r3_mma128(src, lane, wcur, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      // the next layer's weights (or out_fc's tile `wave`) fly during the epilogue and the barrier
-      if (l + 1 < 20) r3_load_w(w.blk + (size_t)(l + 1) * 8 * 4 * 3 * 64, wave, 4, lane, wnext);
-      else r3_load_w(w.out, wave, 4, lane, wnext);
-      const float b = w.blk_b[l * 128 + col];
-      float v[3][4];
-#pragma unroll
-      for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float y = fmaxf(acc[rt][r] + b, 0.f);
-          if (l & 1) { y += hres[rt][r]; hres[rt][r] = y; }
-          v[rt][r] = y;
-        }
-      r3_store_packed(v, strip, (l & 1) ? hb3 : tb3, wave, lane);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) wcur[s][pl] = wnext[s][pl];
-      __syncthreads();
+    // ---- 10 residual blocks: t = relu(W1 h + b1); h = relu(W2 t + b2) + h.  Even layers read wA, odd ones wB.
+    for (int l = 0; l < 20; l += 2) {
+      layer(l, wA, wB);
+      layer(l + 1, wB, wA);
     }
-    // ---- out_fc: N = 159 -> column tiles 0..9; wave w owns tile w (weights already in wcur), waves 0 and 1 also tiles 8, 9
+    // ---- out_fc: N = 159 -> column tiles 0..9; wave w owns tile w (weights already in wA), waves 0 and 1 also tiles 8, 9
+    if (rc + 1 < 3) r3_load_w(w.blk, wave, 4, lane, wB);   // the next recurrence's first block layer
     for (int tI = wave; tI < 10; tI += 8) {
-      if (tI >= 8) r3_load_w(w.out, tI, 4, lane, wcur);
+      if (tI >= 8) r3_load_w(w.out, tI, 4, lane, wA);
 #pragma unroll
       for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      r3_mma128(hb3, lane, wcur, acc);
-      const int nn = tI * 16 + (lane & 15);
-      if (nn < R3_NOUT) {
-        const float b = w.out_b[nn];
+      r3_mma128(hb3, lane, wA, acc);
+      const int nn = tI * 16 + 4 * (lane >> 4);   // four columns of one row (column 159 is padding: it stays zero)
+      float b[4];
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
+      for (int r = 0; r < 4; ++r) b[r] = (nn + r < R3_NOUT) ? w.out_b[nn + r] : 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* xp = xb + (16 * rt + 4 * (lane >> 4) + r) * R3_XBP + nn;
-            *xp = *xp + (acc[rt][r] + b);
-          }
+      for (int rt = 0; rt < 3; ++rt) {
+        f32x4* xp = reinterpret_cast<f32x4*>(xb + (16 * rt + (lane & 15)) * R3_XBP + nn);
+        f32x4 x = *xp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] += (nn + r < R3_NOUT) ? acc[rt][r] + b[r] : 0.f;
+        *xp = x;
       }
     }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wA[s][pl] = wB[s][pl];
     __syncthreads();
   }
   // ---- 6D -> axis-angle tail straight from LDS
@@ -765,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void egx_regressor3_kernel(RegWeights3 w, c
 }
 
 int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, const float* betas, int A, int M, float* out_Yb) {
-  {  // 133 KiB of dynamic LDS: above the 64 KiB default cap; raised once per device
+  {  // 103 KiB of dynamic LDS: above the 64 KiB default cap; raised once per device
     static std::mutex mu;
     static bool attr_set[64] = {false};
     int dev = 0;
@@ -773,17 +803,26 @@ int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, 
     EGX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
     std::lock_guard<std::mutex> lk(mu);
     if (!attr_set[dev]) {
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)R3_LDS));
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor3_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)R3_LDS));
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor3_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)R3_LDS));
       attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL(egx_regressor3_kernel, dim3(egx_ceil_div(M, R3_ROWS)), dim3(512), R3_LDS, st, w, Y, betas, A, M, out_Yb);
+  static const bool early = [] { const char* e = getenv("EGX_R3_EARLY"); return !e || atoi(e) != 0; }();
+  if (early) hipLaunchKernelGGL(egx_regressor3_kernel<true>, dim3(egx_ceil_div(M, R3_ROWS)), dim3(512), R3_LDS, st, w, Y, betas, A, M, out_Yb);
+  else hipLaunchKernelGGL(egx_regressor3_kernel<false>, dim3(egx_ceil_div(M, R3_ROWS)), dim3(512), R3_LDS, st, w, Y, betas, A, M, out_Yb);
   return EGX_OK;
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
 namespace {
+// development knobs, read once
+int d3_env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : dflt;
+}
 template <int TRIP, int MI, int NI, int NW, int NPL>
 void d3_launch_cfg(hipStream_t st, const D3Plain* ps, int n) {
   constexpr int TM = 16 * MI, TN = 16 * NI;
@@ -803,22 +842,19 @@ void d3_launch_cfg(hipStream_t st, const D3Plain* ps, int n) {
     }
   }
   D3Args4 f;
+  static const int rowmap = d3_env_int("EGX_D3_ROWMAP", -1);
+  f.rowmap = rowmap;
   D3Plain* dst[4] = {&f.p0, &f.p1, &f.p2, &f.p3};
   int ends[4] = {0, 0, 0, 0}, total = 0;
   for (int i = 0; i < 4; ++i) {
     *dst[i] = ps[i < n ? i : n - 1];
-    if (i < n) total += d3_blocks(egx_ceil_div(ps[i].M, TM), egx_ceil_div(ps[i].N, TN)) * std::max(1, ps[i].batches);
+    if (i < n) total += d3_blocks(egx_ceil_div(ps[i].M, TM), egx_ceil_div(ps[i].N, TN), d3_rowmap(rowmap, ps[i].M, ps[i].N)) * std::max(1, ps[i].batches);
     ends[i] = total;
   }
   f.end0 = ends[0]; f.end1 = ends[1]; f.end2 = ends[2];
   hipLaunchKernelGGL((egx_dense3_kernel<TRIP, MI, NI, NW, NPL>), dim3(total), dim3(64 * NW), lds, st, f);
 }
 
-// k-steps per burst of the deep (S > 16) layers in the two- and one-plane modes: development knobs, read once
-int d3_env_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return (v && *v) ? std::atoi(v) : dflt;
-}
 }  // namespace
 
 // 32 x 32 tile per 4-wave workgroup, the reduction split over the waves; three k-steps per round trip for deep reductions.
@@ -829,24 +865,32 @@ void egx_launch_dense3_n(hipStream_t st, const D3Plain* ps, int n) {
   int smax = 0;
   for (int i = 0; i < n; ++i) smax = std::max(smax, ps[i].S);
   const bool deep = smax > 16;
+  // 9..16 k-steps: eight waves take two k-steps each, ONE operand round trip (four waves need two).  EGX_D3_NW8=0 turns it off.
+  static const int nw8 = d3_env_int("EGX_D3_NW8", 1);
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += egx_ceil_div(ps[i].M, 32) * egx_ceil_div(ps[i].N, 32) * std::max(1, ps[i].batches);
+  const bool wide = nw8 && smax > 8 && !deep && (nw8 > 1 || tiles <= 512);   // a latency-bound launch: at most two workgroups per CU
   switch (ps[0].prec) {
     case 2: {
       static const int trip = d3_env_int("EGX_D3_TRIP_P2", 3);
-      if (!deep) d3_launch_cfg<2, 2, 2, 4, 2>(st, ps, n);
+      if (wide) d3_launch_cfg<2, 2, 2, 8, 2>(st, ps, n);
+      else if (!deep) d3_launch_cfg<2, 2, 2, 4, 2>(st, ps, n);
       else if (trip >= 5) d3_launch_cfg<5, 2, 2, 4, 2>(st, ps, n);
       else d3_launch_cfg<3, 2, 2, 4, 2>(st, ps, n);
       break;
     }
     case 1: {
       static const int trip = d3_env_int("EGX_D3_TRIP_P1", 5);
-      if (!deep) d3_launch_cfg<2, 2, 2, 4, 1>(st, ps, n);
+      if (wide) d3_launch_cfg<2, 2, 2, 8, 1>(st, ps, n);
+      else if (!deep) d3_launch_cfg<2, 2, 2, 4, 1>(st, ps, n);
       else if (trip >= 9) d3_launch_cfg<9, 2, 2, 4, 1>(st, ps, n);
       else if (trip >= 5) d3_launch_cfg<5, 2, 2, 4, 1>(st, ps, n);
       else d3_launch_cfg<3, 2, 2, 4, 1>(st, ps, n);
       break;
     }
     default:
-      if (deep) d3_launch_cfg<3, 2, 2, 4, 3>(st, ps, n);
+      if (wide) d3_launch_cfg<2, 2, 2, 8, 3>(st, ps, n);
+      else if (deep) d3_launch_cfg<3, 2, 2, 4, 3>(st, ps, n);
       else d3_launch_cfg<2, 2, 2, 4, 3>(st, ps, n);
   }
 }
@@ -863,8 +907,10 @@ static void d3_launch_gru(hipStream_t st, const D3Gru& g0, const D3Gru* g1) {
   constexpr size_t lds = (size_t)(8 * 24 * 64 + 32 * 20) * sizeof(float);   // 50.5 KiB: within the default dynamic-LDS cap
   D3Gru2 two;
   two.g0 = g0; two.g1 = g1 ? *g1 : g0;
-  two.blocks0 = d3_blocks((g0.M + 31) >> 5, g0.H >> 4);
-  const int total = two.blocks0 + (g1 ? d3_blocks((g1->M + 31) >> 5, g1->H >> 4) : 0);
+  static const int rowmap = d3_env_int("EGX_D3_ROWMAP", -1);
+  two.rowmap = rowmap;
+  two.blocks0 = d3_blocks((g0.M + 31) >> 5, g0.H >> 4, d3_rowmap(rowmap, g0.M, 3 * g0.H));
+  const int total = two.blocks0 + (g1 ? d3_blocks((g1->M + 31) >> 5, g1->H >> 4, d3_rowmap(rowmap, g1->M, 3 * g1->H)) : 0);
   switch (g0.prec) {
     case 2: hipLaunchKernelGGL((egx_gru3_kernel<2, 2>), dim3(total), dim3(512), lds, st, two); break;
     case 1: hipLaunchKernelGGL((egx_gru3_kernel<4, 1>), dim3(total), dim3(512), lds, st, two); break;
