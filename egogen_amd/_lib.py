@@ -83,7 +83,7 @@ class PolicyGrads(C.Structure):
 
 
 class VposerWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mu_w", "mu_b")]
+    _fields_ = [(n, C.c_void_p) for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mu_w", "mu_b", "fc1_w3", "fc2_w3", "mu_w3")]
 
 
 class EnvConfig(C.Structure):

@@ -230,7 +230,6 @@ class VecCrowdEnv:
         # workspaces are sized now so that nothing allocates during graph capture
         self.bm.workspace(A20)
         self.prior._ws.get(self.lib.egx_sample_prior_workspace_bytes(A), self.dev)
-        self.vposer._ws.get(self.lib.egx_vposer_workspace_bytes(A20), self.dev)
         if self.vposer._folded is None:
             self.vposer.fold()
         self.prior._weights()

@@ -816,6 +816,219 @@ int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, 
   return EGX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused VPoser encoder mean on the bf16 matrix pipe (three planes: fp32-equivalent): out = mu(lrelu(fc2(lrelu(fc1 x)))) for 48
+// rows per workgroup, BatchNorms folded into fc1 / fc2 by the host (egx_vposer_weights).  Same scheme as the regressor:
+// transposed products, the epilogues write the next layer's operand fragments into LDS themselves.
+//   * eight waves, wave w owns columns 64 w .. 64 w + 63 (four 16-column tiles) of the two 512-wide layers for all three
+//     16-row tiles: 12 accumulators; fc2's weights (1.5 MB, L2-resident: every workgroup reads all of them) come as bursts of
+//     TRIP k-steps x 12 one-KiB fragments per wave -> s_waitcnt -> 72 TRIP MFMAs, the two waves of a SIMD alternating;
+//   * y1 = lrelu(fc1 x) lives in LDS as packed planes [3 row tiles][16 k-steps][3 planes] = 144 KiB - the whole LDS budget:
+//     the packed input rows (18 KiB) borrow its head before y1 exists, y2 = lrelu(fc2 y1) overwrites it in place (a wave
+//     writes the two k-steps it alone will read), the split-K partial sums of mu (wave w reduces over ITS 64 columns of y2)
+//     borrow it once y2 is consumed.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int VP_ROWS = 48;
+constexpr size_t VP_LDS = (size_t)3 * 16 * 3 * 64 * 16;   // 147 456 B
+
+// values v[rt][r] of column tile `ct16` (16 columns: 32-wide k-step ct16 >> 1, half ct16 & 1) -> packed planes in `ybuf`
+__device__ __forceinline__ void vp_store_packed(const float (&v)[3][4], bf16x8* ybuf, int ct16, int lane) {
+  typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+  const int g = lane >> 4;
+  char* o = reinterpret_cast<char*>(ybuf + (size_t)((ct16 >> 1) * 3) * 64 + 16 * (2 * (ct16 & 1) + (g >> 1)) + (lane & 15)) + 8 * (g & 1);
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt) {
+    float r[4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      bf16v4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = (p == 0) ? v[rt][e] : r[e];
+        h[e] = (__bf16)x;
+        r[e] = x - (float)h[e];
+      }
+      *reinterpret_cast<bf16v4*>(o + (size_t)((rt * 16) * 3 + p) * 64 * sizeof(bf16x8)) = h;
+    }
+  }
+}
+// acc[ct][rt] += (a[rt] . w[ct])^T, product-major
+template <int NCT>
+__device__ __forceinline__ void vp_mma(const bf16x8 (&a)[3][3], const bf16x8 (&wf)[NCT][3], f32x4 (&acc)[NCT][3]) {
+#pragma unroll
+  for (int pr = 0; pr < 6; ++pr) {
+    const int pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
+    const int pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][pb], a[rt][pa], acc[ct][rt], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ float vp_lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
+}  // namespace
+
+template <int TRIP>
+__global__ __launch_bounds__(512) void egx_vposer3_kernel(VpWeights3 w, const float* __restrict__ X, int x_ld, int n,
+                                                          float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char vp_smem[];
+  bf16x8* ybuf = reinterpret_cast<bf16x8*>(vp_smem);   // [3 row tiles][16 k-steps][3 planes][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4;
+  const int m0 = blockIdx.x * VP_ROWS;
+  // ---- packed input rows: 3 row tiles x 2 k-steps (63 -> 64 columns), one fragment per wave 0..5, at the head of ybuf
+  if (wave < 6) {
+    const int rt = wave >> 1, s = wave & 1;
+    const int row = min(m0 + 16 * rt + (lane & 15), n - 1), k0 = 32 * s + 8 * g;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (k0 + e < 63) ? X[(size_t)row * x_ld + k0 + e] : 0.f;
+    bf16x8 pl[3];
+    d3_split(x, pl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) ybuf[(wave * 3 + p) * 64 + lane] = pl[p];
+  }
+  __syncthreads();
+  // ---- fc1: 64 -> 512
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) acc[ct][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    bf16x8 wf[2][4][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[s][ct][p] = w.fc1[((size_t)((4 * wave + ct) * 2 + s) * 3 + p) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3][3];
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[rt][p] = ybuf[((rt * 2 + s) * 3 + p) * 64 + lane];
+      vp_mma<4>(a, wf[s], acc);
+    }
+  }
+  __syncthreads();   // the input fragments are consumed: y1 may overwrite them
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const f32x4 b = *reinterpret_cast<const f32x4a1*>(w.b1 + 64 * wave + 16 * ct + 4 * g);
+    float v[3][4];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[rt][r] = vp_lrelu(acc[ct][rt][r] + b[r]);
+    vp_store_packed(v, ybuf, 4 * wave + ct, lane);
+  }
+  __syncthreads();
+  // ---- fc2: 512 -> 512, the weights in bursts of TRIP k-steps
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) acc[ct][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < 16; s0 += TRIP) {
+    bf16x8 wf[TRIP][4][3];
+#pragma unroll
+    for (int u = 0; u < TRIP; ++u) {
+      const int su = min(s0 + u, 15);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[u][ct][p] = w.fc2[((size_t)((4 * wave + ct) * 16 + su) * 3 + p) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < TRIP; ++u) {
+      if (s0 + u < 16) {
+        bf16x8 a[3][3];
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) a[rt][p] = ybuf[((rt * 16 + s0 + u) * 3 + p) * 64 + lane];
+        vp_mma<4>(a, wf[u], acc);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // mu's weights for this wave's two k-steps: their round trip runs under fc2's epilogue
+  bf16x8 wmu[2][2][3];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wmu[u][jt][p] = w.mu[((size_t)(jt * 16 + 2 * wave + u) * 3 + p) * 64 + lane];
+  __syncthreads();   // every wave is done with y1: y2 takes its place
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const f32x4 b = *reinterpret_cast<const f32x4a1*>(w.b2 + 64 * wave + 16 * ct + 4 * g);
+    float v[3][4];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[rt][r] = vp_lrelu(acc[ct][rt][r] + b[r]);
+    vp_store_packed(v, ybuf, 4 * wave + ct, lane);
+  }
+  __syncthreads();
+  // ---- mu: 512 -> 32, wave w reduces over k-steps 2 w, 2 w + 1 (its own columns of y2)
+  f32x4 am[2][3];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) am[jt][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    bf16x8 a[3][3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[rt][p] = ybuf[((rt * 16 + 2 * wave + u) * 3 + p) * 64 + lane];
+    vp_mma<2>(a, wmu[u], am);
+  }
+  __syncthreads();   // y2 is consumed: the partial sums borrow the buffer
+  float* red = reinterpret_cast<float*>(vp_smem);   // [8 waves][24][64]
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 24 + (jt * 3 + rt) * 4 + r) * 64 + lane] = am[jt][rt][r];
+  __syncthreads();
+  for (int idx = tid; idx < 24 * 64; idx += 512) {
+    const int q = idx >> 6, l = idx & 63;
+    float v = ((red[(0 * 24 + q) * 64 + l] + red[(1 * 24 + q) * 64 + l]) + (red[(2 * 24 + q) * 64 + l] + red[(3 * 24 + q) * 64 + l])) +
+              ((red[(4 * 24 + q) * 64 + l] + red[(5 * 24 + q) * 64 + l]) + (red[(6 * 24 + q) * 64 + l] + red[(7 * 24 + q) * 64 + l]));
+    const int jt = q / 12, rt = (q >> 2) % 3, r = q & 3;
+    const int row = m0 + 16 * rt + (l & 15), j = 16 * jt + 4 * (l >> 4) + r;
+    if (row < n) out[(size_t)row * 32 + j] = v + w.bmu[j];
+  }
+}
+
+int egx_launch_vposer3(hipStream_t st, const VpWeights3& w, const float* x, int x_ld, int n, float* out) {
+  // bursts of 2 k-steps: 40.5 us for 10 240 rows (1: 41.6, 3: 42.1; the three fp32-MFMA launches this replaces: 126)
+  {  // 144 KiB of dynamic LDS: above the 64 KiB default cap; raised once per device
+    static std::mutex mu;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    EGX_HIP_CHECK(hipGetDevice(&dev));
+    EGX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
+    std::lock_guard<std::mutex> lk(mu);
+    if (!attr_set[dev]) {
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_vposer3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VP_LDS));
+      attr_set[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(egx_vposer3_kernel<2>, dim3(egx_ceil_div(n, VP_ROWS)), dim3(512), VP_LDS, st, w, x, x_ld, n, out);
+  return EGX_OK;
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------
 namespace {
 // development knobs, read once

@@ -112,6 +112,13 @@ struct RegWeights3 {
 };
 int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, const float* betas, int A, int M, float* out_Yb);
 
+// Fused VPoser encoder mean on packed weights (dense3.hip): fc1 [512,63] (2 k-steps), fc2 [512,512] (16), mu [32,512] (16)
+struct VpWeights3 {
+  const bf16x8 *fc1, *fc2, *mu;
+  const float *b1, *b2, *bmu;
+};
+int egx_launch_vposer3(hipStream_t st, const VpWeights3& w, const float* x, int x_ld, int n, float* out);
+
 // MoshRegressor tail (models_GAMMA_primitive.py:208-219 + baseops.py:119-162): xb6[159] -> xb[93] =
 // transl3 | 22 x (6D -> Gram-Schmidt rotmat -> axis-angle) | hands 24.  One call per (row, item j in 0..22).
 __device__ __forceinline__ void egx_cont6d_item(const float* src, float* dst, int j) {

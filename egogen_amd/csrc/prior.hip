@@ -291,27 +291,21 @@ extern "C" int egx_policy_forward(const egx_policy_weights* w, const float* stat
 
 // ---------------------------------------------------------------------------------------------------------
 extern "C" size_t egx_vposer_workspace_bytes(int n) {
-  if (n <= 0) return 0;
-  return carve_bytes({(size_t)n * 512, (size_t)n * 512});
+  (void)n;
+  return 0;   // the fused encoder keeps its intermediates in LDS (the argument pair stays in the ABI)
 }
 
 extern "C" int egx_vposer_encode(const egx_vposer_weights* w, const float* x, int x_ld, int n, float* out,
                                  void* workspace, size_t workspace_bytes, void* stream_) {
+  (void)workspace; (void)workspace_bytes;
   EGX_REQUIRE(w && x && out && n > 0 && x_ld >= 63, "bad arguments");
-  if (!workspace || workspace_bytes < egx_vposer_workspace_bytes(n)) {
-    egx_set_error("egx_vposer_encode: workspace too small");
-    return EGX_ERR_WORKSPACE;
-  }
-  hipStream_t st = static_cast<hipStream_t>(stream_);
-  Carver cv(workspace, workspace_bytes);
-  float* t1 = cv.take((size_t)n * 512);
-  float* t2 = cv.take((size_t)n * 512);
-  EgxSeg s0{x, 63, x_ld};
-  egx_launch_linear(st, n, 512, &s0, 1, w->fc1_w, w->fc1_b, 3, 0.2f, nullptr, 0, t1, 512);
-  EgxSeg s1{t1, 512, 512};
-  egx_launch_linear(st, n, 512, &s1, 1, w->fc2_w, w->fc2_b, 3, 0.2f, nullptr, 0, t2, 512);
-  EgxSeg s2{t2, 512, 512};
-  egx_launch_linear(st, n, 32, &s2, 1, w->mu_w, w->mu_b, 0, 0.f, nullptr, 0, out, 32);
+  EGX_REQUIRE(w->fc1_w3 && w->fc2_w3 && w->mu_w3, "egx_vposer_encode needs the packed weight images (egx_vposer_weights.fc1_w3 / fc2_w3 / mu_w3, built with egx_pack3)");
+  EGX_REQUIRE(w->fc1_b && w->fc2_b && w->mu_b, "null bias");
+  VpWeights3 v;
+  v.fc1 = static_cast<const bf16x8*>(w->fc1_w3); v.fc2 = static_cast<const bf16x8*>(w->fc2_w3); v.mu = static_cast<const bf16x8*>(w->mu_w3);
+  v.b1 = w->fc1_b; v.b2 = w->fc2_b; v.bmu = w->mu_b;
+  const int rc = egx_launch_vposer3(static_cast<hipStream_t>(stream_), v, x, x_ld, n, out);
+  if (rc) return rc;
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

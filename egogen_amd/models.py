@@ -643,7 +643,6 @@ class VPoserEncoder(nn.Module):
         self.bodyprior_enc_fc2 = nn.Linear(num_neurons, num_neurons)
         self.bodyprior_enc_mu = nn.Linear(num_neurons, latentD)
         self.bodyprior_enc_logvar = nn.Linear(num_neurons, latentD)
-        self._ws = _Workspace()
         self._folded = None
 
     @torch.no_grad()
@@ -664,6 +663,10 @@ class VPoserEncoder(nn.Module):
         w = _lib.VposerWeights()
         for k, v in self._folded.items():
             setattr(w, k, _p(v))
+        if dev.type == "cuda":   # packed images of the folded weights: what egx_vposer_encode computes from
+            self._packed = {k: pack3(self._folded[k]) for k in ("fc1_w", "fc2_w", "mu_w")}
+            for k, v in self._packed.items():
+                setattr(w, k + "3", v.data_ptr())
         self._wstruct = w
         return self
 
@@ -672,9 +675,8 @@ class VPoserEncoder(nn.Module):
         lib = _lib.load()
         if self._folded is None:
             self.fold()
-        ws = self._ws.get(lib.egx_vposer_workspace_bytes(n), out.device)
         rc = lib.egx_vposer_encode(C.byref(self._wstruct), C.c_void_p(x.data_ptr()), int(x_ld), int(n), _lib.ptr(out),
-                                   _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr())
+                                   None, 0, _lib.current_stream_ptr())
         _lib.check(rc, "egx_vposer_encode")
 
     @torch.no_grad()

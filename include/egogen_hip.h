@@ -403,6 +403,9 @@ typedef struct egx_vposer_weights {
   const float *fc1_w, *fc1_b; /* 512x63  */
   const float *fc2_w, *fc2_b; /* 512x512 */
   const float *mu_w, *mu_b;   /* 32x512  */
+  /* Packed images (egx_pack3) of fc1_w [512,63], fc2_w [512,512], mu_w [32,512]: the encoder is ONE launch on the bf16 matrix
+   * pipe (three-term operands: fp32-equivalent, like the motion prior).  Required. */
+  const void *fc1_w3, *fc2_w3, *mu_w3;
 } egx_vposer_weights;
 
 size_t egx_vposer_workspace_bytes(int num_rows);

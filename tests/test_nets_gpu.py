@@ -129,7 +129,8 @@ def test_policy_matches_reference_golden(prec):
     assert max_abs(hx.detach().cpu(), g["hx"]) < 2e-5
 
 
-def test_vposer_encoder_matches_oracle():
+@pytest.mark.parametrize("n", [1, 47, 100, 1000])
+def test_vposer_encoder_matches_oracle(n):
     from egogen_amd.models import VPoserEncoder
     from egogen_amd.synth import seeded_fill
     from oracle import nets
@@ -140,10 +141,17 @@ def test_vposer_encoder_matches_oracle():
     vals["bodyprior_enc_bn2.num_batches_tracked"] = torch.tensor(0)
     enc.load_state_dict(vals)
     enc.cuda()
-    x = torch.randn(100, 63, generator=torch.Generator().manual_seed(1)) * 0.3
+    x = torch.randn(n, 63, generator=torch.Generator().manual_seed(1)) * 0.3
     out = enc.encode_mean(x.cuda())
     ref = nets.vposer_encode({k: v.float() for k, v in vals.items()}, x)
     assert max_abs(out.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    # rows inside a wider buffer (the environment hands over the pose columns of its parameter rows)
+    wide = torch.full((n, 93), 7.0)
+    wide[:, 3:66] = x
+    out2 = torch.empty(n, 32, device="cuda")
+    wd = wide.cuda()
+    enc.encode_mean_into(wd[:, 3:66], 93, n, out2)
+    assert torch.equal(out2, out)
 
 
 def test_policy_bf16_mode_is_close_to_fp32_and_restorable():
