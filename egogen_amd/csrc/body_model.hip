@@ -446,7 +446,7 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
 #endif
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
-    const unsigned long long q0 = LBS_NOW();
+    [[maybe_unused]] const unsigned long long q0 = LBS_NOW();
     const f32x4* Aq = p.A4 + (size_t)min(bt0 + q, num_bt - 1) * NJ * 3 * 32 + n;
     // rows are handled in adjacent pairs (r, r+1): the accumulator registers, weights and outputs of a pair are
     // neighbours, so the nine transform FMAs and three weight FMAs map onto packed fp32 instructions
@@ -765,7 +765,7 @@ __device__ __forceinline__ void lbs_blend_split(const LbsParams& p, f32x16 (&acc
     // burst: this wave's share of the stage's base pieces + its own feature pieces
     constexpr int NGA = (SP + 3) / 4;
     bf16x8 ga[NGA], b[SKS][NPL][NB];
-    const unsigned long long t0 = LBS_NOW();
+    [[maybe_unused]] const unsigned long long t0 = LBS_NOW();
 #pragma unroll
     for (int i = 0; i < NGA; ++i) {
       const int piece = wave + 4 * i;                 // (ks, plane, coord) of the stage, planes 0..NPL-1 only
@@ -780,7 +780,7 @@ __device__ __forceinline__ void lbs_blend_split(const LbsParams& p, f32x16 (&acc
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long t1 = LBS_NOW();
+    [[maybe_unused]] const unsigned long long t1 = LBS_NOW();
     bf16x8* buf = sA + (st & 1) * 18 * 64;
 #pragma unroll
     for (int i = 0; i < NGA; ++i) {
@@ -788,7 +788,7 @@ __device__ __forceinline__ void lbs_blend_split(const LbsParams& p, f32x16 (&acc
       if (piece < SP) buf[piece * 64 + lane] = ga[i];
     }
     __syncthreads();  // stage visible; also: everyone is done reading the other buffer's previous contents
-    const unsigned long long t2 = LBS_NOW();
+    [[maybe_unused]] const unsigned long long t2 = LBS_NOW();
 #pragma unroll
     for (int ks = 0; ks < SKS; ++ks) {
       bf16x8 a[NPL][3];  // [plane][coord]
