@@ -1732,7 +1732,10 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
       }
     }
     const int num_cu = di.num_cu;
-    p.bg_block = 2;
+    // three body groups per block: features + joint transforms of a block (3 x 1.2 MB) still live in the XCD's 4 MiB L2 and the
+    // bases stream through twice per XCD instead of three times (5 groups per XCD at 10 240 bodies): fabric-side traffic 1.77 ->
+    // 1.43 GB per launch at the same launch time (1: 2.6 GB, 5: 1.65 GB and +4 % time; profiles/r04_lbs_traffic.md)
+    p.bg_block = 3;
 #ifdef EGX_LBS_DEVELOPMENT
     if (const char* e = getenv("EGX_LBS_BG_BLOCK")) p.bg_block = atoi(e);
 #endif
