@@ -40,21 +40,71 @@ struct PackEntry {
   int red, cols, ld, col0;   // source block: `red` rows x `cols` columns starting at column col0 (leading dimension ld)
   bf16x8* dst;
   int S_total, s0;           // destination: k-steps per row tile, first k-step
-  int transpose;             // 0: image rows = source rows (reduction along the columns); 1: image rows = source columns
+  int transpose;             // 0: image rows = source rows (reduction along the columns); 1: image rows = source columns;
+                             // 2: BOTH images of the whole matrix from one read (dst: rows = source rows, dst2: rows = source
+                             //    columns), a 32 x 32 source block per wave
   int ones_row;              // transposed images: image row that is all ones (-1: none)
-  int frag_end;              // running fragment count (this entry owns [previous frag_end, frag_end))
+  int frag_end;              // running fragment count (this entry owns [previous frag_end, frag_end)); blocks for transpose 2
+  bf16x8* dst2;              // transpose 2: the transposed image
+  int S_total2;              //              and its k-steps per row tile
 };
 
 __global__ __launch_bounds__(256) void egx_pack3_table_kernel(const PackEntry* __restrict__ tab, int n, int nplanes) {
   int frag = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  int i = 0, base = 0;
-  while (i < n && frag >= tab[i].frag_end) { base = tab[i].frag_end; ++i; }
-  if (i >= n) return;
-  const PackEntry e = tab[i];
-  frag -= base;
+  if (n <= 0 || frag >= tab[n - 1].frag_end) return;
+  int lo = 0, hi = n - 1;   // first entry whose running count exceeds `frag`
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (frag >= tab[mid].frag_end) lo = mid + 1; else hi = mid;
+  }
+  const PackEntry e = tab[lo];
+  frag -= lo > 0 ? tab[lo - 1].frag_end : 0;
   float x[8];
   int rt, s;
+  if (e.transpose == 2) {
+    // weight matrix W [red, cols] -> image of W (the forward products' operand) and image of W^T (the input-gradient
+    // products'): the wave reads its 32 x 32 block once, writes W's two fragments from registers and W^T's two after a
+    // transposition through its LDS strip
+    __shared__ float sblk[4][32][33];
+    float (*sb)[33] = sblk[threadIdx.x >> 6];
+    const int BJ = (e.cols + 31) >> 5;
+    const int bi = frag / BJ, bj = frag % BJ;
+    const int r = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 32 * bi + 16 * t + r, k0 = 32 * bj + 8 * kg;
+      const float* sp = e.src + (size_t)row * e.ld + e.col0 + k0;
+      if (row < e.red && k0 + 7 < e.cols && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {   // the interior: two 16-byte loads
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(sp), x1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2]; x[3] = x0[3]; x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = (row < e.red && k0 + q < e.cols) ? sp[q] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sb[16 * t + r][8 * kg + q] = x[q];
+      bf16x8 pl[3];
+      u3_split(x, pl);
+      bf16x8* o = e.dst + ((size_t)(2 * bi + t) * e.S_total + e.s0 + bj) * 3 * 64 + lane;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        if (p < nplanes) o[p * 64] = pl[p];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = sb[8 * kg + q][16 * t + r];
+      bf16x8 pl[3];
+      u3_split(x, pl);
+      bf16x8* o = e.dst2 + ((size_t)(2 * bj + t) * e.S_total2 + bi) * 3 * 64 + lane;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        if (p < nplanes) o[p * 64] = pl[p];
+    }
+    return;
+  }
   if (!e.transpose) {
     const int S = (e.cols + 31) >> 5;
     rt = frag / S; s = frag % S;
@@ -236,9 +286,13 @@ namespace {
 int upload_table(std::vector<PackEntry>& v, PackEntry** dev, int* frags) {
   int run = 0;
   for (PackEntry& e : v) {
-    const int rows = e.transpose ? e.cols + (e.ones_row >= 0 ? 1 : 0) : e.red;
-    const int red = e.transpose ? e.red : e.cols;
-    run += (int)img_frags(rows, red);
+    if (e.transpose == 2) {
+      run += egx_ceil_div(e.red, 32) * egx_ceil_div(e.cols, 32);
+    } else {
+      const int rows = e.transpose ? e.cols + (e.ones_row >= 0 ? 1 : 0) : e.red;
+      const int red = e.transpose ? e.red : e.cols;
+      run += (int)img_frags(rows, red);
+    }
     e.frag_end = run;
   }
   *frags = run;
@@ -344,23 +398,27 @@ extern "C" int egx_policy_train_create(const egx_policy_weights* w, const egx_po
                 int transpose, int ones_row) {
     PackEntry e;
     e.src = src; e.red = red; e.cols = cols; e.ld = ld; e.col0 = col0; e.dst = dst; e.S_total = S_total; e.s0 = s0;
-    e.transpose = transpose; e.ones_row = ones_row; e.frag_end = 0;
+    e.transpose = transpose; e.ones_row = ones_row; e.frag_end = 0; e.dst2 = nullptr; e.S_total2 = 0;
+    v.push_back(e);
+  };
+  // W and W^T images of a whole weight matrix [rows, cols] from one read of it
+  auto add_both = [](std::vector<PackEntry>& v, const float* src, int rows, int cols, bf16x8* img, bf16x8* imgT) {
+    PackEntry e;
+    e.src = src; e.red = rows; e.cols = cols; e.ld = cols; e.col0 = 0; e.dst = img; e.S_total = egx_ceil_div(cols, 32); e.s0 = 0;
+    e.transpose = 2; e.ones_row = -1; e.frag_end = 0; e.dst2 = imgT; e.S_total2 = egx_ceil_div(rows, 32);
     v.push_back(e);
   };
   for (int e = 0; e < 2; ++e) {
     Encoder& En = h->enc[e];
     add(tw, En.Wih, 3 * HD, En.in_dim, En.in_dim, 0, En.Wih_r, egx_ceil_div(En.in_dim, 32), 0, 0, -1);
-    add(tw, En.Whh, 3 * HD, HD, HD, 0, En.Whh_r, HD / 32, 0, 0, -1);
-    add(tw, En.Whh, 3 * HD, HD, HD, 0, En.Whh_t, 3 * HD / 32, 0, 1, -1);
+    add_both(tw, En.Whh, 3 * HD, HD, En.Whh_r, En.Whh_t);
   }
   for (int b = 0; b < 2; ++b) {
     Branch& B = h->br[b];
     for (int l = 0; l < 4; ++l) {
-      add(tw, B.W[l], CAT, CAT, CAT, 0, B.W_r[l], CAT / 32, 0, 0, -1);
-      add(tw, B.W[l], CAT, CAT, CAT, 0, B.W_t[l], CAT / 32, 0, 1, -1);
+      add_both(tw, B.W[l], CAT, CAT, B.W_r[l], B.W_t[l]);
     }
-    add(tw, B.Wout, B.nout, CAT, CAT, 0, B.Wout_r, CAT / 32, 0, 0, -1);
-    add(tw, B.Wout, B.nout, CAT, CAT, 0, B.Wout_t, egx_ceil_div(B.nout, 32), 0, 1, -1);
+    add_both(tw, B.Wout, B.nout, CAT, B.Wout_r, B.Wout_t);
   }
   h->n_weights = (int)tw.size();
   int rc = upload_table(tw, &h->tab_weights, &h->frags_weights);
