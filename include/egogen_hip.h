@@ -408,6 +408,8 @@ typedef struct egx_vposer_weights {
   const void *fc1_w3, *fc2_w3, *mu_w3;
 } egx_vposer_weights;
 
+/* The encoder is one fused launch whose intermediates live in LDS: it needs no workspace (egx_vposer_workspace_bytes returns 0,
+ * `workspace` may be NULL); the argument pair stays so that the signature matches the other network entries. */
 size_t egx_vposer_workspace_bytes(int num_rows);
 int egx_vposer_encode(const egx_vposer_weights* w, const float* x, int x_ld, int num_rows, float* out,
                       void* workspace, size_t workspace_bytes, void* stream);
