@@ -13,7 +13,9 @@
 //   * concatenated inputs ([hx | z], [x_enc | ego_enc | posenc]) are k-step ranges of one packed buffer: no copies;
 //   * the GRU cell is ONE launch: a workgroup owns 32 rows x 16 hidden columns of all three gates on both sides
 //     (x W_ih^T and h W_hh^T), so the gate math runs in its epilogue (was: paired GEMM launch + pointwise launch).
-// Weights are packed once (motion prior: at load; policy: once per collect).
+// Weights are packed once (motion prior: at load; policy: after every optimiser step, update3.hip).
+// Also here, built on the same packed operands: the fused body regressor (egx_regressor3_kernel) and the fused VPoser encoder
+// (egx_vposer3_kernel) - whole networks per launch with their activations as packed planes in LDS.
 #include <cstddef>
 #include <cstdlib>
 #include <mutex>
@@ -269,7 +271,7 @@ __device__ __forceinline__ D3Plain d3_pick(int which) {
   return a;
 }
 
-// MI x NI MFMA tiles of 16 x 16 per workgroup of NW waves (instantiated: 2 x 2 tiles, four waves).
+// MI x NI MFMA tiles of 16 x 16 per workgroup of NW waves (instantiated: 2 x 2 tiles; four waves, eight for 9..16 k-steps).
 template <int TRIP, int MI, int NI, int NW, int NPL>
 __global__ __launch_bounds__(64 * NW) void egx_dense3_kernel(D3Args4 four) {
   constexpr int TM = 16 * MI, TN = 16 * NI, NACC = MI * NI * 4, PITCH = TN + 4;
