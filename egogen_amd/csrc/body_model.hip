@@ -266,7 +266,11 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       }
       for (int e = 0; e < 12; ++e) sG[w][j][e] = G[e];
     }
-    __syncthreads();
+    // sG[w] is private to this wave (one body per wave) and a wave's LDS operations complete in order: the next level's reads
+    // only have to stay behind these writes in program order - no workgroup barrier per level of the tree
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   if (j < NJ && live) {
     // relative transform: translation column minus R_g * rest joint (smplx batch_rigid_transform)
