@@ -560,10 +560,11 @@ void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Fused body regressor on the bf16 matrix pipe: MoshRegressor.forward (models_GAMMA_primitive.py:222-301) for 48 rows per
+// Fused body regressor on the bf16 matrix pipe: MoshRegressor.forward (models_GAMMA_primitive.py:222-301) for 16 NRT rows per
 // workgroup - all 3 recurrences x (in_fc + 10 residual blocks + out_fc) and the 6D -> axis-angle tail in ONE launch.
-//   * 48 rows: 18 x 512 = 9216 rows give 192 workgroups, one per CU and all equally loaded (the fp32 kernel's 288 32-row
-//     workgroups put two on 32 of the 256 CUs, which then set the launch time);
+//   * 48 rows (NRT = 3): 18 x 512 = 9216 rows give 192 workgroups, one per CU and all equally loaded (the fp32 kernel's 288
+//     32-row workgroups put two on 32 of the 256 CUs, which then set the launch time); smaller batches take 32 or 16 rows per
+//     workgroup so that more CUs work (a workgroup's time follows its own rows, not the chip's load);
 //   * eight waves, wave w owns output columns 16 w .. 16 w + 15 of every 128-wide layer for all three 16-row tiles; the
 //     activations live in LDS as packed planes (operand fragments: 16 rows x 32 reduction indices, eight consecutive indices per
 //     lane).  Every product is taken TRANSPOSED, out^T = W act^T (the weight fragment is the MFMA's first operand, the
@@ -577,9 +578,10 @@ void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, in
 //   * weights are read from packed images (one contiguous KiB per fragment), the next layer's prefetched under the epilogue.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int R3_ROWS = 48, R3_XBP = 164, R3_NOUT = 159;
-constexpr int R3_ACT_FRAGS = 3 * 4 * 3 * 64;            // one 48 x 128 activation buffer, in bf16x8 fragments-lanes
-constexpr size_t R3_LDS = (size_t)R3_ROWS * R3_XBP * 4 + 2 * (size_t)R3_ACT_FRAGS * 16;   // 102.75 KiB
+constexpr int R3_XBP = 164, R3_NOUT = 159;
+// NRT 16-row tiles per workgroup: 3 (48 rows) when the rows fill the chip that way, fewer for small batches (see the launcher)
+constexpr int r3_act_frags(int nrt) { return nrt * 4 * 3 * 64; }   // one (16 NRT) x 128 activation buffer, in bf16x8 fragments-lanes
+constexpr size_t r3_lds(int nrt) { return (size_t)16 * nrt * R3_XBP * 4 + 2 * (size_t)r3_act_frags(nrt) * 16; }   // 102.75 KiB at NRT = 3
 
 // this wave's weight fragments of one 128-deep layer: column tile `tile`, 4 k-steps x 3 planes
 __device__ __forceinline__ void r3_load_w(const bf16x8* P, int tile, int S, int lane, bf16x8 (&wf)[4][3]) {
@@ -591,35 +593,38 @@ __device__ __forceinline__ void r3_load_w(const bf16x8* P, int tile, int S, int 
 }
 // acc[rt] += (a[rt] . w)^T for the three row tiles, product-major (no MFMA waits for the previous one's result): lane
 // (m = lane & 15, g = lane >> 4) holds row 16 rt + m, columns 4 g .. 4 g + 3 of the wave's 16-column tile
-__device__ __forceinline__ void r3_mma3(const bf16x8 (&a)[3][3], const bf16x8 (&wf)[3], f32x4 (&acc)[3]) {
+template <int NRT>
+__device__ __forceinline__ void r3_mma3(const bf16x8 (&a)[NRT][3], const bf16x8 (&wf)[3], f32x4 (&acc)[NRT]) {
 #pragma unroll
   for (int pr = 0; pr < 6; ++pr) {
     const int pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
     const int pb = (pr == 0) ? 1 : (pr == 1) ? 2 : (pr == 2) ? 0 : (pr == 3) ? 1 : (pr == 4) ? 0 : 0;
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[pb], a[rt][pa], acc[rt], 0, 0, 0);
+    for (int rt = 0; rt < NRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[pb], a[rt][pa], acc[rt], 0, 0, 0);
   }
 }
 // acc[rt] += act(48 x 128, packed in LDS) . w^T for the wave's 16 columns
-__device__ __forceinline__ void r3_mma128(const bf16x8* act, int lane, const bf16x8 (&wf)[4][3], f32x4 (&acc)[3]) {
+template <int NRT>
+__device__ __forceinline__ void r3_mma128(const bf16x8* act, int lane, const bf16x8 (&wf)[4][3], f32x4 (&acc)[NRT]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    bf16x8 a[3][3];
+    bf16x8 a[NRT][3];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) a[rt][pl] = act[((rt * 4 + s) * 3 + pl) * 64 + lane];
-    r3_mma3(a, wf[s], acc);
+    r3_mma3<NRT>(a, wf[s], acc);
   }
 }
 // v[rt][r] = element (row 16 rt + (lane & 15), column 16 wave + 4 (lane >> 4) + r) -> the packed planes of `dst`: k-step
 // wave >> 1, fragment lane 16 (2 (wave & 1) + (g >> 1)) + m, elements 4 (g & 1) .. + 3 of its eight
-__device__ __forceinline__ void r3_store_packed(const float (&v)[3][4], bf16x8* dst, int wave, int lane) {
+template <int NRT>
+__device__ __forceinline__ void r3_store_packed(const float (&v)[NRT][4], bf16x8* dst, int wave, int lane) {
   typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
   const int g = lane >> 4;
   char* o = reinterpret_cast<char*>(dst + (size_t)((wave >> 1) * 3) * 64 + 16 * (2 * (wave & 1) + (g >> 1)) + (lane & 15)) + 8 * (g & 1);
 #pragma unroll
-  for (int rt = 0; rt < 3; ++rt) {
+  for (int rt = 0; rt < NRT; ++rt) {
     float r[4];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -636,21 +641,22 @@ __device__ __forceinline__ void r3_store_packed(const float (&v)[3][4], bf16x8* 
 }
 }  // namespace
 
-template <bool EARLY>
+template <int NRT>
 __global__ __launch_bounds__(512) void egx_regressor3_kernel(RegWeights3 w, const float* __restrict__ Y,
                                                                 const float* __restrict__ betas, int A, int M,
                                                                 float* __restrict__ out_Yb) {
+  constexpr int ROWS = 16 * NRT;
   extern __shared__ __attribute__((aligned(16))) char r3_smem[];
   float* xb = reinterpret_cast<float*>(r3_smem);                                      // [48][164] fp32: the running 6D parameters
-  bf16x8* hb3 = reinterpret_cast<bf16x8*>(r3_smem + (size_t)R3_ROWS * R3_XBP * 4);    // packed h (also: scratch of the prologue)
-  bf16x8* tb3 = hb3 + R3_ACT_FRAGS;                                                   // packed t
+  bf16x8* hb3 = reinterpret_cast<bf16x8*>(r3_smem + (size_t)ROWS * R3_XBP * 4);    // packed h (also: scratch of the prologue)
+  bf16x8* tb3 = hb3 + r3_act_frags(NRT);                                                   // packed t
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * R3_ROWS;
+  const int m0 = blockIdx.x * ROWS;
   const int col4 = 16 * wave + 4 * (lane >> 4);   // this lane's four output columns in every 128-wide layer
-  for (int i = tid; i < R3_ROWS * R3_XBP; i += 512) xb[i] = 0.f;
+  for (int i = tid; i < ROWS * R3_XBP; i += 512) xb[i] = 0.f;
   // ---- prologue: [markers | betas] as packed planes in the (still unused) activation region: 3 row tiles x (7 + 1) k-steps
   bf16x8* in3 = hb3;
-  for (int f = wave; f < 3 * 8; f += 8) {
+  for (int f = wave; f < NRT * 8; f += 8) {
     const int rt = f >> 3, s = f & 7;
     const int row = min(m0 + 16 * rt + (lane & 15), M - 1), k0 = 8 * (lane >> 4);
     float x[8];
@@ -665,67 +671,61 @@ __global__ __launch_bounds__(512) void egx_regressor3_kernel(RegWeights3 w, cons
     for (int p = 0; p < 3; ++p) in3[((rt * 8 + s) * 3 + p) * 64 + lane] = pl[p];
   }
   __syncthreads();
-  f32x4 base[3];   // W_m markers + W_b betas + b_in for this wave's columns
+  f32x4 base[NRT];   // W_m markers + W_b betas + b_in for this wave's columns
   {
     const f32x4 b = *reinterpret_cast<const f32x4a1*>(w.in_b + col4);
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) base[rt] = b;
+    for (int rt = 0; rt < NRT; ++rt) base[rt] = b;
     for (int s = 0; s < 8; ++s) {
       bf16x8 wf[3];
       const bf16x8* pw = (s < 7) ? w.in_m + ((size_t)(wave * 7 + s) * 3) * 64 + lane : w.in_b3 + ((size_t)wave * 3) * 64 + lane;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) wf[pl] = pw[pl * 64];
-      bf16x8 a[3][3];
+      bf16x8 a[NRT][3];
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt)
+      for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) a[rt][pl] = in3[((rt * 8 + s) * 3 + pl) * 64 + lane];
-      r3_mma3(a, wf, base);
+      r3_mma3<NRT>(a, wf, base);
     }
   }
   __syncthreads();
   bf16x8 wA[4][3], wB[4][3];
-  float hres[3][4];   // residual stream h of this lane's elements
-  f32x4 acc[3];
+  float hres[NRT][4];   // residual stream h of this lane's elements
+  f32x4 acc[NRT];
   // one 128 -> 128 layer of a residual block with the weights in `cur`; the NEXT layer's weights (or out_fc's tile `wave`) are
   // requested into `nxt` before the products start, so that their round trip to L2 runs under this layer's matrix work and
   // epilogue instead of in front of the next layer's
   auto layer = [&](int l, const bf16x8 (&cur)[4][3], bf16x8 (&nxt)[4][3]) __attribute__((always_inline)) {
     const bf16x8* src = (l & 1) ? tb3 : hb3;
     const f32x4 b = *reinterpret_cast<const f32x4a1*>(w.blk_b + l * 128 + col4);
-    if (EARLY) {
-      if (l + 1 < 20) r3_load_w(w.blk + (size_t)(l + 1) * 8 * 4 * 3 * 64, wave, 4, lane, nxt);
-      else r3_load_w(w.out, wave, 4, lane, nxt);
-    }
+    if (l + 1 < 20) r3_load_w(w.blk + (size_t)(l + 1) * 8 * 4 * 3 * 64, wave, 4, lane, nxt);
+    else r3_load_w(w.out, wave, 4, lane, nxt);
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
-    r3_mma128(src, lane, cur, acc);
+    r3_mma128<NRT>(src, lane, cur, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if (!EARLY) {
-      if (l + 1 < 20) r3_load_w(w.blk + (size_t)(l + 1) * 8 * 4 * 3 * 64, wave, 4, lane, nxt);
-      else r3_load_w(w.out, wave, 4, lane, nxt);
-    }
-    float v[3][4];
+    float v[NRT][4];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float y = fmaxf(acc[rt][r] + b[r], 0.f);
         if (l & 1) { y += hres[rt][r]; hres[rt][r] = y; }
         v[rt][r] = y;
       }
-    r3_store_packed(v, (l & 1) ? hb3 : tb3, wave, lane);
+    r3_store_packed<NRT>(v, (l & 1) ? hb3 : tb3, wave, lane);
     __syncthreads();
   };
   r3_load_w(w.blk, wave, 4, lane, wA);   // first block layer's weights: independent of the activations
   for (int rc = 0; rc < 3; ++rc) {
     // ---- in_fc: h = base + W_xb xb (xb is zero in the first recurrence)
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) acc[rt] = base[rt];
+    for (int rt = 0; rt < NRT; ++rt) acc[rt] = base[rt];
     if (rc > 0) {
       bf16x8* xb3 = hb3;   // 3 row tiles x 5 k-steps of packed xb, made by all waves (the activation region is free here)
-      for (int f = wave; f < 3 * 5; f += 8) {
+      for (int f = wave; f < NRT * 5; f += 8) {
         const int rt = f / 5, s = f % 5;
         const float* sp = xb + (16 * rt + (lane & 15)) * R3_XBP + 32 * s + 8 * (lane >> 4);
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(sp), x1 = *reinterpret_cast<const f32x4*>(sp + 4);
@@ -740,22 +740,22 @@ __global__ __launch_bounds__(512) void egx_regressor3_kernel(RegWeights3 w, cons
         bf16x8 wf[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) wf[pl] = w.in_xb[((size_t)(wave * 5 + s) * 3 + pl) * 64 + lane];
-        bf16x8 a[3][3];
+        bf16x8 a[NRT][3];
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
+        for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) a[rt][pl] = xb3[((rt * 5 + s) * 3 + pl) * 64 + lane];
-        r3_mma3(a, wf, acc);
+        r3_mma3<NRT>(a, wf, acc);
       }
       __syncthreads();   // everyone is done reading xb3 before h overwrites the region
     }
     {
-      float v[3][4];
+      float v[NRT][4];
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt)
+      for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[rt][r] = acc[rt][r]; hres[rt][r] = acc[rt][r]; }
-      r3_store_packed(v, hb3, wave, lane);
+      r3_store_packed<NRT>(v, hb3, wave, lane);
     }
     __syncthreads();
     // ---- 10 residual blocks: t = relu(W1 h + b1); h = relu(W2 t + b2) + h.  Even layers read wA, odd ones wB.
@@ -768,14 +768,14 @@ __global__ __launch_bounds__(512) void egx_regressor3_kernel(RegWeights3 w, cons
     for (int tI = wave; tI < 10; tI += 8) {
       if (tI >= 8) r3_load_w(w.out, tI, 4, lane, wA);
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      r3_mma128(hb3, lane, wA, acc);
+      for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      r3_mma128<NRT>(hb3, lane, wA, acc);
       const int nn = tI * 16 + 4 * (lane >> 4);   // four columns of one row (column 159 is padding: it stays zero)
       float b[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) b[r] = (nn + r < R3_NOUT) ? w.out_b[nn + r] : 0.f;
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt) {
+      for (int rt = 0; rt < NRT; ++rt) {
         f32x4* xp = reinterpret_cast<f32x4*>(xb + (16 * rt + (lane & 15)) * R3_XBP + nn);
         f32x4 x = *xp;
 #pragma unroll
@@ -790,14 +790,16 @@ __global__ __launch_bounds__(512) void egx_regressor3_kernel(RegWeights3 w, cons
     __syncthreads();
   }
   // ---- 6D -> axis-angle tail straight from LDS
-  for (int idx = tid; idx < R3_ROWS * 23; idx += 512) {
+  for (int idx = tid; idx < ROWS * 23; idx += 512) {
     const int r = idx / 23, j = idx % 23;
     if (m0 + r < M) egx_cont6d_item(xb + r * R3_XBP, out_Yb + (size_t)(m0 + r) * 93, j);
   }
 }
 
-int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, const float* betas, int A, int M, float* out_Yb) {
-  {  // 103 KiB of dynamic LDS: above the 64 KiB default cap; raised once per device
+namespace {
+template <int NRT>
+int r3_launch(hipStream_t st, const RegWeights3& w, const float* Y, const float* betas, int A, int M, float* out_Yb) {
+  if (r3_lds(NRT) > 64 * 1024) {  // dynamic LDS above the 64 KiB default cap: raised once per device
     static std::mutex mu;
     static bool attr_set[64] = {false};
     int dev = 0;
@@ -805,17 +807,27 @@ int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, 
     EGX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
     std::lock_guard<std::mutex> lk(mu);
     if (!attr_set[dev]) {
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor3_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)R3_LDS));
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor3_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)R3_LDS));
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_regressor3_kernel<NRT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)r3_lds(NRT)));
       attr_set[dev] = true;
     }
   }
-  static const bool early = [] { const char* e = getenv("EGX_R3_EARLY"); return !e || atoi(e) != 0; }();
-  if (early) hipLaunchKernelGGL(egx_regressor3_kernel<true>, dim3(egx_ceil_div(M, R3_ROWS)), dim3(512), R3_LDS, st, w, Y, betas, A, M, out_Yb);
-  else hipLaunchKernelGGL(egx_regressor3_kernel<false>, dim3(egx_ceil_div(M, R3_ROWS)), dim3(512), R3_LDS, st, w, Y, betas, A, M, out_Yb);
+  hipLaunchKernelGGL(egx_regressor3_kernel<NRT>, dim3(egx_ceil_div(M, 16 * NRT)), dim3(512), r3_lds(NRT), st, w, Y, betas, A, M, out_Yb);
   return EGX_OK;
+}
+}  // namespace
+
+// Rows per workgroup: a workgroup's time hardly depends on how many of the chip's CUs are busy, so a batch that does not fill
+// 256 CUs with 48-row workgroups takes fewer rows per workgroup (9216 rows = 512 agents: 192 x 48; 4608: 144 x 32; <= 4096
+// rows: 16 each).  EGX_R3_ROWTILES = 1..3 forces the tile count (tests run every variant on small batches).
+int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, const float* betas, int A, int M, float* out_Yb) {
+  static const int forced = [] { const char* e = getenv("EGX_R3_ROWTILES"); return (e && *e) ? atoi(e) : 0; }();
+  const int nrt = forced >= 1 && forced <= 3 ? forced : std::min(3, std::max(1, egx_ceil_div(M, 16 * 256)));
+  switch (nrt) {
+    case 1: return r3_launch<1>(st, w, Y, betas, A, M, out_Yb);
+    case 2: return r3_launch<2>(st, w, Y, betas, A, M, out_Yb);
+    default: return r3_launch<3>(st, w, Y, betas, A, M, out_Yb);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------

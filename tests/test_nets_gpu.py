@@ -99,6 +99,32 @@ def test_sample_prior_matches_oracle():
     assert max_abs(Yb.cpu()[..., 69:], Ybo[..., 69:]) < 2e-4 * max(1.0, float(Ybo[..., 69:].abs().max()))
 
 
+def test_regressor_row_tile_variants_agree(tmp_path):
+    """The fused regressor takes 16, 32 or 48 rows per workgroup depending on the batch (csrc/dense3.hip, egx_launch_regressor3);
+    an element's arithmetic does not depend on that, so the three variants (forced with EGX_R3_ROWTILES, one process each: the
+    switch is read once) give bit-identical parameters on a ragged batch."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from egogen_amd import setup_world as sw\n"
+        "prior = sw.build_motion_prior(seed=0)\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "A = 53\n"
+        "X = (torch.randn(2, A, 201, generator=g) * 0.3).cuda(); z = torch.randn(A, 128, generator=g).cuda(); b = torch.randn(A, 10, generator=g).cuda()\n"
+        "Y, Yb = prior.sample_prior(X, b[None].repeat(18, 1, 1), z)\n"
+        "np.save(sys.argv[1], Yb.cpu().numpy())\n" % root)
+    outs = []
+    for nrt in (1, 2, 3):
+        f = str(tmp_path / f"yb{nrt}.npy")
+        env = dict(os.environ, EGX_R3_ROWTILES=str(nrt))
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=env, cwd=root, timeout=600)
+        outs.append(np.load(f))
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[2])
+
+
 @pytest.mark.parametrize("prec", [0, 2])
 def test_policy_matches_reference_golden(prec):
     """egx_policy_forward against the outputs of the reference's own GAMMAPolicyBase / Actor / Critic (policy_ref.npz), in the
