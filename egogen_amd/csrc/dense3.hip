@@ -843,16 +843,16 @@ int egx_launch_regressor3(hipStream_t st, const RegWeights3& w, const float* Y, 
 //     borrow it once y2 is consumed.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int VP_ROWS = 48;
-constexpr size_t VP_LDS = (size_t)3 * 16 * 3 * 64 * 16;   // 147 456 B
+constexpr size_t vp_lds(int nrt) { return (size_t)nrt * 16 * 3 * 64 * 16; }   // 48 KiB per 16-row tile: 147 456 B at NRT = 3
 
 // values v[rt][r] of column tile `ct16` (16 columns: 32-wide k-step ct16 >> 1, half ct16 & 1) -> packed planes in `ybuf`
-__device__ __forceinline__ void vp_store_packed(const float (&v)[3][4], bf16x8* ybuf, int ct16, int lane) {
+template <int NRT>
+__device__ __forceinline__ void vp_store_packed(const float (&v)[NRT][4], bf16x8* ybuf, int ct16, int lane) {
   typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
   const int g = lane >> 4;
   char* o = reinterpret_cast<char*>(ybuf + (size_t)((ct16 >> 1) * 3) * 64 + 16 * (2 * (ct16 & 1) + (g >> 1)) + (lane & 15)) + 8 * (g & 1);
 #pragma unroll
-  for (int rt = 0; rt < 3; ++rt) {
+  for (int rt = 0; rt < NRT; ++rt) {
     float r[4];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -868,8 +868,8 @@ __device__ __forceinline__ void vp_store_packed(const float (&v)[3][4], bf16x8* 
   }
 }
 // acc[ct][rt] += (a[rt] . w[ct])^T, product-major
-template <int NCT>
-__device__ __forceinline__ void vp_mma(const bf16x8 (&a)[3][3], const bf16x8 (&wf)[NCT][3], f32x4 (&acc)[NCT][3]) {
+template <int NCT, int NRT>
+__device__ __forceinline__ void vp_mma(const bf16x8 (&a)[NRT][3], const bf16x8 (&wf)[NCT][3], f32x4 (&acc)[NCT][NRT]) {
 #pragma unroll
   for (int pr = 0; pr < 6; ++pr) {
     const int pa = (pr == 0) ? 1 : (pr == 1) ? 0 : (pr == 2) ? 2 : (pr == 3) ? 0 : (pr == 4) ? 1 : 0;
@@ -877,22 +877,22 @@ __device__ __forceinline__ void vp_mma(const bf16x8 (&a)[3][3], const bf16x8 (&w
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt) acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][pb], a[rt][pa], acc[ct][rt], 0, 0, 0);
+      for (int rt = 0; rt < NRT; ++rt) acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][pb], a[rt][pa], acc[ct][rt], 0, 0, 0);
   }
 }
 __device__ __forceinline__ float vp_lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
 }  // namespace
 
-template <int TRIP>
+template <int TRIP, int NRT>
 __global__ __launch_bounds__(512) void egx_vposer3_kernel(VpWeights3 w, const float* __restrict__ X, int x_ld, int n,
                                                           float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char vp_smem[];
   bf16x8* ybuf = reinterpret_cast<bf16x8*>(vp_smem);   // [3 row tiles][16 k-steps][3 planes][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4;
-  const int m0 = blockIdx.x * VP_ROWS;
+  const int m0 = blockIdx.x * 16 * NRT;
   // ---- packed input rows: 3 row tiles x 2 k-steps (63 -> 64 columns), one fragment per wave 0..5, at the head of ybuf
-  if (wave < 6) {
+  if (wave < 2 * NRT) {
     const int rt = wave >> 1, s = wave & 1;
     const int row = min(m0 + 16 * rt + (lane & 15), n - 1), k0 = 32 * s + 8 * g;
     float x[8];
@@ -905,11 +905,11 @@ __global__ __launch_bounds__(512) void egx_vposer3_kernel(VpWeights3 w, const fl
   }
   __syncthreads();
   // ---- fc1: 64 -> 512
-  f32x4 acc[4][3];
+  f32x4 acc[4][NRT];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) acc[ct][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < NRT; ++rt) acc[ct][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     bf16x8 wf[2][4][3];
 #pragma unroll
@@ -920,31 +920,31 @@ __global__ __launch_bounds__(512) void egx_vposer3_kernel(VpWeights3 w, const fl
         for (int p = 0; p < 3; ++p) wf[s][ct][p] = w.fc1[((size_t)((4 * wave + ct) * 2 + s) * 3 + p) * 64 + lane];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 a[3][3];
+      bf16x8 a[NRT][3];
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt)
+      for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int p = 0; p < 3; ++p) a[rt][p] = ybuf[((rt * 2 + s) * 3 + p) * 64 + lane];
-      vp_mma<4>(a, wf[s], acc);
+      vp_mma<4, NRT>(a, wf[s], acc);
     }
   }
   __syncthreads();   // the input fragments are consumed: y1 may overwrite them
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
     const f32x4 b = *reinterpret_cast<const f32x4a1*>(w.b1 + 64 * wave + 16 * ct + 4 * g);
-    float v[3][4];
+    float v[NRT][4];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[rt][r] = vp_lrelu(acc[ct][rt][r] + b[r]);
-    vp_store_packed(v, ybuf, 4 * wave + ct, lane);
+    vp_store_packed<NRT>(v, ybuf, 4 * wave + ct, lane);
   }
   __syncthreads();
   // ---- fc2: 512 -> 512, the weights in bursts of TRIP k-steps
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) acc[ct][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < NRT; ++rt) acc[ct][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int s0 = 0; s0 < 16; s0 += TRIP) {
     bf16x8 wf[TRIP][4][3];
 #pragma unroll
@@ -961,12 +961,12 @@ __global__ __launch_bounds__(512) void egx_vposer3_kernel(VpWeights3 w, const fl
 #pragma unroll
     for (int u = 0; u < TRIP; ++u) {
       if (s0 + u < 16) {
-        bf16x8 a[3][3];
+        bf16x8 a[NRT][3];
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
+        for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
           for (int p = 0; p < 3; ++p) a[rt][p] = ybuf[((rt * 16 + s0 + u) * 3 + p) * 64 + lane];
-        vp_mma<4>(a, wf[u], acc);
+        vp_mma<4, NRT>(a, wf[u], acc);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -983,51 +983,53 @@ __global__ __launch_bounds__(512) void egx_vposer3_kernel(VpWeights3 w, const fl
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
     const f32x4 b = *reinterpret_cast<const f32x4a1*>(w.b2 + 64 * wave + 16 * ct + 4 * g);
-    float v[3][4];
+    float v[NRT][4];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[rt][r] = vp_lrelu(acc[ct][rt][r] + b[r]);
-    vp_store_packed(v, ybuf, 4 * wave + ct, lane);
+    vp_store_packed<NRT>(v, ybuf, 4 * wave + ct, lane);
   }
   __syncthreads();
   // ---- mu: 512 -> 32, wave w reduces over k-steps 2 w, 2 w + 1 (its own columns of y2)
-  f32x4 am[2][3];
+  f32x4 am[2][NRT];
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) am[jt][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < NRT; ++rt) am[jt][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    bf16x8 a[3][3];
+    bf16x8 a[NRT][3];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
       for (int p = 0; p < 3; ++p) a[rt][p] = ybuf[((rt * 16 + 2 * wave + u) * 3 + p) * 64 + lane];
-    vp_mma<2>(a, wmu[u], am);
+    vp_mma<2, NRT>(a, wmu[u], am);
   }
   __syncthreads();   // y2 is consumed: the partial sums borrow the buffer
-  float* red = reinterpret_cast<float*>(vp_smem);   // [8 waves][24][64]
+  float* red = reinterpret_cast<float*>(vp_smem);   // [8 waves][8 NRT][64]
+  constexpr int NQ = 8 * NRT;
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(wave * 24 + (jt * 3 + rt) * 4 + r) * 64 + lane] = am[jt][rt][r];
+      for (int r = 0; r < 4; ++r) red[(wave * NQ + (jt * NRT + rt) * 4 + r) * 64 + lane] = am[jt][rt][r];
   __syncthreads();
-  for (int idx = tid; idx < 24 * 64; idx += 512) {
+  for (int idx = tid; idx < NQ * 64; idx += 512) {
     const int q = idx >> 6, l = idx & 63;
-    float v = ((red[(0 * 24 + q) * 64 + l] + red[(1 * 24 + q) * 64 + l]) + (red[(2 * 24 + q) * 64 + l] + red[(3 * 24 + q) * 64 + l])) +
-              ((red[(4 * 24 + q) * 64 + l] + red[(5 * 24 + q) * 64 + l]) + (red[(6 * 24 + q) * 64 + l] + red[(7 * 24 + q) * 64 + l]));
-    const int jt = q / 12, rt = (q >> 2) % 3, r = q & 3;
+    float v = ((red[(0 * NQ + q) * 64 + l] + red[(1 * NQ + q) * 64 + l]) + (red[(2 * NQ + q) * 64 + l] + red[(3 * NQ + q) * 64 + l])) +
+              ((red[(4 * NQ + q) * 64 + l] + red[(5 * NQ + q) * 64 + l]) + (red[(6 * NQ + q) * 64 + l] + red[(7 * NQ + q) * 64 + l]));
+    const int jt = q / (4 * NRT), rt = (q >> 2) % NRT, r = q & 3;
     const int row = m0 + 16 * rt + (l & 15), j = 16 * jt + 4 * (l >> 4) + r;
     if (row < n) out[(size_t)row * 32 + j] = v + w.bmu[j];
   }
 }
 
-int egx_launch_vposer3(hipStream_t st, const VpWeights3& w, const float* x, int x_ld, int n, float* out) {
-  // bursts of 2 k-steps: 40.5 us for 10 240 rows (1: 41.6, 3: 42.1; the three fp32-MFMA launches this replaces: 126)
-  {  // 144 KiB of dynamic LDS: above the 64 KiB default cap; raised once per device
+namespace {
+template <int NRT>
+int vp_launch(hipStream_t st, const VpWeights3& w, const float* x, int x_ld, int n, float* out) {
+  if (vp_lds(NRT) > 64 * 1024) {  // dynamic LDS above the 64 KiB default cap: raised once per device
     static std::mutex mu;
     static bool attr_set[64] = {false};
     int dev = 0;
@@ -1035,12 +1037,26 @@ int egx_launch_vposer3(hipStream_t st, const VpWeights3& w, const float* x, int 
     EGX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
     std::lock_guard<std::mutex> lk(mu);
     if (!attr_set[dev]) {
-      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_vposer3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VP_LDS));
+      EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(egx_vposer3_kernel<2, NRT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)vp_lds(NRT)));
       attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL(egx_vposer3_kernel<2>, dim3(egx_ceil_div(n, VP_ROWS)), dim3(512), VP_LDS, st, w, x, x_ld, n, out);
+  hipLaunchKernelGGL((egx_vposer3_kernel<2, NRT>), dim3(egx_ceil_div(n, 16 * NRT)), dim3(512), vp_lds(NRT), st, w, x, x_ld, n, out);
   return EGX_OK;
+}
+}  // namespace
+
+// bursts of 2 k-steps: 40.5 us for 10 240 rows (1: 41.6, 3: 42.1; the three fp32-MFMA launches this replaces: 126).  Rows per
+// workgroup as for the regressor: 48 when that fills the chip, 32 / 16 for smaller batches (EGX_VP_ROWTILES forces 1..3).
+int egx_launch_vposer3(hipStream_t st, const VpWeights3& w, const float* x, int x_ld, int n, float* out) {
+  static const int forced = [] { const char* e = getenv("EGX_VP_ROWTILES"); return (e && *e) ? atoi(e) : 0; }();
+  const int nrt = forced >= 1 && forced <= 3 ? forced : std::min(3, std::max(1, egx_ceil_div(n, 16 * 256)));
+  switch (nrt) {
+    case 1: return vp_launch<1>(st, w, x, x_ld, n, out);
+    case 2: return vp_launch<2>(st, w, x, x_ld, n, out);
+    default: return vp_launch<3>(st, w, x, x_ld, n, out);
+  }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------

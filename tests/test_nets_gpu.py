@@ -180,6 +180,26 @@ def test_vposer_encoder_matches_oracle(n):
     assert torch.equal(out2, out)
 
 
+def test_vposer_row_tile_variants_agree(tmp_path):
+    """egx_vposer3_kernel with 16, 32 or 48 rows per workgroup (EGX_VP_ROWTILES, read once per process): bit-identical output."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from egogen_amd import setup_world as sw\n"
+        "vp = sw.build_vposer(seed=0)\n"
+        "x = (torch.randn(1001, 63, generator=torch.Generator().manual_seed(3)) * 0.3).cuda()\n"
+        "np.save(sys.argv[1], vp.encode_mean(x).cpu().numpy())\n" % root)
+    outs = []
+    for nrt in (1, 2, 3):
+        f = str(tmp_path / f"vp{nrt}.npy")
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=dict(os.environ, EGX_VP_ROWTILES=str(nrt)), cwd=root, timeout=600)
+        outs.append(np.load(f))
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[2])
+
+
 def test_policy_bf16_mode_is_close_to_fp32_and_restorable():
     """BASELINE config 5: bf16 operands / fp32 accumulate in the policy's dense layers.  Parity is statistical (SURVEY 8(d)
     C5): over 256 observations the outputs stay within bf16 round-off of the fp32 policy, and switching back restores the
