@@ -85,7 +85,10 @@ def get_args():
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="time cap of each secondary CPU-baseline leg")
     p.add_argument("--cpu-repeats", type=int, default=3, help="repeats of the headline CPU leg (min / median reported)")
     p.add_argument("--cpu-agent-steps", type=int, default=200, help="agent-steps of each sequential CPU-baseline leg (or the time cap)")
-    p.add_argument("--extra-configs", type=int, default=1, help="N = 1: also time configs[2] and the reference-default shape")
+    p.add_argument("--extra-configs", type=int, default=1,
+                   help="N = 1: 1 = also time configs[2], the strictly fp32-equivalent arithmetic and the reference-default shape (scalars of "
+                        "the stdout line); 2 = secondary shapes as well (detail file only); 0 = none")
+    p.add_argument("--detail-file", type=str, default="bench_detail.json", help="full record (sidecar of the <= 4 KB stdout line); '' = none")
     p.add_argument("--graph", type=int, default=0, help="capture the env step into a HIP graph")
     p.add_argument("--update-graph", type=int, default=1, help="replay the PPO minibatch update as HIP graphs")
     return p.parse_args()
@@ -282,6 +285,51 @@ def _baseline_config_name(args, world):
     else:
         k = "BASELINE configs[0] scene (room0-shaped SDF) in the batched loop"
     return k
+
+
+LINE_BUDGET = 4096     # bytes of the ONE stdout line (the driver keeps a bounded tail of stdout: round 4's 21 KB line did not parse)
+
+
+def _r(x, nd=4):
+    return None if x is None else (round(float(x), nd) if isinstance(x, (float, np.floating)) else x)
+
+
+def compact_line(full):
+    """The ONE JSON line of the bench contract, self-sufficient and below LINE_BUDGET bytes: headline metric, config, the
+    dominant kernel's roofline, the CPU baseline and three scalars (BASELINE configs[2] verbatim, the strictly
+    fp32-equivalent arithmetic, the reference-default shape).  Everything else of `full` (secondary configurations, in-scene
+    launches, CPU legs, notes) goes to bench_detail.json and stderr."""
+    rf, cb, cfg = full.get("roofline") or {}, full.get("cpu_baseline"), full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(line["value"], 1), _r(line["ms_per_step"], 4)
+    line["config"] = {k: cfg.get(k) for k in ("workload", "agents_total", "agents_per_gpu", "scene", "vec_steps_per_collect",
+                                              "minibatch_global", "parallelism", "update_paths") if k in cfg}
+    line["roofline"] = {k: _r(rf.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+                                                      "launches", "bodies_per_launch", "flop_per_body", "products_per_fp32_product")}
+    if cb is not None:
+        line["cpu_baseline"] = {k: _r(cb.get(k), 3) for k in ("value", "unit", "cores", "kind")}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:200]
+    for k in ("value_configs2", "value_fp32_equivalent", "value_reference_shape"):
+        line[k] = _r(full.get(k), 1)
+    if full.get("regions"):
+        line["regions_ms_per_step"] = [_r(t, 4) for t in full["regions"]["ms_per_step"]]
+    ar = full.get("allreduce")
+    if ar:
+        line["allreduce"] = {k: _r(ar.get(k), 4) for k in ("bytes", "buckets", "calls_per_step", "in_loop_ms_per_step", "standalone_ms",
+                                                           "standalone_busbw_GBps")}
+    if full.get("weak"):
+        w = full["weak"]
+        line["weak"] = {"value": _r(w.get("value"), 1), "ms_per_step": _r(w.get("ms_per_step"), 4), "agents_per_gpu": w.get("agents_per_gpu"),
+                        "allreduce_in_loop_ms_per_step": _r((w.get("allreduce") or {}).get("in_loop_ms_per_step"), 4)}
+    line["precision"] = {k: v for k, v in (full.get("precision") or {}).items() if k != "note"}
+    line["detail"] = full.get("detail_file")
+    if len(json.dumps(line)) > LINE_BUDGET:      # never let an optional object cost the record
+        for k in ("precision", "weak", "regions_ms_per_step"):
+            line.pop(k, None)
+            if len(json.dumps(line)) <= LINE_BUDGET:
+                break
+    return line
 
 
 def _log(msg):
@@ -636,7 +684,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
-                     "flop_per_body": FLOP_PER_BODY, "vertices_evaluated": verts_eval, "vertices_total": bm_handle.V,
+                     "flop_per_body": FLOP_PER_BODY, "products_per_fp32_product": BLEND_PRODUCTS.get(blend), "vertices_evaluated": verts_eval, "vertices_total": bm_handle.V,
                      "peak_note": peak_note, "executed_bf16_tflops": executed,
                      "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene, "in_scene_penetrating": penetrating,
                      "culling": {"model_allows": bool(bm_handle.culls), "reference_margin_m": bm_handle.cull_reference_margin,
@@ -659,44 +707,39 @@ def main():
         torch.cuda.empty_cache()
     if world == 1 and args.extra_configs and args.scene == "single_box" and args.agents == 512:
         # each extra configuration in a fresh process (a second environment + policy inside this one measurably disturbs the
-        # timing: allocator state, captured graphs of the first policy)
+        # timing: allocator state, captured graphs of the first policy).  --extra-configs 1 (default): the three whose values
+        # are scalars of the stdout line; 2: the secondary ones as well (detail file only)
+        first = (("value_configs2", "BASELINE configs[2]: 512 agents, random-box scene set (walkability-map penetration term)", ["--scene", "box"]),
+                 ("value_fp32_equivalent", "headline workload, STRICTLY fp32-equivalent arithmetic everywhere (LBS blend, PPO update and rollout "
+                  "policy on three-term bf16 splits: 2^-24 per product)", ["--lbs-blend", "bf16x3", "--update-prec", "f32", "--policy-prec", "f32"]),
+                 ("value_reference_shape", "reference default shape: 256 agents, 1024 transitions per collect, single-box SDF scene", ["--agents", "256"]))
+        second = ((None, "per-rank shape of the 4-way strong split (configs[3] at N = 4): 128 agents, 64-sample minibatch",
+                   ["--agents", "128", "--batch-size", "64"]),
+                  (None, "per-rank shape of the 8-way strong split (configs[3] at N = 8): 64 agents, 32-sample minibatch",
+                   ["--agents", "64", "--batch-size", "32"]),
+                  (None, "headline workload with the policy's dense layers (rollout + update) on bf16 operands: north_star's 'bf16 MFMA'",
+                   ["--update-prec", "bf16", "--policy-prec", "bf16"]),
+                  (None, "headline workload on a synthetic body with 12 skinning weights per vertex (real SMPL-X has 4..~12)", ["--skin-weights", "12"]))
         others = []
-        for label, flags in (("BASELINE configs[2]: 512 agents, random-box scene set (walkability-map penetration term)", ["--scene", "box"]),
-                             ("reference default shape: 256 agents, 1024 transitions per collect, single-box SDF scene", ["--agents", "256"]),
-                             ("per-rank shape of the 4-way strong split (configs[3] at N = 4): 128 agents, 64-sample minibatch",
-                              ["--agents", "128", "--batch-size", "64"]),
-                             ("per-rank shape of the 8-way strong split (configs[3] at N = 8): 64 agents, 32-sample minibatch",
-                              ["--agents", "64", "--batch-size", "32"]),
-                             ("headline workload, STRICTLY fp32-equivalent arithmetic everywhere (LBS blend, PPO update and rollout policy on "
-                              "three-term bf16 splits: 2^-24 per product)", ["--lbs-blend", "bf16x3", "--update-prec", "f32", "--policy-prec", "f32"]),
-                             ("headline workload with the policy's dense layers (rollout + update) on bf16 operands: north_star's 'bf16 MFMA' "
-                              "(gradients ~1-4 % from float64, profiles/r04_p3_yardstick.txt)", ["--update-prec", "bf16", "--policy-prec", "bf16"]),
-                             ("headline workload on a synthetic body with 12 skinning weights per vertex (real SMPL-X has 4..~12)",
-                              ["--skin-weights", "12"]),
-                             ("headline workload on the STRUCTURED synthetic body (smooth shape fields, local pose correctives - the statistics "
-                              "of a learned model), SDF work items in provably free space culled (opt-in, results bit-identical): see lbs_in_scene for the launch "
-                              "with agents standing in the room - in the timed loop the random-init policy's bodies leave the room and nothing "
-                              "can be skipped", ["--body", "structured", "--lbs-cull", "1"]),
-                             ("the same structured body without the culling", ["--body", "structured"])):
+        for key, label, flags in first + (second if args.extra_configs >= 2 else ()):
             cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--extra-configs", "0", "--steps", str(args.steps),
                    "--warmup", str(args.warmup), "--num-verts", str(args.num_verts), "--sdf-res", str(args.sdf_res),
-                   "--vec-steps", str(args.vec_steps), "--batch-size", str(args.batch_size)] + flags
+                   "--vec-steps", str(args.vec_steps), "--batch-size", str(args.batch_size), "--detail-file", ""] + flags
             try:
-                out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, stdin=subprocess.DEVNULL)
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
                 line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
                 r2 = json.loads(line)
                 others.append({"workload": label, "value": r2["value"], "unit": r2["unit"], "ms_per_step": r2["ms_per_step"],
-                               "regions": r2.get("regions"), "lbs_avg_launch_ms": r2["roofline"]["avg_launch_ms"],
+                               "regions_ms_per_step": r2.get("regions_ms_per_step"), "lbs_avg_launch_ms": r2["roofline"]["avg_launch_ms"],
                                "lbs_frac": r2["roofline"]["frac"], "lbs_peak": r2["roofline"]["peak"], "steps": r2["steps"],
-                               "precision": r2.get("precision"), "lbs_culling": r2["roofline"].get("culling"),
-                               "lbs_in_scene": r2["roofline"].get("in_scene"), "command": " ".join(cmd[1:])})
-                if "--scene" in flags and "box" in flags:   # BASELINE configs[2] verbatim: a first-class record, not a footnote
-                    result["configs2"] = {k: r2[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "regions",
-                                                             "dtype", "data", "config", "precision") if k in r2}
-                    result["configs2"]["lbs"] = {k: r2["roofline"][k] for k in ("kernel", "avg_launch_ms", "achieved", "peak", "frac",
-                                                                                "vertices_evaluated", "vertices_total")}
+                               "precision": r2.get("precision"), "config": r2.get("config"), "dtype": r2.get("dtype"),
+                               "command": " ".join(cmd[1:])})
+                if key:
+                    result[key] = r2["value"]
+                _log(f"extra config done: {label[:60]}: {r2['value']:.0f} env-steps/s")
             except Exception as e:
                 others.append({"workload": label, "value": None, "error": f"{type(e).__name__}: {e}"})
+                _log(f"extra config FAILED: {label[:60]}: {type(e).__name__}: {e}")
         result["other_configs"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _log("cpu baseline ...")
@@ -706,7 +749,20 @@ def main():
             result["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
                                       "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        detail = args.detail_file
+        result["detail_file"] = os.path.basename(detail) if detail else None
+        if detail:      # the full record (secondary configurations, in-scene launches, CPU legs, notes): a sidecar, never stdout
+            try:
+                with open(detail if os.path.isabs(detail) else os.path.join(ROOT, detail), "w") as f:
+                    json.dump(result, f, indent=1)
+            except OSError as e:
+                _log(f"could not write {detail}: {e}")
+            for k in ("roofline", "cpu_baseline", "other_configs"):
+                if result.get(k) is not None:
+                    _log(f"detail {k}: " + json.dumps(result[k]))
+        line = json.dumps(compact_line(result))
+        assert len(line) <= LINE_BUDGET, len(line)
+        print(line, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -58,3 +58,40 @@ def test_missing_config_raises(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     with pytest.raises(FileNotFoundError):
         sw.load_model(cfg_dir=str(tmp_path / "nowhere"))
+
+
+def test_bench_stdout_line_fits_the_drivers_tail():
+    """Round 4's bench line grew to 21 KB and the driver's stdout tail cut its head off (BENCH_r04.json parsed = null).  The
+    stdout line is now built by bench.compact_line from the full record: held below 4 KB here on round 4's own full record
+    (profiles/r04_final_bench.json, the 21 KB case) and on a multi-rank stub, with every contract field present."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r04_final_bench.json")))
+    assert len(json.dumps(full)) > 8192          # the record that did not parse
+    full["value_configs2"], full["value_fp32_equivalent"], full["value_reference_shape"] = 252654.1, 128053.2, 139300.3
+    full["detail_file"] = "bench_detail.json"
+    for world in (1, 8):
+        if world > 1:
+            full["n_gpus"] = world
+            full["allreduce"] = {"bytes": 52672004, "buckets": 2, "calls_per_step": 8, "in_loop_avg_ms": 0.5, "in_loop_ms_per_step": 4.0,
+                                 "standalone_ms": 0.4, "standalone_algbw_GBps": 130.0, "standalone_busbw_GBps": 228.0, "note": "x" * 300}
+            full["weak"] = {"value": 1.2e6, "unit": "env-steps/s", "ms_per_step": 13.0, "agents_per_gpu": 512, "minibatch_per_gpu": 256,
+                            "allreduce": dict(full["allreduce"]), "update_paths": {"chain+graph": 48}}
+        line = bench.compact_line(full)
+        text = json.dumps(line)
+        assert len(text) < bench.LINE_BUDGET <= 4096, len(text)
+        back = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "value_configs2", "value_fp32_equivalent", "value_reference_shape"):
+            assert k in back, k
+        assert back["config"]["workload"] and "model" not in back["config"]
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "bodies_per_launch", "flop_per_body"):
+            assert k in back["roofline"], k
+        assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in back["cpu_baseline"], k
+        assert back["value"] == round(full["value"], 1)
+        if world > 1:
+            assert back["allreduce"]["in_loop_ms_per_step"] == 4.0 and back["weak"]["value"] == 1.2e6
