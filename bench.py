@@ -304,7 +304,7 @@ def compact_line(full):
                                      "scaling", "vs_baseline", "dtype", "data")}
     line["value"], line["ms_per_step"] = _r(line["value"], 1), _r(line["ms_per_step"], 4)
     line["config"] = {k: cfg.get(k) for k in ("workload", "agents_total", "agents_per_gpu", "scene", "vec_steps_per_collect",
-                                              "minibatch_global", "parallelism", "update_paths") if k in cfg}
+                                              "minibatch_global", "parallelism", "hip_graph_update", "update_paths") if k in cfg}
     line["roofline"] = {k: _r(rf.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
                                                       "launches", "bodies_per_launch", "flop_per_body", "products_per_fp32_product")}
     if cb is not None:

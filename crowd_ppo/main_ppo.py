@@ -28,8 +28,9 @@ SCENE_DEFAULT = "room0"
 CFG_NAME = "MPVAEPolicy_samp_collision"
 
 
-def get_args(argv=None, extra=()):
-    """`extra`: [(flag, add_argument kwargs)] of a sibling driver (main_egobody_eval.py)."""
+def get_args(argv=None, extra=(), defaults=None):
+    """`extra`: [(flag, add_argument kwargs)] of a sibling driver (main_egobody_eval.py, main_ppo_box.py); `defaults`: the
+    sibling's own default values for flags of this table."""
     p = argparse.ArgumentParser()
     p.add_argument("--task", type=str, default="collision-avoidance")
     p.add_argument("--seed", type=int, default=0)
@@ -82,6 +83,8 @@ def get_args(argv=None, extra=()):
     p.add_argument("--num-scenes", type=int, default=None, help="main_crowd_eval.py: independent 4-human scenes per GPU")
     for flag, kw in extra:
         p.add_argument(flag, **kw)
+    if defaults:
+        p.set_defaults(**defaults)
     return p.parse_args(argv)
 
 

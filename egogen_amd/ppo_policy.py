@@ -37,7 +37,9 @@ class RunningMeanStd:
 
     def update(self, x) -> None:
         x = np.asarray(x, np.float64).reshape(-1)
-        bm, bv, bc = float(x.mean()), float(x.var()), x.size
+        self.update_from_moments(float(x.mean()), float(x.var()), x.size)
+
+    def update_from_moments(self, bm: float, bv: float, bc) -> None:
         delta = bm - self.mean
         tot = self.count + bc
         new_mean = self.mean + delta * bc / tot
@@ -192,9 +194,19 @@ class GAMMAPPOPolicy(nn.Module):
                          float(self._lambda), _lib.ptr(batch.returns), _lib.ptr(batch.adv), _lib.current_stream_ptr())
         _lib.check(rc, "egx_gae")
         if self._rew_norm:   # :131-133 (one host round trip per collect, like the reference's numpy statistics)
-            unnorm = batch.returns.detach().double().cpu().numpy()
+            unnorm = batch.returns.detach().double()
             batch.returns.div_(scale)
-            self.ret_rms.update(unnorm)
+            if self._dp:
+                # one critic is shared by all ranks (gradients are all-reduced): its target scale must be the same everywhere, so
+                # the running statistics take the moments of ALL ranks' returns (tianshou keeps them per process)
+                mom = torch.stack([unnorm.sum(), (unnorm * unnorm).sum(), torch.tensor(float(unnorm.numel()), dtype=torch.float64,
+                                                                                       device=unnorm.device)])
+                dist.all_reduce(mom)
+                s1, s2, cnt = (float(v) for v in mom.cpu())
+                mean = s1 / cnt
+                self.ret_rms.update_from_moments(mean, max(0.0, s2 / cnt - mean * mean), cnt)
+            else:
+                self.ret_rms.update(unnorm.cpu().numpy())
         return batch
 
     # ---- update side (autograd) ---------------------------------------------------------------------
@@ -671,6 +683,11 @@ class GAMMAPPOPolicy(nn.Module):
             if self._recompute_adv and step > 0:    # ppo_policy.py:185-186: values of ALL observations with the current weights
                 self._recomputing = True
                 try:
+                    # replayed update graphs write the parameters by address (no tensor version changes, and the
+                    # mark_dirty() inside _clip_and_step ran at capture time only): the packed images the value pass
+                    # reads must be re-made from the CURRENT weights first
+                    self._runner.mark_dirty()
+                    self._refresh_images()
                     self.process_fn(batch)
                 finally:
                     self._recomputing = False
@@ -715,6 +732,9 @@ class GAMMAPPOPolicy(nn.Module):
                 if float(kl.item()) >= 0.02:
                     break
         self._runner.mark_dirty()   # replayed graphs update the parameters by address: re-pack before the next rollout forward
+        # a captured refresh writes the planes of the precision in force at capture time; one eager refresh here writes those of
+        # the precision in force NOW (e.g. egx_policy_set_precision(0) for an fp32 evaluation after bf16x2 training)
+        self._refresh_images()
         if logs:
             L = torch.stack(logs)
             if dp:

@@ -275,7 +275,7 @@ def _box_sdf(p, lo, hi):
     return outside + inside
 
 
-def make_sdf_scene(res: int = 256, room: str = "single_box", seed: int = 0) -> Dict[str, np.ndarray]:
+def make_sdf_scene(res: int = 256, room: str = "single_box", seed: int = 0, obstacle=None) -> Dict[str, np.ndarray]:
     """Analytic SDF grid with the reference's storage convention (crowd_ppo/utils.py:54-84):
     grid value > 0 inside obstacles / outside the room, < 0 in free space, so that
     calc_sdf() = -trilinear(grid) is negative where a vertex penetrates.  Grid is indexed
@@ -305,6 +305,8 @@ def make_sdf_scene(res: int = 256, room: str = "single_box", seed: int = 0) -> D
         room_hi = np.array([3.9, 3.9, 4.9])
         obs_lo = np.array([1.0, -0.5, 0.0])
         obs_hi = np.array([2.0, 0.5, 1.0])
+    if obstacle is not None:                    # (lo[3], hi[3]): the obstacle somewhere else (tests: a box on an agent)
+        obs_lo, obs_hi = np.asarray(obstacle[0], np.float64), np.asarray(obstacle[1], np.float64)
     d_room = _box_sdf(P, room_lo, room_hi)      # <0 inside the room
     d_obs = _box_sdf(P, obs_lo, obs_hi)         # <0 inside the obstacle
     free = np.maximum(d_room, -d_obs)           # <0 in free space

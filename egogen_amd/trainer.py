@@ -212,7 +212,20 @@ def onpolicy_trainer(policy: GAMMAPPOPolicy, train_collector: Collector, test_co
     env_step, gradient_step = 0, 0
     best_reward, best_epoch = -float("inf"), 0
     t_start = time.time()
+    # tianshou's BaseTrainer.reset [upstream] (the trainer main_ppo.py:221-235 calls): one evaluation BEFORE epoch 1 fixes
+    # best_reward / best_epoch = 0, and save_best_fn is called once so that policy.pth exists from the start
+    if test_collector is not None:
+        policy.eval()
+        r0 = test_collector.collect_episodes(episode_per_test)
+        best_reward, best_epoch = r0["rew"], 0
+        if logger is not None and rank == 0:
+            logger.write("test", 0, {"reward": r0["rew"], "length": r0["len"]})
+        if verbose and rank == 0:
+            print(f"Epoch #0: test_reward: {r0['rew']:.6f}", flush=True)
+    if save_best_fn is not None and rank == 0:
+        save_best_fn(policy)
     train_collector.reset()
+    forced_seen = 0
     for epoch in range(1, max_epoch + 1):
         policy.train()
         steps_in_epoch = 0
@@ -246,6 +259,18 @@ def onpolicy_trainer(policy: GAMMAPPOPolicy, train_collector: Collector, test_co
                     save_best_fn(policy)
         if save_checkpoint_fn is not None and rank == 0 and epoch % save_interval == 0:
             save_checkpoint_fn(epoch, env_step, gradient_step)
+        # box scenes: an agent none of whose reset draws passed the start check starts in penetration (the reference's
+        # `while True` loop, crowd_env_2f_box.py:349-416, would still be drawing): say so, once per epoch (one host sync)
+        fa = getattr(train_collector.env, "forced_accepts", None)
+        if fa is not None:
+            n_forced = fa()
+            if n_forced > forced_seen:
+                import warnings
+                warnings.warn(f"epoch {epoch}: {n_forced - forced_seen} episode(s) started without a valid start among their reset draws "
+                              f"({n_forced} since construction)")
+                if logger is not None and rank == 0:
+                    logger.write("train", env_step, {"forced_accepts": float(n_forced)})
+                forced_seen = n_forced
         if verbose and rank == 0:
             msg = f"Epoch #{epoch}: env_step {env_step}, gradient_step {gradient_step}"
             if result is not None:

@@ -1,0 +1,432 @@
+#!/usr/bin/env python3
+"""Golden vectors of the ENVIRONMENT COMPOSITE and of the PPO update, produced by EXECUTING the reference's own code
+(build container only - /root/reference does not exist on the GPU box):
+
+  crowd_ppo/crowd_env_2f.py::CrowdEnv.reset (:320-415) / .step (:78-317)            -> env_step_ref.npz   (`sdf`)
+  crowd_ppo/crowd_env_2f_box.py::CrowdEnv.reset (:342-431) / .step (:78-340)        -> env_box_ref.npz    (`box`)
+  exp_GAMMAPrimitive/utils/environments.py::BatchGeneratorScene2frameTrain.next_body (:65-335) and
+      BatchGeneratorScene2frameTrainBox.next_body (:371-627)                         (inside the two resets)
+  models/baseops.py::SMPLXParser (forward_smplx / get_new_coordinate / update_transl_glorot / calc_calibrate_offset)
+  models/models_GAMMA_primitive.py::GAMMAPrimitiveCombo.sample_prior                (the reference classes, seeded weights)
+  crowd_ppo/ppo_policy.py::GAMMAPPOPolicy.learn (:182-265)                          -> ppo_learn_ref.npz  (`learn`)
+
+What is substituted, and by what (the packages are absent from this image):
+  smplx.create(...)                      -> adapter around oracle/smplx_lbs.py on the synthetic full-size body (V = 10 475)
+  torchgeometry.{angle_axis_to_rotation_matrix, rotation_matrix_to_angle_axis}, pytorch3d.transforms.{axis_angle_to_matrix,
+      matrix_to_axis_angle, euler_angles_to_matrix} -> oracle/rot.py's restatements of those releases
+  human_body_prior VPoser `.encode(x).loc` -> oracle/nets.py::vposer_encode on seeded weights
+  CrowdEnv._calc_egosensing (shapely)    -> oracle/env.py::calc_egosensing (the only METHOD of the env that is replaced)
+  trimesh.load / the navmesh             -> a (vertices, faces) namespace of the synthetic scene
+  tianshou.policy.PPOPolicy / Batch / to_torch_as (learn only) -> a 40-line stand-in holding the attributes `learn` reads
+  device spellings ('cuda', torch.cuda.FloatTensor, Tensor.cuda()) -> CPU
+The fixtures therefore pin the env / loss COMPOSITE's own arithmetic - reward block and its thresholds (40 vertices, 0.075,
+0.02, 11), termination, state / seed / frame bookkeeping, the sampler's rotations, the loss terms and the clip quirk - on top of
+pieces that are pinned (nets, calc_sdf, get_map, features) or restated (smplx, rotations, VPoser) elsewhere.
+
+Locals of `step` (the eight reward terms, counts, intermediate tensors) are read from its frame at the moment it calls
+`_calc_egosensing` (after the reward block) - nothing of the method is re-typed here.
+"""
+import json
+import os
+import pickle
+import random
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, ".."))
+import gen_goldens as gg  # noqa: E402
+
+REF, OUT = gg.REF, gg.OUT
+NB = 4        # n_gens_2frame: the reference replicates every env's batch x4 (crowd_env_2f.py:29)
+
+
+class AttrDict(dict):
+    """omegaconf.DictConfig as the env uses it: attribute and item access on nested dicts."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return AttrDict(v) if isinstance(v, dict) else v
+
+
+class _Out:
+    pass
+
+
+class FakeSMPLX:
+    """smplx.SMPLX call signature (keyword tensors; parameters that are not passed are the module's zero parameters of the
+    construction batch size) on the oracle LBS."""
+
+    def __init__(self, bm, batch_size):
+        self.bm, self.batch_size = bm, batch_size
+        self.faces = np.zeros((1, 3), np.int64)
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, return_verts=True, transl=None, global_orient=None, body_pose=None, betas=None, left_hand_pose=None,
+                 right_hand_pose=None, **kw):
+        from oracle.smplx_lbs import smplx_forward
+        given = [t for t in (transl, global_orient, body_pose, betas, left_hand_pose, right_hand_pose) if t is not None]
+        n = max([t.shape[0] for t in given] + [1]) if given else self.batch_size
+        if all(t.shape[0] == 1 for t in given) and given:
+            n = 1
+        if not any(t is not None for t in (transl, global_orient, body_pose)):
+            n = self.batch_size
+        xb = torch.zeros(n, 93)
+        for t, sl in ((transl, slice(0, 3)), (global_orient, slice(3, 6)), (body_pose, slice(6, 69)), (left_hand_pose, slice(69, 81)),
+                      (right_hand_pose, slice(81, 93))):
+            if t is not None:
+                xb[:, sl] = t
+        b = torch.zeros(n, 10) if betas is None else betas.reshape(-1, 10).expand(n, 10)
+        v, j = smplx_forward(self.bm, xb.to(self.bm.dtype), b.to(self.bm.dtype))
+        o = _Out()
+        o.vertices, o.joints = v.float(), j.float()
+        return o
+
+
+def _euler_xyz(euler, convention="XYZ"):
+    """pytorch3d 0.7.4 euler_angles_to_matrix [upstream]: R = R_c0(e0) R_c1(e1) R_c2(e2)."""
+    def axis_rot(axis, a):
+        c, s, o, z = torch.cos(a), torch.sin(a), torch.ones_like(a), torch.zeros_like(a)
+        flat = {"X": (o, z, z, z, c, -s, z, s, c), "Y": (c, z, s, z, o, z, -s, z, c), "Z": (c, -s, z, s, c, z, z, z, o)}[axis]
+        return torch.stack(flat, -1).reshape(a.shape + (3, 3))
+    ms = [axis_rot(c, e) for c, e in zip(convention, torch.unbind(euler, -1))]
+    return ms[0] @ ms[1] @ ms[2]
+
+
+class cpu_world(gg.cuda_to_cpu):
+    """gen_goldens.cuda_to_cpu plus Tensor.cuda() / Module.cuda() / torch.cuda.LongTensor / torch.eye(..).cuda()."""
+
+    def __enter__(self):
+        super().__enter__()
+        self._tc, self._mc, self._lt = torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.LongTensor
+        torch.Tensor.cuda = lambda t, *a, **k: t
+        torch.nn.Module.cuda = lambda m, *a, **k: m
+        torch.cuda.LongTensor = torch.LongTensor
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.LongTensor = self._tc, self._mc, self._lt
+        super().__exit__(*exc)
+
+
+def install(recorder):
+    """Stubs + substitutes (module docstring).  `recorder` collects the random draws of the samplers."""
+    from oracle import rot as orot
+    gg.install_stubs()
+    gg.install_env_stubs()
+    tgm = sys.modules["torchgeometry"]
+    tgm.rotation_matrix_to_angle_axis = lambda m: orot.tgm_rotation_matrix_to_angle_axis(m[:, :3, :3])
+    tgm.angle_axis_to_rotation_matrix = lambda aa: orot.tgm_angle_axis_to_rotation_matrix(aa)
+    p3t = sys.modules["pytorch3d.transforms"]
+    p3t.axis_angle_to_matrix = orot.p3d_axis_angle_to_matrix
+    p3t.matrix_to_axis_angle = orot.p3d_matrix_to_axis_angle
+
+    def euler(e, convention="XYZ"):
+        recorder.setdefault("euler_z", []).append(float(e.reshape(-1)[2]))
+        return _euler_xyz(e, convention)
+    p3t.euler_angles_to_matrix = euler
+    sys.modules["pytorch3d"].transforms = p3t
+    st = sys.modules["pytorch3d.structures"]
+    st.Meshes = lambda **k: None
+    sys.modules["pytorch3d"].structures = st
+    class _Space:                     # gymnasium.spaces.Box / Dict: constructed in CrowdEnv.__init__, never read afterwards
+        def __init__(self, *a, **k):
+            pass
+    sys.modules["gymnasium.spaces"].Box = sys.modules["gymnasium.spaces"].Dict = _Space
+    # names the sampler module imports from shapely at module level (never called on the paths exercised)
+    sh = sys.modules["shapely"]
+    sh.union_all = None
+    for n in ("Polygon", "Point", "MultiPoint", "mapping"):
+        setattr(sys.modules["shapely.geometry"], n, object)
+
+
+def reference_first():
+    """`crowd_ppo` names a package in this repo AND a directory of the reference: import everything of the repo that the
+    adapters need first, then take the repo root off sys.path so that `crowd_ppo.*` resolves under /root/reference/motion."""
+    import egogen_amd.synth, oracle.env, oracle.nets, oracle.rot, oracle.smplx_lbs, oracle.ppo, tests.helpers  # noqa: F401,E401
+    root = os.path.abspath(os.path.join(HERE, ".."))
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != root]
+    sys.modules.pop("crowd_ppo", None)
+    sys.path.insert(0, REF)
+
+
+def load_yaml(name):
+    import yaml
+    with open(os.path.join(REF, "crowd_ppo", "cfg_samp20", name)) as f:
+        return yaml.safe_load(f)
+
+
+PRIOR_SEED, PRIOR_GAINS = 200, (0.25, 0.25)     # a TAME seeded motion prior: the body stays within ~1 m of its start per primitive,
+# so the penetration counts live around the thresholds (the suite's default gains 0.7 / 0.6 throw it ~5 m: every count saturates)
+
+
+def build_combo(mgp):
+    """The reference's GAMMAPrimitiveCombo with seeded weights (tests/helpers.py::seeded_prior_state_dict)."""
+    from tests.helpers import seeded_prior_state_dict
+    combo_cfg = load_yaml("MPVAECombo_samp_2frame.yml")["modelconfig"]
+    pcfg = load_yaml(combo_cfg["predictor_config"] + ".yml")["modelconfig"]
+    rcfg = load_yaml(combo_cfg["regressor_config"] + ".yml")["modelconfig"]
+    combo = mgp.GAMMAPrimitiveCombo(pcfg, rcfg)
+    sd = seeded_prior_state_dict(PRIOR_SEED, *PRIOR_GAINS)
+    missing, unexpected = combo.load_state_dict(sd, strict=False)
+    assert not unexpected and all("markers" in k or "bm" in k for k in missing), (missing, unexpected)
+    combo.eval()
+    return types.SimpleNamespace(model=combo)
+
+
+class FakeVPoser:
+    def __init__(self, sd):
+        self.sd = sd
+
+    def encode(self, body_pose):
+        from oracle.nets import vposer_encode
+        return types.SimpleNamespace(loc=vposer_encode(self.sd, body_pose))
+
+
+_STEP_LOCALS = {}
+
+
+def ego_hook(self, joint):
+    """Stands in for CrowdEnv._calc_egosensing (shapely).  `step` calls it after the whole reward block (:296), so the caller's
+    frame holds every local of that block: snapshot it (sys.setprofile / settrace cannot be used - SMPLXParser.get_jts builds its
+    keyword arguments from locals(), which a trace function re-synchronises)."""
+    from oracle.env import calc_egosensing
+    fr = sys._getframe(1)
+    if fr.f_code.co_name == "step":
+        _STEP_LOCALS.clear()
+        _STEP_LOCALS.update(fr.f_locals)
+    return calc_egosensing(joint, self.scene_poly).float()
+
+
+def capture_step(env_cls, env, z):
+    """Call the reference's `step` and return (its return value, its local variables when it calls _calc_egosensing)."""
+    _STEP_LOCALS.clear()
+    ret = env.step(z)
+    return ret, dict(_STEP_LOCALS)
+
+
+def t2n(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def record_state(env, pre):
+    return {pre + "state": t2n(env.state), pre + "seed": t2n(env.body_param_seed[0]), pre + "R0": t2n(env.R0[0]), pre + "T0": t2n(env.T0[0]),
+            pre + "dist": t2n(env.dist).reshape(-1)[:1], pre + "wpath": t2n(env.body_scene_data["wpath"]), pre + "steps": np.int64(env.steps)}
+
+
+STEP_LOCALS = ("r_skate", "r_floor", "r_face_target", "r_look_target", "r_goal", "r_target_dist", "r_pene", "r_vp", "vp_norm")
+
+
+def record_step(ret, loc, env, pre, box=False):
+    obs, reward, terminated, truncated, _ = ret
+    out = {pre + "obs_state": t2n(obs["state"]), pre + "obs_ego": t2n(obs["egosensing"]), pre + "obs_dist": t2n(obs["dist"]).reshape(-1),
+           pre + "obs_time": t2n(obs["time"]).reshape(-1), pre + "reward": np.float64(reward), pre + "terminated": np.bool_(terminated),
+           pre + "truncated": np.bool_(truncated)}
+    for k in STEP_LOCALS:
+        out[pre + k] = np.float64(t2n(loc[k]).reshape(-1)[0])
+    out[pre + "penetration"] = np.bool_(loc["penetration"])
+    if box:
+        out[pre + "num_pene"] = np.float64(t2n(loc["num_pene"]).reshape(-1)[0])
+    else:
+        out[pre + "num_inside_max"] = np.int64(t2n(loc["num_inside_max"]))
+        out[pre + "pene_count"] = t2n(loc["sdf_values"].lt(0.0).sum(dim=-1)[0]).astype(np.int64)       # [20] (feet zeroed)
+        near = loc["sdf_values"][0].abs() < 2e-5        # vertices within fp32 round-off of the zero level set: their sign is not
+        near[:, env.feet_vids] = False                  # reproducible by another fp32 evaluation order (tests bound |d count| by it)
+        out[pre + "pene_near_zero"] = t2n(near.sum(-1)).astype(np.int64)
+    out[pre + "Y_gen"] = t2n(loc["Y_gen"][:, 0])                       # [18,201]
+    out[pre + "pred_params"] = t2n(loc["pred_params"][0])             # [20,93] (after _blend_params)
+    out[pre + "joints"] = t2n(loc["pred_output"].joints.reshape(NB, 20, -1, 3)[0])
+    out[pre + "marker_b"] = t2n(loc["pred_marker_b"][0])
+    out.update(record_state(env, pre + "after_"))
+    return out
+
+
+def body_and_parsers(baseops, smplx_mod, V=None):
+    from egogen_amd import synth
+    from oracle.smplx_lbs import BodyModel
+    bm = BodyModel(synth.make_body_model(0))
+    smplx_mod.create = lambda *a, batch_size=1, **k: FakeSMPLX(bm, batch_size)
+    mk = dict(device="cpu", marker_placement="ssm2_67")
+    parsers = [baseops.SMPLXParser(dict(mk, n_batch=n * NB)) for n in (1, 2, 20)]
+    return bm, parsers
+
+
+def feet_marker_idx_and_markers():
+    with open(os.path.join(REF, "data", "SSM2.json")) as f:
+        d = json.load(f)["markersets"][0]["indices"]
+    feet = ["RHEE", "RTOE", "RRSTBEEF", "LHEE", "LTOE", "LRSTBEEF"]          # main_ppo.py:296-298
+    return [list(d.keys()).index(n) for n in feet], list(d.values())
+
+
+def sdf_scene_tensors(scene):
+    return {k: torch.as_tensor(np.asarray(scene[k]), dtype=torch.float32) for k in ("sdf", "center", "scale")}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def gen_sdf():
+    from egogen_amd import synth
+    from oracle.env import calc_egosensing
+    from tests.helpers import seeded_vposer_state_dict
+    rec = {}
+    install(rec)
+    cwd = os.getcwd()
+    os.chdir(REF)       # the env / parser / sampler open data/*.json relative to motion/
+    reference_first()
+    try:
+        with cpu_world():
+            from crowd_ppo import crowd_env_2f as ce
+            from exp_GAMMAPrimitive.utils import environments as envs
+            from models import baseops, models_GAMMA_primitive as mgp
+            cfg = AttrDict(load_yaml("MPVAEPolicy_samp_collision.yaml"))
+            bm, (p1, p2, pmp) = body_and_parsers(baseops, sys.modules["smplx"])
+            fmi, markers = feet_marker_idx_and_markers()
+            assert markers == [int(v) for v in synth.marker_ids()] and fmi == list(synth.feet_marker_idx())
+            genop = build_combo(mgp)
+            vsd = {k: v.float() for k, v in seeded_vposer_state_dict().items()}
+            RES = 64
+            scene_free = synth.make_sdf_scene(RES)
+            rings = synth.sdf_scene_polygon(scene_free)
+            edges = synth.rings_to_edges(rings)
+            # the sampler, without its constructor (it loads licensed body models / the Replica navmesh)
+            sampler = object.__new__(envs.BatchGeneratorScene2frameTrain)
+            sampler.scene_list, sampler.scene_type, sampler.index_rec = None, "room_0", 0
+            from pathlib import Path
+            sampler.scene_dir = Path("data/room_0")
+            sampler.navmesh_path = sampler.scene_dir / "navmesh_tight.ply"
+            sampler.navmesh = types.SimpleNamespace(vertices=np.zeros((3, 3)), faces=np.zeros((1, 3), np.int64), visual=types.SimpleNamespace())
+            sampler.shapely_poly = edges                      # what `_calc_egosensing` (replaced below) receives as self.scene_poly
+            sampler.motion_data = np.load("data/locomotion/subseq_00343.npz")
+            sampler.bm_2frame = FakeSMPLX(bm, 2)
+            ce.CrowdEnv._calc_egosensing = ego_hook
+            out = {"sdf_res": np.int64(RES), "body_model_seed": np.int64(0), "n_cases": np.int64(0), "prior_seed": np.int64(PRIOR_SEED),
+                   "prior_gains": np.asarray(PRIOR_GAINS, np.float64)}
+            cases = []
+
+            def make_env(finetuning, vposer_gain=1.0):
+                sd = dict(vsd)
+                if vposer_gain != 1.0:      # scale the embedding (last layer) so that the 11-threshold of :201 is crossed
+                    for k in list(sd):
+                        if k.startswith("bodyprior_enc_mu."):
+                            sd[k] = sd[k] * vposer_gain
+                init_env = (cfg, genop, genop, "data/smplx/models", sampler, p1, p2, pmp, fmi, markers, FakeVPoser(sd), sdf_scene_tensors(scene_free))
+                return ce.CrowdEnv(init_env, save_rollout=False, render=False, finetuning=finetuning)
+
+            def run_case(name, pair, zs, finetuning=False, obstacle_on_agent=False, goal_on_pelvis=False, steps_before=None, vposer_gain=1.0,
+                         graze=False):
+                env = make_env(finetuning, vposer_gain)
+                sampler.sample_pairs = [(np.asarray(pair[0], np.float64), np.asarray(pair[1], np.float64))]
+                torch.manual_seed(7)
+                obs, _ = env.reset()
+                pre = f"{name}_"
+                c = {pre + "pair": np.asarray(pair, np.float32), pre + "finetuning": np.bool_(finetuning), pre + "vposer_gain": np.float64(vposer_gain),
+                     pre + "z": np.stack([t2n(z) for z in zs]), pre + "reset_obs_state": t2n(obs["state"]), pre + "reset_obs_ego": t2n(obs["egosensing"]),
+                     pre + "reset_obs_dist": t2n(obs["dist"]).reshape(-1), pre + "reset_obs_time": t2n(obs["time"]).reshape(-1),
+                     pre + "motion_transl": t2n(env.body_scene_data["motion_seed"]["transl"]),
+                     pre + "motion_glorot": t2n(env.body_scene_data["motion_seed"]["global_orient"]),
+                     pre + "motion_body_pose": t2n(env.body_scene_data["motion_seed"]["body_pose"]), pre + "betas": t2n(env.betas).reshape(-1)}
+                c.update(record_state(env, pre + "reset_"))
+                if obstacle_on_agent:
+                    # a 1 m cube on the agent's position: the same scene generator with the obstacle moved (state manipulation BEFORE
+                    # the reference's step, which reads self.scene_sdf)
+                    p = t2n(env.T0[0]).reshape(3)
+                    lo, hi = np.array([p[0] - 0.5, p[1] - 0.5, 0.0]), np.array([p[0] + 0.5, p[1] + 0.5, 1.0])
+                    env.scene_sdf = sdf_scene_tensors(synth.make_sdf_scene(RES, obstacle=(lo, hi)))
+                    c[pre + "obstacle_lo"], c[pre + "obstacle_hi"] = lo.astype(np.float32), hi.astype(np.float32)
+                if graze:
+                    # an obstacle that only GRAZES the body: a cube centred on a marker of frame 10, its size bisected until the
+                    # largest per-frame count is in (0, 40) - below the penetration threshold of :174, r_pene strictly in (0, 1)
+                    import copy
+                    from crowd_ppo.utils import calc_sdf
+                    keep = {k: copy.deepcopy(getattr(env, k)) for k in ("state", "body_param_seed", "R0", "T0", "dist", "steps", "betas")}
+                    _, loc = capture_step(ce.CrowdEnv, env, zs[0].clone())
+                    for k, v in keep.items():
+                        setattr(env, k, v)
+                    env.flag = False
+                    vw = loc["vertices_w"][0]                                        # [20, V, 3]
+                    ctr = t2n(vw[10, markers[20]]).astype(np.float64)
+                    lo_h, hi_h, pick = 0.02, 0.6, None
+                    for _ in range(24):
+                        h = 0.5 * (lo_h + hi_h)
+                        sc = sdf_scene_tensors(synth.make_sdf_scene(RES, obstacle=(ctr - h, ctr + h)))
+                        sv = calc_sdf(vw, sc)
+                        sv[:, env.feet_vids] = 0.0
+                        mx = int(sv.lt(0.0).sum(-1).max())
+                        if 5 <= mx < 40:
+                            pick = h
+                            break
+                        lo_h, hi_h = (h, hi_h) if mx < 5 else (lo_h, h)
+                    assert pick is not None, "no grazing obstacle found"
+                    env.scene_sdf = sdf_scene_tensors(synth.make_sdf_scene(RES, obstacle=(ctr - pick, ctr + pick)))
+                    c[pre + "obstacle_lo"], c[pre + "obstacle_hi"] = (ctr - pick).astype(np.float32), (ctr + pick).astype(np.float32)
+                if steps_before is not None:
+                    env.steps = int(steps_before)
+                    c[pre + "steps_before"] = np.int64(steps_before)
+                if goal_on_pelvis:
+                    # probe step on a scratch copy of the env state to learn where the pelvis ends, then put the goal there
+                    import copy
+                    keep = {k: copy.deepcopy(getattr(env, k)) for k in ("state", "body_param_seed", "R0", "T0", "dist", "steps", "betas")}
+                    wp_keep = env.body_scene_data["wpath"].clone()
+                    _, loc = capture_step(ce.CrowdEnv, env, zs[0].clone())
+                    pel_w = (torch.einsum("ij,j->i", keep["R0"][0], loc["pred_pelvis_loc"][0, -1]) + keep["T0"][0, 0])
+                    for k, v in keep.items():
+                        setattr(env, k, v)
+                    env.flag = False
+                    wp = wp_keep.clone()
+                    wp[1] = pel_w + torch.tensor([0.03, -0.02, 0.04])
+                    env.body_scene_data["wpath"] = wp
+                    c[pre + "wpath_override"] = t2n(wp)
+                for i, z in enumerate(zs):
+                    ret, loc = capture_step(ce.CrowdEnv, env, z.clone())
+                    c.update(record_step(ret, loc, env, f"{pre}s{i}_"))
+                    if ret[2]:
+                        break
+                c[pre + "n_steps"] = np.int64(i + 1)
+                cases.append(name)
+                out.update(c)
+                return c
+
+            g = torch.Generator().manual_seed(123)
+            z = lambda: torch.randn(128, generator=g)   # noqa: E731
+            free = [[-2.0, -1.5, 0.0], [-0.5, 2.0, 0.0]]
+            run_case("free", free, [z(), z(), z()])
+            run_case("pene_ft", [[-1.0, 2.0, 0.0], [2.5, 2.5, 0.0]], [z()], finetuning=True, obstacle_on_agent=True)
+            run_case("pene", [[-1.0, 2.0, 0.0], [2.5, 2.5, 0.0]], [z(), z()], finetuning=False, obstacle_on_agent=True)
+            run_case("graze_ft", free, [z()], finetuning=True, graze=True)
+            run_case("goal", [[2.0, -2.5, 0.0], [-1.0, -2.0, 0.0]], [z()], goal_on_pelvis=True)
+            run_case("depth", free, [z()], steps_before=cfg.trainconfig.max_depth - 1)
+            run_case("vposer", free, [z()], vposer_gain=40.0)
+            out["n_cases"] = np.int64(len(cases))
+            out["cases"] = np.array(cases)
+            out["cfg_json"] = np.array(json.dumps({k: cfg[k] for k in ("modelconfig", "lossconfig", "trainconfig")}))
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "env_step_ref.npz"), **out)
+    for name in cases:
+        n = int(out[f"{name}_n_steps"])
+        last = f"{name}_s{n - 1}_"
+        print(f"{name:8s} steps {n} reward {float(out[last + 'reward']):+.4f} term {bool(out[last + 'terminated'])} "
+              f"pene {bool(out[last + 'penetration'])} max_inside {int(out[last + 'num_inside_max'])} r_goal {float(out[last + 'r_goal'])} "
+              f"r_vp {float(out[last + 'r_vp'])} vp_norm {float(out[last + 'vp_norm']):.2f}")
+    print("env_step_ref", os.path.getsize(os.path.join(OUT, "env_step_ref.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sdf"]
+    for w in which:
+        {"sdf": gen_sdf}[w]()

@@ -95,3 +95,16 @@ def test_bench_stdout_line_fits_the_drivers_tail():
         assert back["value"] == round(full["value"], 1)
         if world > 1:
             assert back["allreduce"]["in_loop_ms_per_step"] == 4.0 and back["weak"]["value"] == 1.2e6
+
+
+def test_main_ppo_box_has_its_own_command_line():
+    """main_ppo_box.py:40-104: the box driver's defaults differ from main_ppo.py's in three places and it parses two more flags."""
+    from crowd_ppo import main_ppo, main_ppo_box
+    a, b = main_ppo.get_args([]), main_ppo_box.get_args([])
+    assert (a.test_num, a.logdir, a.save_interval) == (20, "./log", 2)             # main_ppo.py:52,67,81
+    assert (b.test_num, b.logdir, b.save_interval) == (10, "./log/log_box", 1)     # main_ppo_box.py:52,67,81
+    assert b.dynobs is False and b.more_ego is False
+    c = main_ppo_box.get_args(["--dynobs", "--more-ego", "--test-num", "3", "--deterministic-eval"])
+    assert c.dynobs and c.more_ego and c.test_num == 3 and c.deterministic_eval
+    for k in ("training_num", "batch_size", "step_per_collect", "lr", "eps_clip", "max_grad_norm", "epoch", "step_per_epoch"):
+        assert getattr(a, k) == getattr(b, k)

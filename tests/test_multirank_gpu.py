@@ -251,13 +251,20 @@ def test_bench_gpus2_refuses_to_run_on_one_device():
     assert '"n_gpus"' not in r.stdout
 
 
-def test_bench_gpus2_spawns_two_ranks():
-    """bench.py --gpus 2 launches its own ranks; here both sit on one device over gloo (test knobs)."""
-    r = _bench({"EGX_SINGLE_DEVICE": "1", "EGX_DIST_BACKEND": "gloo"}, "--gpus", "2")
+def test_bench_gpus2_spawns_two_ranks(tmp_path):
+    """bench.py --gpus 2 launches its own ranks; here both sit on one device over gloo (test knobs).  The stdout line is the
+    compact (< 4 KB) record; the full one is the --detail-file sidecar."""
+    detail = str(tmp_path / "detail.json")
+    r = _bench({"EGX_SINGLE_DEVICE": "1", "EGX_DIST_BACKEND": "gloo"}, "--gpus", "2", "--detail-file", detail)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
-    res = json.loads(lines[0])
+    assert len(lines[0]) < 4096
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["roofline"]["frac"] > 0 and line["config"]["workload"]
+    assert line["allreduce"]["in_loop_ms_per_step"] > 0 and line["weak"]["value"] > 0 and line["detail"] == "detail.json"
+    res = json.load(open(detail))
+    assert res["value"] == pytest.approx(line["value"], rel=1e-4)
     assert res["n_gpus"] == 2 and res["scaling"] == "strong"
     assert res["config"]["agents_per_gpu"] == 16 and res["config"]["agents_total"] == 32
     assert res["config"]["hip_graph_update"] is True

@@ -62,31 +62,132 @@ def test_sample_action_kernel():
     assert torch.equal(act, muc)
 
 
+def _rollout_logp_vs_float64(policy, bb):
+    """Rollout log-probabilities (policy forward + egx_sample_action on the packed images) against the plain torch modules
+    evaluated in FLOAT64 on the same observations and actions: (max |d logp|, max |logp|)."""
+    import copy
+    p64 = copy.deepcopy(policy).double()
+    with torch.no_grad():
+        obs = {k: v.double() for k, v in bb.obs_flat().items()}
+        _, mu, sigma = p64._dist_params(obs)
+        lp = p64.log_prob(mu, sigma, bb.act.reshape(-1, 128).double())
+    return max_abs(lp.cpu(), bb.logp_old.reshape(-1).cpu()), float(lp.abs().max())
+
+
 @pytest.mark.parametrize("kind", ["sdf", "box"])
 def test_collect_and_update_loop(kind):
+    """Collector + trainer on the DEFAULT update path: minibatches of 32 rows = the hand-written chain replayed as HIP graphs
+    (round 4 ran this loop at batch size 8, i.e. on the autograd-node fallback)."""
     from egogen_amd import setup_world as sw
     from egogen_amd.trainer import Collector, onpolicy_trainer
-    w = build_world(V=1024, A=16, scene_kind=kind, sdf_res=32, n_pairs=64, n_scenes=4)
+    w = build_world(V=1024, A=32, scene_kind=kind, sdf_res=32, n_pairs=64, n_scenes=4)
     env = w["env"]
     policy = sw.build_policy(_Args())
     before = policy.actor.pnet.out_fc.weight.clone()
     col = Collector(policy, env)
-    res = onpolicy_trainer(policy, col, None, max_epoch=1, step_per_epoch=64, repeat_per_collect=1, episode_per_test=0,
-                           batch_size=8, step_per_collect=32, verbose=False)
-    assert res["train_step"] == 64 and res["gradient_step"] == 8
+    res = onpolicy_trainer(policy, col, None, max_epoch=1, step_per_epoch=128, repeat_per_collect=1, episode_per_test=0,
+                           batch_size=32, step_per_collect=64, verbose=False)
+    assert res["train_step"] == 128 and res["gradient_step"] == 4
+    assert policy.update_paths == {"chain+graph": 4}, policy.update_paths
     assert not torch.equal(before, policy.actor.pnet.out_fc.weight)
     for p in policy.parameters():
         assert torch.isfinite(p).all()
     b = col._batches[2]
     assert torch.isfinite(b.rew).all() and torch.isfinite(b.adv).all() and torch.isfinite(b.returns).all()
-    # the rollout log-probs equal the update path's log-probs before any parameter change (same function, two code paths)
+    # the rollout log-probs (packed images, default two-term arithmetic) against the torch modules in float64, before any
+    # parameter change: 1e-4 RELATIVE is north_star's bar; the values are ~ -2e2, measured ~1e-4 absolute
     policy2 = sw.build_policy(_Args())
     col2 = Collector(policy2, env)
     bb = col2.collect(2)
-    with torch.no_grad():
-        _, mu, sigma = policy2._dist_params(bb.obs_flat())
-        lp = policy2.log_prob(mu, sigma, bb.act.reshape(-1, 128))
-    assert max_abs(lp.cpu(), bb.logp_old.reshape(-1).cpu()) < 2e-3
+    d, mag = _rollout_logp_vs_float64(policy2, bb)
+    assert d <= 1e-4 * mag and d <= 2e-3, (d, mag)
+    # and the update chain sees the same function: on its first minibatch (no step taken yet) mean(logp_old - logp) ~ 0
+    policy2.process_fn(bb)
+    hs = policy2._train_handle(32)
+    assert hs is not None
+    log = torch.zeros(6, device="cuda")
+    policy2._ensure_flat_grads()
+    policy2._fwd_bwd(bb, torch.arange(32, device="cuda"), None, log)
+    assert abs(float(log[5])) <= 2e-4, float(log[5])
+
+
+def test_full_size_loop_on_the_default_update_path():
+    """BASELINE configs[2] at its own size: 512 agents on the 64 random-box scenes, V = 10 475, 4 vector steps per collect,
+    minibatch 256, two collect + update cycles.  Every minibatch must run the hand-written chain as replayed graphs, no episode
+    may start in penetration, parameters stay finite, and the rollout log-probs agree with float64 torch before any step."""
+    from egogen_amd import setup_world as sw, synth
+    from egogen_amd.body_model import BodyModelHandle
+    from egogen_amd.trainer import Collector
+    bm, _ = sw.load_body_model("male", seed=0, num_verts=synth.NUM_VERTS)
+    body = BodyModelHandle(bm, synth.marker_ids(synth.NUM_VERTS), synth.feet_vids(synth.NUM_VERTS))
+    scene = sw.build_scene("box", seed=0)
+    assert len(scene["box_scenes"]) == 64
+    env = sw.build_env(512, scene, body, sw.build_motion_prior(seed=0), sw.build_vposer(seed=0), seed=0)
+    a = _Args()
+    a.update_graph = True
+    policy = sw.build_policy(a)
+    policy.train()
+    col = Collector(policy, env)
+    col.reset()
+    first = None
+    for cycle in range(2):
+        batch = col.collect(4)
+        env.check_finite()
+        if first is None:
+            first = _rollout_logp_vs_float64(policy, batch)
+        policy.process_fn(batch)
+        out = policy.learn(batch, 256, 1)
+        assert len(out["loss"]) == 8 and np.isfinite(out["loss"]).all()
+    assert policy.update_paths == {"chain+graph": 16}, policy.update_paths
+    assert env.forced_accepts() == 0
+    for p in policy.parameters():
+        assert torch.isfinite(p).all()
+    d, mag = first
+    assert d <= 1e-4 * mag and d <= 2e-3, first
+
+
+def test_recompute_adv_reads_current_weights_under_graph_replay():
+    """--recompute-adv with a loss option (value_clip routes the minibatch through the autograd nodes, replayed as graphs):
+    replayed graphs write the parameters by address, so from the third pass on the value pass of ppo_policy.py:185-186 used to
+    read packed images that were a whole pass old.  Every recompute must equal a fresh critic evaluation of the CURRENT
+    parameters (plain torch modules)."""
+    from egogen_amd import setup_world as sw
+
+    class A(_Args):
+        value_clip = 1; recompute_adv = 1
+        update_graph = True
+    pol = sw.build_policy(A())
+    b = _filled_batch(4, 32, 11, pol)
+    b.term.zero_()
+    b.rew.copy_(torch.randn(4, 32, generator=torch.Generator().manual_seed(3)))
+    pol.process_fn(b)
+    with torch.no_grad():     # ratio exactly 1 at the start: the early stop on approx_kl must not end the passes
+        _, mu, sigma = pol._dist_params(b.obs_flat())
+        b.logp_old.copy_(pol.log_prob(mu, sigma, b.act.reshape(-1, 128)).reshape(4, 32))
+    seen, drift, prev = [], [], []
+    inner = pol.process_fn
+
+    def spy(batch):
+        r = inner(batch)
+        if getattr(pol, "_recomputing", False):
+            with torch.no_grad():
+                hx = pol.shared_net(batch.obs_flat(batch.n + 1))
+                fresh = pol.critic(hx).flatten().reshape(batch.n + 1, batch.A)
+            seen.append(max_abs(batch.values.cpu(), fresh.cpu()))
+            if prev:
+                drift.append(max_abs(fresh.cpu(), prev[-1]))
+            prev.append(fresh.cpu().clone())
+        return r
+    pol.process_fn = spy
+    for g in pol.optim.param_groups:
+        g["lr"] = 1e-4
+    pol.learn(b, 32, 4)
+    assert len(seen) >= 2, seen            # pass 3 is the first one that used to read stale images
+    assert any(k.endswith("+graph") for k in pol.update_paths), pol.update_paths
+    # seen[0] (the first recompute was never stale) is the images-vs-fp32-modules yardstick; a stale image is off by a whole
+    # pass of optimiser steps = `drift`
+    assert min(drift) > 20 * max(seen[0], 1e-6), (seen, drift)
+    assert max(seen) <= 3 * seen[0] + 2e-5, (seen, drift)
 
 
 def test_main_ppo_entry_point_writes_reference_layout(tmp_path):
