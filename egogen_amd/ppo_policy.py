@@ -679,6 +679,7 @@ class GAMMAPPOPolicy(nn.Module):
         stats = {k: [] for k in names}
         logs = []
         use_graph = self.use_update_graph and dev.type == "cuda"
+        kld_rows = []
         for step in range(repeat):
             if self._recompute_adv and step > 0:    # ppo_policy.py:185-186: values of ALL observations with the current weights
                 self._recomputing = True
@@ -691,7 +692,10 @@ class GAMMAPPOPolicy(nn.Module):
                     self.process_fn(batch)
                 finally:
                     self._recomputing = False
-            perm = torch.randperm(N, generator=self._perm_gen).to(dev)
+            if getattr(self, "_perm_queue", None):        # parity tests: the row order the reference's Batch.split drew
+                perm = torch.as_tensor(self._perm_queue.pop(0), dtype=torch.long).to(dev)
+            else:
+                perm = torch.randperm(N, generator=self._perm_gen).to(dev)
             # Batch.split(size, shuffle=True, merge_last=True)
             bounds = list(range(0, N, local_bs))
             if len(bounds) > 1 and N - bounds[-1] < local_bs:
@@ -724,6 +728,9 @@ class GAMMAPPOPolicy(nn.Module):
                     last_log = log
                     self.update_paths[path] = self.update_paths.get(path, 0) + 1
                 logs.append(last_log[:5])
+                # `loss/kld` of ppo_policy.py:232 reads minibatch.z_mu - the means the ROLLOUT stored - not the current network's:
+                # 0.5 mean(mu_rollout^2) over the minibatch's rows, evaluated for all minibatches at once after the loop
+                kld_rows.append(idx)
             # early stop on the last minibatch's approximate KL (ppo_policy.py:252-257); inert at repeat=1
             if repeat > 1 and last_log is not None:
                 kl = last_log[5].clone()
@@ -737,6 +744,14 @@ class GAMMAPPOPolicy(nn.Module):
         self._refresh_images()
         if logs:
             L = torch.stack(logs)
+            mu2 = batch.mu.reshape(N, -1).pow(2).mean(1)               # [N]: per-row mean of the rollout's mu^2
+            if len({int(r.shape[0]) for r in kld_rows}) == 1:
+                kld = 0.5 * mu2.index_select(0, torch.cat(kld_rows)).reshape(len(kld_rows), -1).mean(1)
+            else:
+                kld = torch.stack([0.5 * mu2.index_select(0, r).mean() for r in kld_rows])
+            if dp:
+                kld = kld / ws                                          # summed over the ranks below: the global minibatch mean
+            L[:, 4] = kld
             if dp:
                 dist.all_reduce(L)
             for row in L.cpu().tolist():

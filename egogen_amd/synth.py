@@ -345,6 +345,32 @@ def room0_polygon() -> List[np.ndarray]:
     return [A["room0_ring_xy"][off[i]:off[i + 1]].copy() for i in range(len(off) - 1)]
 
 
+def box_scene_geometry(lo, hi):
+    """8x8 m floor minus the axis-aligned hole [lo, hi] (xy): navmesh triangles [8,3,2] (4 rectangles) and the walkable
+    polygon's rings (exterior ccw, hole cw)."""
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    F_lo = np.array([-4.0, -4.0])
+    F_hi = np.array([4.0, 4.0])
+    rects = [(F_lo, np.array([F_hi[0], lo[1]])),
+             (np.array([F_lo[0], hi[1]]), F_hi),
+             (np.array([F_lo[0], lo[1]]), np.array([lo[0], hi[1]])),
+             (np.array([hi[0], lo[1]]), np.array([F_hi[0], hi[1]]))]
+    tris = []
+    for a, b in rects:
+        p00 = [a[0], a[1]]; p10 = [b[0], a[1]]; p11 = [b[0], b[1]]; p01 = [a[0], b[1]]
+        tris.append([p00, p10, p11])
+        tris.append([p00, p11, p01])
+    return np.array(tris, np.float32), [rect_ring(F_lo, F_hi, True), rect_ring(lo, hi, False)]
+
+
+def box_scene_from_hole(lo, hi, pairs=None) -> Dict[str, np.ndarray]:
+    """One scene of the `make_box_scenes` form with the (inflated) obstacle footprint given (tests: a hole under an agent)."""
+    tris, rings = box_scene_geometry(lo, hi)
+    return {"tris": tris, "edges": rings_to_edges(rings).astype(np.float32),
+            "pairs": np.zeros((1, 2, 3), np.float32) if pairs is None else np.asarray(pairs, np.float32),
+            "box_lo": np.asarray(lo, np.float32), "box_hi": np.asarray(hi, np.float32), "floor_height": np.float32(0.0)}
+
+
 def make_box_scenes(num_scenes: int = 64, pairs_per_scene: int = 2048, seed: int = 0) -> List[Dict[str, np.ndarray]]:
     """Synthetic stand-in for data/scenes/random_box_obstacle_new (environments.py:386-402):
     8x8 m floor, one axis-aligned box 0.5-1.5 m, navmesh = floor minus the box inflated by
@@ -357,20 +383,7 @@ def make_box_scenes(num_scenes: int = 64, pairs_per_scene: int = 2048, seed: int
         c = rng.uniform(-2.0, 2.0, 2)
         lo = c - size / 2 - 0.2
         hi = c + size / 2 + 0.2
-        F_lo = np.array([-4.0, -4.0])
-        F_hi = np.array([4.0, 4.0])
-        # floor minus hole as 4 rectangles -> 8 triangles
-        rects = [(F_lo, np.array([F_hi[0], lo[1]])),
-                 (np.array([F_lo[0], hi[1]]), F_hi),
-                 (np.array([F_lo[0], lo[1]]), np.array([lo[0], hi[1]])),
-                 (np.array([hi[0], lo[1]]), np.array([F_hi[0], hi[1]]))]
-        tris = []
-        for a, b in rects:
-            p00 = [a[0], a[1]]; p10 = [b[0], a[1]]; p11 = [b[0], b[1]]; p01 = [a[0], b[1]]
-            tris.append([p00, p10, p11])
-            tris.append([p00, p11, p01])
-        tris = np.array(tris, np.float32)  # [8,3,2]
-        rings = [rect_ring(F_lo, F_hi, True), rect_ring(lo, hi, False)]
+        tris, rings = box_scene_geometry(lo, hi)
         pairs = np.zeros((pairs_per_scene, 2, 3), np.float32)
         n = 0
         while n < pairs_per_scene:

@@ -78,3 +78,62 @@ def ppo_loss(mu, logvar, value, act, adv, returns, logp_old, eps_clip=0.1, vf_co
     ent = entropy(sigma).mean()
     loss = clip_loss + vf_coef * vf_loss - ent_coef * ent
     return loss, {"loss/clip": clip_loss, "loss/vf": vf_loss, "loss/ent": ent, "loss/kld": 0.5 * torch.mean(mu.pow(2))}
+
+
+def split_spans(n: int, size: int):
+    """tianshou.data.Batch.split(size, merge_last=True) [upstream]: chunks of `size` rows of a permutation, a remainder shorter
+    than `size` merged into the last chunk."""
+    merge = n % size > 0
+    spans, i = [], 0
+    while i < n:
+        if merge and i + 2 * size >= n:
+            spans.append((i, n))
+            break
+        spans.append((i, min(i + size, n)))
+        i += size
+    return spans
+
+
+def ppo_learn(P, optim, clip_params, obs, act, adv, returns, logp_old, batch_size, perms, v_s=None, z_mu=None, repeat=1, eps_clip=0.1,
+              vf_coef=1.0, ent_coef=0.01, max_grad_norm=0.1, norm_adv=True, dual_clip=None, value_clip=False, on_step=None):
+    """ppo_policy.py:182-265 (`GAMMAPPOPolicy.learn`) on a dict of parameter tensors `P` (keys of the policy's state_dict, leaves
+    that require grad; evaluated with oracle.nets.policy_*): per pass one permutation (`perms[pass]`, the rows Batch.split draws),
+    per minibatch the loss of :189-241, zero_grad / backward (:242-243), clip_grad_norm_ over `clip_params` - tianshou's
+    ActorCritic(actor, critic): `self._actor_critic: ActorCritic(...)` of :88 is an annotation, so the SHARED encoders are not
+    clipped (:244-247) - and optim.step (:248); the logged `loss/kld` is 0.5 mean(z_mu^2) of the ROLLOUT's stored means (:232,
+    `minibatch.z_mu`); early stop on the last minibatch's mean(logp_old - logp) >= 0.02 (:255-258).
+    `on_step(i, grads)` is called before every optimiser step (tests)."""
+    from . import nets
+    n = act.shape[0]
+    out = {"loss": [], "loss/clip": [], "loss/vf": [], "loss/ent": [], "loss/kld": []}
+    k = 0
+    for step in range(repeat):
+        perm = torch.as_tensor(perms[step]).long()
+        kl = None
+        for s, e in split_spans(n, batch_size):
+            i = perm[s:e]
+            o = {kk: v[i] for kk, v in obs.items()}
+            hx = nets.policy_base(P, o)
+            mu, logvar = nets.policy_actor(P, hx)
+            value = nets.policy_critic(P, hx)
+            loss, terms = ppo_loss(mu, logvar, value, act[i], adv[i], returns[i], logp_old[i], eps_clip=eps_clip, vf_coef=vf_coef,
+                                   ent_coef=ent_coef, norm_adv=norm_adv, dual_clip=dual_clip, value_clip=value_clip,
+                                   v_s=None if v_s is None else v_s[i])
+            optim.zero_grad()
+            loss.backward()
+            if max_grad_norm:
+                torch.nn.utils.clip_grad_norm_(clip_params, max_norm=max_grad_norm)
+            if on_step is not None:
+                on_step(k, P)
+            optim.step()
+            k += 1
+            out["loss"].append(float(loss.detach()))
+            for kk in ("loss/clip", "loss/vf", "loss/ent"):
+                out[kk].append(float(terms[kk].detach()))
+            out["loss/kld"].append(float(0.5 * torch.mean(z_mu[i].pow(2))) if z_mu is not None else float(terms["loss/kld"].detach()))
+            with torch.no_grad():
+                m_, s_ = action_dist(mu, logvar)
+                kl = float((logp_old[i] - log_prob(m_, s_, act[i])).mean())
+        if kl is not None and kl >= 0.02:
+            break
+    return out

@@ -426,7 +426,315 @@ def gen_sdf():
     print("env_step_ref", os.path.getsize(os.path.join(OUT, "env_step_ref.npz")), "bytes")
 
 
+# ------------------------------------------------------------------------------------------------------------------
+def _nav(scene):
+    """trimesh.load(navmesh_path) of the box sampler / scene['navmesh'] of the env: vertices [n,3] float64, faces."""
+    tris = np.asarray(scene["tris"], np.float32).reshape(-1, 3, 2)
+    verts = np.concatenate([tris.reshape(-1, 2), np.full((tris.shape[0] * 3, 1), 1.0, np.float32)], axis=1).astype(np.float64)
+    return types.SimpleNamespace(vertices=verts, faces=np.arange(tris.shape[0] * 3).reshape(-1, 3), visual=types.SimpleNamespace())
+
+
+def gen_box():
+    from egogen_amd import synth
+    from tests.helpers import seeded_vposer_state_dict
+    rec = {}
+    install(rec)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    reference_first()
+    try:
+        with cpu_world(), tempfile.TemporaryDirectory() as td:
+            from pathlib import Path
+            from crowd_ppo import crowd_env_2f_box as cb
+            from exp_GAMMAPrimitive.utils import environments as envs
+            from models import baseops, models_GAMMA_primitive as mgp
+            cfg = AttrDict(load_yaml("MPVAEPolicy_samp_collision_2.yaml"))
+            bm, (p1, p2, pmp) = body_and_parsers(baseops, sys.modules["smplx"])
+            fmi, markers = feet_marker_idx_and_markers()
+            genop = build_combo(mgp)
+            vsd = {k: v.float() for k, v in seeded_vposer_state_dict().items()}
+            # two scenes of the make_box_scenes form with their obstacles in opposite corners: the middle of the floor is free, so an
+            # agent that starts there stays on the 8 x 8 m floor for a few primitives
+            scenes = {"s0": synth.box_scene_from_hole([-3.2, -3.2], [-2.2, -2.2]), "s1": synth.box_scene_from_hole([2.0, 2.2], [3.1, 3.0])}
+            stype = "random_box_obstacle_new"
+            os.makedirs(os.path.join(td, stype))
+            navs = {}
+
+            def add_scene(name, sc):
+                scenes[name] = sc
+                navs[name + "_navmesh_tight.ply"] = _nav(sc)
+                with open(os.path.join(td, stype, name + "_shapely.pkl"), "wb") as f:
+                    pickle.dump(np.asarray(sc["edges"], np.float64), f)
+                with open(os.path.join(td, stype, name + "_samples.pkl"), "wb") as f:
+                    pickle.dump([(np.zeros(3), np.ones(3))], f)
+            for k in list(scenes):
+                add_scene(k, scenes[k])
+            sys.modules["trimesh"].load = lambda path, force=None: navs[os.path.basename(str(path))]
+            inner = object.__new__(envs.BatchGeneratorScene2frameTrainBox)
+            inner.scene_dir, inner.scene_type, inner.index_rec = Path(td), stype, 0
+            inner.motion_seed_list = [os.path.join(REF, "data", "locomotion", "subseq_00343.npz")]
+            inner.bm_2frame = FakeSMPLX(bm, 2)
+            motion = np.load(inner.motion_seed_list[0])
+
+            class QueueSampler:
+                """The env's reset loop draws until a start passes (crowd_env_2f_box.py:349-416); the draws of a case are queued
+                here and handed to the reference sampler through its own `scene_idx` / `start_target` arguments."""
+
+                def __init__(self):
+                    self.queue, self.log = [], []
+
+                def next_body(self, **kw):
+                    name, pair = self.queue.pop(0)
+                    inner.scene_list = [name]
+                    rec["euler_z"] = []
+                    d = inner.next_body(scene_idx=0, start_target=np.asarray(pair, np.float64), **kw)
+                    bp = t2n(d["motion_seed"]["body_pose"])
+                    start = [s for s in range(len(motion["poses"]) - 1) if np.allclose(motion["poses"][s:s + 2, 3:66], bp, atol=1e-6)]
+                    assert len(start) == 1
+                    self.log.append({"scene": name, "pair": np.asarray(pair, np.float32), "start_frame": start[0], "yaw_jitter": rec["euler_z"][2],
+                                     "transl": t2n(d["motion_seed"]["transl"]), "glorot": t2n(d["motion_seed"]["global_orient"]),
+                                     "wpath": t2n(d["wpath"])})
+                    return d
+            qs = QueueSampler()
+            cb.CrowdEnv._calc_egosensing = ego_hook
+            out = {"body_model_seed": np.int64(0), "prior_seed": np.int64(PRIOR_SEED), "prior_gains": np.asarray(PRIOR_GAINS, np.float64),
+                   }
+            cases = []
+
+            def restore(env, keep, nav, poly):
+                for k, v in keep.items():
+                    setattr(env, k, v)
+                env.flag = False
+                env.body_scene_data["navmesh"], env.scene_poly = nav, poly
+
+            def run_case(name, draws, zs, hole=None):
+                """draws: [(scene, pair)], the last one is the start the loop accepts.  hole: None | 'cover' | 'graze' - the scene is
+                swapped (navmesh + polygon, like an agent moved into another scene) before the step."""
+                import copy
+                init_env = (cfg, genop, genop, "data/smplx/models", qs, p1, p2, pmp, fmi, markers, FakeVPoser(vsd))
+                env = cb.CrowdEnv(init_env, save_rollout=False, render=False)
+                qs.queue, qs.log = list(draws), []
+                torch.manual_seed(11 + len(cases))
+                obs, _ = env.reset()
+                assert not qs.queue, "the reference's loop accepted an earlier draw than planned"
+                pre = f"{name}_"
+                c = {pre + "n_draws": np.int64(len(qs.log)), pre + "z": np.stack([t2n(z) for z in zs]), pre + "betas": t2n(env.betas).reshape(-1),
+                     pre + "reset_obs_state": t2n(obs["state"]), pre + "reset_obs_ego": t2n(obs["egosensing"]),
+                     pre + "reset_obs_dist": t2n(obs["dist"]).reshape(-1), pre + "reset_obs_time": t2n(obs["time"]).reshape(-1)}
+                for i, d in enumerate(qs.log):
+                    c[f"{pre}draw{i}_scene"] = np.array(d["scene"])
+                    for k in ("pair", "transl", "glorot", "wpath"):
+                        c[f"{pre}draw{i}_{k}"] = d[k]
+                    c[f"{pre}draw{i}_start_frame"] = np.int64(d["start_frame"])
+                    c[f"{pre}draw{i}_yaw_jitter"] = np.float64(d["yaw_jitter"])
+                c.update(record_state(env, pre + "reset_"))
+                if hole is not None:
+                    keep = {k: copy.deepcopy(getattr(env, k)) for k in ("state", "body_param_seed", "R0", "T0", "dist", "steps", "betas")}
+                    nav0, poly0 = env.body_scene_data["navmesh"], env.scene_poly
+                    _, loc = capture_step(cb.CrowdEnv, env, zs[0].clone())
+                    ctr = t2n(env.T0[0]).reshape(3)[:2].astype(np.float64)     # origin of the frame the map is sampled in
+                    restore(env, keep, nav0, poly0)
+                    if hole == "cover":
+                        lo, hi = ctr - 0.75, ctr + 0.75
+                    else:      # slide a 1 m hole towards the body until 0 < num_pene <= pene_thres (no penetration, but counted)
+                        lo = hi = None
+                        for off in np.linspace(1.0, 0.0, 101):     # diagonally: a corner of the hole enters the marker box first
+                            l_, h_ = ctr + np.array([off, off]), ctr + np.array([off + 1.0, off + 1.0])
+                            sc = synth.box_scene_from_hole(l_, h_)
+                            env.body_scene_data["navmesh"], env.scene_poly = _nav(sc), np.asarray(sc["edges"], np.float64)
+                            _, loc = capture_step(cb.CrowdEnv, env, zs[0].clone())
+                            restore(env, keep, nav0, poly0)
+                            n = float(loc["num_pene"][0])
+                            if os.environ.get("EGX_GEN_DEBUG"):
+                                print("graze search", round(float(off), 3), n, ctr, t2n(env.T0[0]).ravel(), float(loc["local_map"].sum()),
+                                      t2n(loc["box_min"]).ravel(), t2n(loc["box_max"]).ravel(), flush=True)
+                            if 0 < n <= cfg.trainconfig.pene_thres:
+                                lo, hi = l_, h_
+                                break
+                            assert n == 0, "stepped over the (0, pene_thres] window: refine the offsets"
+                        assert lo is not None, "no grazing hole found"
+                    sc = synth.box_scene_from_hole(lo, hi)
+                    env.body_scene_data["navmesh"], env.scene_poly = _nav(sc), np.asarray(sc["edges"], np.float64)
+                    c[pre + "hole_lo"], c[pre + "hole_hi"] = lo.astype(np.float32), hi.astype(np.float32)
+                for i, z in enumerate(zs):
+                    ret, loc = capture_step(cb.CrowdEnv, env, z.clone())
+                    c.update(record_step(ret, loc, env, f"{pre}s{i}_", box=True))
+                    if ret[2]:
+                        break
+                c[pre + "n_steps"] = np.int64(i + 1)
+                cases.append(name)
+                out.update(c)
+
+            g = torch.Generator().manual_seed(321)
+            z = lambda: torch.randn(128, generator=g)   # noqa: E731
+            free0 = np.array([[0.3, -0.4, 0.0], [2.5, -1.0, 0.0]], np.float32)
+            free1 = np.array([[-0.5, 0.6, 0.0], [-2.5, 1.5, 0.0]], np.float32)
+            on_box = np.array(free0, np.float32).copy()
+            on_box[0, :2] = 0.5 * (scenes["s0"]["box_lo"] + scenes["s0"]["box_hi"])
+            run_case("free", [("s0", free0)], [z(), z()])
+            run_case("reject", [("s0", on_box), ("s0", on_box), ("s1", free1)], [z()])
+            run_case("cover", [("s1", free1)], [z(), z()], hole="cover")
+            run_case("graze", [("s0", free0)], [z()], hole="graze")
+            out["cases"] = np.array(cases)
+            for k in ("s0", "s1"):
+                for f_ in ("tris", "edges", "box_lo", "box_hi"):
+                    out[f"scene_{k}_{f_}"] = np.asarray(scenes[k][f_])
+            out["cfg_json"] = np.array(json.dumps({k: cfg[k] for k in ("modelconfig", "lossconfig", "trainconfig")}))
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "env_box_ref.npz"), **out)
+    for name in cases:
+        n = int(out[f"{name}_n_steps"])
+        for i in range(n):
+            k = f"{name}_s{i}_"
+            print(f"{name:8s} draws {int(out[name + '_n_draws'])} step {i} reward {float(out[k + 'reward']):+.4f} term {bool(out[k + 'terminated'])} "
+                  f"num_pene {float(out[k + 'num_pene'])} r_pene {float(out[k + 'r_pene'])} r_goal {float(out[k + 'r_goal'])}")
+    print("env_box_ref", os.path.getsize(os.path.join(OUT, "env_box_ref.npz")), "bytes")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def install_tianshou_stub(record):
+    """The attributes of tianshou 0.5 that GAMMAPPOPolicy.__init__ / learn read (policy/base.py, modelfree/pg.py, a2c.py, ppo.py,
+    data/batch.py [upstream]) - the loss, the backward pass, the clip and the optimiser step executed are ppo_policy.py's own lines."""
+    class Batch:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def __len__(self):
+            return len(self.act)
+
+        def __getitem__(self, idx):
+            def pick(v):
+                if isinstance(v, dict):
+                    return {k: pick(x) for k, x in v.items()}
+                return v[idx]
+            return Batch(**{k: pick(v) for k, v in self.__dict__.items()})
+
+        def split(self, size, shuffle=True, merge_last=False):
+            """tianshou.data.Batch.split: a random permutation, chunks of `size`, the remainder merged into the last chunk."""
+            length = len(self)
+            indices = np.random.permutation(length) if shuffle else np.arange(length)
+            record.setdefault("perms", []).append(indices.copy())
+            merge_last = merge_last and length % size > 0
+            for idx in range(0, length, size):
+                if merge_last and idx + size + size >= length:
+                    yield self[indices[idx:]]
+                    break
+                yield self[indices[idx:idx + size]]
+
+    class _AC(torch.nn.Module):                      # tianshou.utils.net.common.ActorCritic: actor + critic ONLY
+        def __init__(self, actor, critic):
+            super().__init__()
+            self.actor, self.critic = actor, critic
+
+    class PPOPolicy(torch.nn.Module):
+        """BasePolicy -> PGPolicy -> A2CPolicy -> PPOPolicy constructor chain, reduced to the attributes it leaves behind."""
+
+        def __init__(self, actor, critic, optim, dist_fn, discount_factor=0.99, gae_lambda=0.95, max_grad_norm=None, vf_coef=0.5,
+                     ent_coef=0.01, reward_normalization=False, max_batchsize=256, deterministic_eval=False, action_space=None,
+                     action_scaling=True, action_bound_method="clip", lr_scheduler=None, **kw):
+            super().__init__()
+            self.actor, self.critic, self.optim, self.dist_fn = actor, critic, optim, dist_fn
+            self._gamma, self._lambda, self._grad_norm = discount_factor, gae_lambda, max_grad_norm
+            self._weight_vf, self._weight_ent, self._rew_norm, self._batch = vf_coef, ent_coef, reward_normalization, max_batchsize
+            self._deterministic_eval, self._eps = deterministic_eval, 1e-8
+            self._actor_critic = _AC(self.actor, self.critic)       # a2c.py: what clip_grad_norm_ of :244-247 sees
+    ts = gg._stub("tianshou")
+    ts.data = gg._stub("tianshou.data", Batch=Batch, ReplayBuffer=object, to_torch_as=lambda x, y: torch.as_tensor(x).to(y))
+    ts.policy = gg._stub("tianshou.policy", PPOPolicy=PPOPolicy)
+    return Batch
+
+
+def gen_learn():
+    from torch.distributions import Independent, Normal
+    rec = {}
+    gg.install_stubs()
+    Batch = install_tianshou_stub(rec)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    reference_first()
+    try:
+        from crowd_ppo.ppo_policy import GAMMAPPOPolicy
+        from models.models_policy_ppo import ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase
+        cfg = load_yaml("MPVAEPolicy_samp_collision.yaml")["modelconfig"]
+        out = {}
+        for case, kw in (("default", dict()), ("options", dict(value_clip=1, dual_clip=2.0))):
+            torch.manual_seed(3)
+            actor, critic, base = GAMMAActor(cfg), GAMMACritic(cfg), GAMMAPolicyBase(cfg)
+            gg.fill_module(base, seed=102)
+            gg.fill_module(actor, seed=103, gain=1.4)
+            gg.fill_module(critic, seed=104, gain=1.4)
+            for m in actor.pnet.modules():                         # main_ppo.py:128-131: last-policy-layer scaling (keeps sigma, ratio sane)
+                if isinstance(m, torch.nn.Linear):
+                    m.weight.data.mul_(0.05)
+            ac = ActorCritic(actor, critic, base)
+            key_shapes = {}
+            for pre_, mod in (("shared_net.", base), ("actor.", actor), ("critic.", critic)):
+                for k, v in mod.state_dict().items():
+                    key_shapes[pre_ + k] = tuple(v.shape)
+            optim = torch.optim.AdamW(ac.parameters(), lr=3e-4, weight_decay=0.01)
+            pol = GAMMAPPOPolicy(actor, critic, base, optim, lambda *l: Independent(Normal(*l), 1), discount_factor=0.99, gae_lambda=0.95,
+                                 max_grad_norm=0.1, vf_coef=1.0, ent_coef=0.01, weight_kld=0, reward_normalization=False, action_space=None,
+                                 action_scaling=False, action_bound_method="", eps_clip=0.1, value_clip=kw.get("value_clip", 0),
+                                 dual_clip=kw.get("dual_clip"), advantage_normalization=1, recompute_advantage=0, deterministic_eval=False)
+            assert not hasattr(pol, "_actor_critic") or not any(p is q for p in pol._actor_critic.parameters() for q in base.parameters()), \
+                "ppo_policy.py:88 is an annotation: the clipped set is the parent's actor + critic"
+            g = torch.Generator().manual_seed(500)
+            N, BS = 160, 64                       # minibatches of 64 and 96 rows (merge_last)
+            obs = {"state": torch.randn(N, 2, 402, generator=g) * 0.5, "egosensing": torch.rand(N, 2, 32, generator=g) * 2 - 1,
+                   "dist": torch.rand(N, generator=g), "time": torch.rand(N, generator=g)}
+            with torch.no_grad():
+                hx = base(obs)
+                (mu, lv), _ = actor(hx)
+                sig = torch.exp(lv.clamp(-2.5, 2.5)) ** 0.5
+                act = mu + sig * torch.randn(N, 128, generator=g)
+                dist0 = Independent(Normal(mu, sig), 1)
+                logp_old = dist0.log_prob(act) + 0.05 * torch.randn(N, generator=g)     # ratios on both sides of the clip range
+                v_s = critic(hx).flatten()
+            adv = torch.randn(N, generator=g) * 2.0
+            ret = v_s + adv + 0.3 * torch.randn(N, generator=g)
+            batch = Batch(obs=obs, act=act, adv=adv.clone(), returns=ret, logp_old=logp_old, v_s=v_s, z_mu=mu, info={})
+            p0 = {k: v.detach().clone() for k, v in ac.state_dict().items()}
+            steps = []
+            real_step = optim.step
+
+            def spy_step(*a, **k):
+                steps.append({n_: p_.grad.detach().clone() for n_, p_ in ac.named_parameters()})
+                return real_step(*a, **k)
+            optim.step = spy_step
+            np.random.seed(77)
+            rec["perms"] = []
+            res = pol.learn(batch, BS, 1)
+            pre = case + "_"
+            names = [n_ for n_, _ in ac.named_parameters()]
+            out.update({pre + "fill_seeds": np.array([102, 103, 104], np.int64), pre + "fill_gains": np.array([1.0, 1.4, 1.4]),
+                        pre + "pnet_scale": np.float64(0.05), pre + "state_dict_keys": np.array(list(key_shapes.keys())),
+                        pre + "state_dict_shapes": np.array([str(v) for v in key_shapes.values()]), pre + "batch_size": np.int64(BS),
+                        pre + "perm": rec["perms"][0].astype(np.int64), pre + "act": act.numpy(), pre + "adv": adv.numpy(), pre + "returns": ret.numpy(),
+                        pre + "logp_old": logp_old.numpy(), pre + "v_s": v_s.numpy(), pre + "z_mu": mu.numpy(),
+                        pre + "value_clip": np.int64(kw.get("value_clip", 0)), pre + "dual_clip": np.float64(kw.get("dual_clip") or 0.0),
+                        pre + "param_names": np.array(names)})
+            out.update({pre + "obs_" + k: v.numpy() for k, v in obs.items()})
+            for k, v in res.items():
+                out[pre + "res_" + k.replace("/", "_")] = np.asarray(v, np.float64)
+            for i, gr in enumerate(steps):           # the gradients the optimiser saw (after the actor + critic clip of :244-247)
+                out[f"{pre}mb{i}_grad_norm"] = np.array([float(gr[n_].norm()) for n_ in names])
+                out[f"{pre}mb{i}_grad_head"] = np.stack([np.resize(gr[n_].flatten()[:8].numpy(), 8) for n_ in names])
+                ac_names = [n_ for n_ in names if not n_.startswith("shared_net.")]
+                out[f"{pre}mb{i}_clipped_set_norm"] = np.float64(torch.sqrt(sum(gr[n_].pow(2).sum() for n_ in ac_names)))
+            p1 = ac.state_dict()
+            out[pre + "delta_norm"] = np.array([float((p1[n_] - p0[n_]).norm()) for n_ in names])
+            out[pre + "delta_head"] = np.stack([np.resize((p1[n_] - p0[n_]).flatten()[:8].numpy(), 8) for n_ in names])
+            out[pre + "param_head_after"] = np.stack([np.resize(p1[n_].flatten()[:8].numpy(), 8) for n_ in names])
+            print(case, {k: np.round(v, 5).tolist() for k, v in res.items()}, "clipped-set norms", [float(out[f"{pre}mb{i}_clipped_set_norm"]) for i in range(len(steps))],
+                  "shared_net grad norm", float(np.sqrt(sum(float(steps[0][n_].pow(2).sum()) for n_ in names if n_.startswith("shared_net.")))))
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "ppo_learn_ref.npz"), **out)
+    print("ppo_learn_ref", os.path.getsize(os.path.join(OUT, "ppo_learn_ref.npz")), "bytes")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sdf"]
     for w in which:
-        {"sdf": gen_sdf}[w]()
+        {"sdf": gen_sdf, "box": gen_box, "learn": gen_learn}[w]()

@@ -232,9 +232,9 @@ def test_hip_env_matches_reference_execution(gpu_world, case, blend):
         scene = synth.make_sdf_scene(w["res"])
         rings = synth.sdf_scene_polygon(scene)
         vp = VPoserEncoder()
-        vp.load_state_dict({k: (v if v.dtype != torch.float32 else v) for k, v in
-                            {**seeded_vposer_state_dict(), **{k: v for k, v in _vposer_sd(float(g[pre + "vposer_gain"])).items()
-                                                              if k.startswith("bodyprior_enc_mu.")}}.items()})
+        vsd = seeded_vposer_state_dict()
+        vsd.update({k: v for k, v in _vposer_sd(float(g[pre + "vposer_gain"])).items() if k.startswith("bodyprior_enc_mu.")})
+        vp.load_state_dict(vsd)
         vp.cuda().eval()
         pair = np.asarray(g[pre + "pair"], np.float32).reshape(1, 2, 3)
         env = VecCrowdEnv(1, w["handle"], w["combo"], vp, finetuning=bool(g[pre + "finetuning"]), seed=0, scene_kind="sdf", sdf_dict=scene,
@@ -266,7 +266,7 @@ def test_hip_env_matches_reference_execution(gpu_world, case, blend):
             z = torch.as_tensor(g[pre + "z"][i])[None].cuda().contiguous()
             obs, rew, term = env.step(z, auto_reset=False)
             rt = env.rterms[0].cpu().numpy()
-            got = {"Y_gen": env.Y_gen.reshape(18, 201) if env.Y_gen.shape[0] == 18 else env.Y_gen.reshape(-1, 201),
+            got = {"Y_gen": env.Y_gen.reshape(-1, 201),
                    "pred_params": env.pred_params.reshape(20, 93), "joints": env.joints.reshape(20, -1, 3),
                    "r_skate": rt[0], "r_floor": rt[1], "r_face_target": rt[2], "r_look_target": rt[3], "r_goal": rt[4], "r_target_dist": rt[5],
                    "r_pene": rt[6], "r_vp": rt[7], "reward": rew[0], "terminated": term[0], "after_state": env.state[0],
@@ -276,3 +276,138 @@ def test_hip_env_matches_reference_execution(gpu_world, case, blend):
             assert int(env.steps[0]) == int(g[sp + "after_steps"])
     finally:
         _lib.check(lib.egx_lbs_set_blend_mode(old), "egx_lbs_set_blend_mode")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# box env (crowd_env_2f_box.py) - env_box_ref.npz
+# ----------------------------------------------------------------------------------------------------------------------
+BOX_CASES = ["free", "reject", "cover", "graze"]
+
+
+@pytest.fixture(scope="module")
+def box_world():
+    from egogen_amd import synth
+    g = load_golden("env_box_ref.npz")
+    scenes = [synth.box_scene_from_hole(g[f"scene_{k}_box_lo"], g[f"scene_{k}_box_hi"]) for k in ("s0", "s1")]
+    for sc, k in zip(scenes, ("s0", "s1")):      # the generator's scenes are reproduced from their holes
+        assert np.array_equal(sc["tris"], g[f"scene_{k}_tris"]) and np.array_equal(sc["edges"], g[f"scene_{k}_edges"])
+    return {"g": g, "bm": synth.make_body_model(0), "mk": synth.marker_ids(), "feet": synth.feet_vids(), "fmi": synth.feet_marker_idx(),
+            "prior_sd": seeded_prior_state_dict(int(g["prior_seed"]), *[float(v) for v in g["prior_gains"]]), "scenes": scenes,
+            "cfg": json.loads(str(g["cfg_json"]))}
+
+
+def _box_scene_list(w, pre):
+    from egogen_amd import synth
+    g = w["g"]
+    scenes = list(w["scenes"])
+    if pre + "hole_lo" in g:
+        scenes.append(synth.box_scene_from_hole(g[pre + "hole_lo"].astype(np.float64), g[pre + "hole_hi"].astype(np.float64)))
+    return scenes
+
+
+def _box_got(L, rew, term, o, obs):
+    return {"Y_gen": L["Y_gen"][:, 0], "pred_params": L["pred_params"][0], "joints": L["joints"][0], "marker_b": L["marker_b"][0],
+            "r_skate": L["r_skate"][0], "r_floor": L["r_floor"][0], "r_face_target": L["r_face"][0], "r_look_target": L["r_look"][0],
+            "r_goal": L["r_goal"][0], "r_target_dist": L["r_target_dist"][0], "r_vp": L["r_vp"][0], "r_pene": L["r_pene"][0],
+            "reward": rew[0], "terminated": term[0], "after_state": o.state[0], "after_seed": o.body_param_seed[0], "after_R0": o.R0[0],
+            "after_T0": o.T0[0], "after_dist": o.dist, "obs_ego": obs["egosensing"][0], "obs_dist": obs["dist"], "obs_time": obs["time"]}
+
+
+@pytest.mark.parametrize("case", BOX_CASES)
+def test_oracle_box_env_matches_reference_execution(box_world, case):
+    from oracle.env import OracleCrowdEnv
+    from oracle.smplx_lbs import BodyModel
+    w = box_world
+    g = w["g"]
+    pre = case + "_"
+    scenes = _box_scene_list(w, pre)
+    o = OracleCrowdEnv(BodyModel(w["bm"]), w["prior_sd"], _vposer_sd(1.0), w["mk"], w["feet"], w["fmi"], scene_kind="box", box_scenes=scenes)
+    c = w["cfg"]
+    assert o.cfg["weight_pene"] == c["lossconfig"]["weight_pene"] and o.cfg["pene_type"] == c["lossconfig"]["pene_type"]
+    assert o.cfg["pene_thres"] == c["trainconfig"]["pene_thres"] and o.cfg["max_depth"] == c["trainconfig"]["max_depth"]
+    assert o.cfg["map_res"] == c["modelconfig"]["map_res"] and o.cfg["map_extent"] == c["modelconfig"]["map_extent"]
+    n = int(g[pre + "n_draws"])
+    for i in range(n):      # the reference's `while True` loop: every draw but the last was rejected by the start check
+        d = f"{pre}draw{i}_"
+        poses, trans, betas = _motion_seed(int(g[d + "start_frame"]))
+        pair = torch.as_tensor(g[d + "pair"])
+        tr, go, bp, wpath = o.next_body(pair[0:1], pair[1:2], poses, trans, betas, yaw_jitter=torch.tensor([float(g[d + "yaw_jitter"])]))
+        _close(tr[0], g[d + "transl"], "m", d + "sampler transl")
+        _aa_close(go[0], g[d + "glorot"], d + "sampler glorot")
+        _close(wpath[0], g[d + "wpath"], "m", d + "sampler wpath")
+        sidx = {"s0": 0, "s1": 1}[str(g[d + "scene"])]
+        obs, accept = o.reset_from(tr, go, bp, betas, wpath, scene_idx=[sidx])
+        assert bool(accept[0]) == (i == n - 1), (case, i, bool(accept[0]))
+    _close(o.state[0], g[pre + "reset_state"], "unit", pre + "reset state")
+    _close(o.R0[0], g[pre + "reset_R0"], "unit", pre + "reset R0")
+    _close(o.T0[0].reshape(-1), g[pre + "reset_T0"].reshape(-1), "m", pre + "reset T0")
+    _close(o.dist, g[pre + "reset_dist"], "m", pre + "reset dist")
+    _close(obs["egosensing"][0], g[pre + "reset_obs_ego"], "ego", pre + "reset egosensing")
+    _close(obs["dist"].reshape(-1), g[pre + "reset_obs_dist"], "unit", pre + "reset obs dist")
+    if pre + "hole_lo" in g:
+        o.scene_idx = torch.tensor([2])
+    for i in range(int(g[pre + "n_steps"])):
+        sp = f"{pre}s{i}_"
+        obs, rew, term = o.step(torch.as_tensor(g[pre + "z"][i])[None])
+        _check_step_common(g, sp, _box_got(o.last, rew, term, o, obs))
+        assert float(o.last["num_pene"][0]) == float(g[sp + "num_pene"])
+        assert bool(o.last["penetration"][0]) == bool(g[sp + "penetration"])
+    last = f"{pre}s{int(g[pre + 'n_steps']) - 1}_"
+    if case == "reject":
+        assert n == 3
+    if case == "cover":
+        assert float(g[f"{pre}s0_num_pene"]) > 3 and bool(g[f"{pre}s0_terminated"]) and float(g[f"{pre}s0_r_pene"]) == 0.0
+    if case == "graze":
+        assert 0 < float(g[last + "num_pene"]) <= 3 and not bool(g[last + "terminated"]) and float(g[last + "r_pene"]) == pytest.approx(0.05)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", BOX_CASES)
+def test_hip_box_env_matches_reference_execution(box_world, case):
+    """VecCrowdEnv(scene_kind='box') through the C ABI against the reference's recorded draws / reset / steps: the reset kernel
+    must commit the draw the reference's loop accepted (`choice`), the step kernels the recorded quantities."""
+    from egogen_amd.body_model import BodyModelHandle
+    from egogen_amd.crowd_env import VecCrowdEnv
+    from egogen_amd.models import GAMMAPrimitiveCombo, PREDICTOR_CFG, REGRESSOR_CFG, VPoserEncoder
+    w = box_world
+    g = w["g"]
+    pre = case + "_"
+    scenes = _box_scene_list(w, pre)
+    h = BodyModelHandle(w["bm"], w["mk"], w["feet"])
+    combo = GAMMAPrimitiveCombo(PREDICTOR_CFG, REGRESSOR_CFG)
+    combo.load_state_dict(w["prior_sd"])
+    combo.cuda().eval()
+    vp = VPoserEncoder()
+    vp.load_state_dict(seeded_vposer_state_dict())
+    vp.cuda().eval()
+    env = VecCrowdEnv(1, h, combo, vp, seed=0, scene_kind="box", box_scenes=scenes)
+    K, n = env.K, int(g[pre + "n_draws"])
+    assert n <= K
+    idx = [min(i, n - 1) for i in range(K)]          # the recorded draws, the accepted one repeated up to K
+    pairs = np.stack([g[f"{pre}draw{i}_pair"] for i in idx]).reshape(1, K, 2, 3)
+    yaw = np.array([[float(g[f"{pre}draw{i}_yaw_jitter"]) for i in idx]], np.float32)
+    variant = np.array([[env.variant_starts.index(int(g[f"{pre}draw{i}_start_frame"])) for i in idx]])
+    scene = np.array([[{"s0": 0, "s1": 1}[str(g[f"{pre}draw{i}_scene"])] for i in idx]])
+    env.set_candidates(pairs, yaw, variant, scene)
+    obs = env.reset()
+    assert int(env.choice[0]) == n - 1 and env.forced_accepts() == 0
+    _close(env.wpath[0], g[pre + "reset_wpath"], "m", pre + "wpath")
+    _close(env.state[0], g[pre + "reset_state"], "unit", pre + "reset state")
+    _close(env.R0[0], g[pre + "reset_R0"], "unit", pre + "reset R0")
+    _close(env.T0[0], g[pre + "reset_T0"].reshape(-1), "m", pre + "reset T0")
+    _close(env.dist, g[pre + "reset_dist"], "m", pre + "reset dist")
+    _close(obs["egosensing"][0], g[pre + "reset_obs_ego"], "ego", pre + "reset egosensing")
+    _close(obs["dist"].reshape(-1), g[pre + "reset_obs_dist"], "unit", pre + "reset obs dist")
+    if pre + "hole_lo" in g:
+        env.scene_idx.fill_(2)
+    for i in range(int(g[pre + "n_steps"])):
+        sp = f"{pre}s{i}_"
+        z = torch.as_tensor(g[pre + "z"][i])[None].cuda().contiguous()
+        obs, rew, term = env.step(z, auto_reset=False)
+        rt = env.rterms[0].cpu().numpy()
+        got = {"Y_gen": env.Y_gen.reshape(-1, 201), "pred_params": env.pred_params.reshape(20, 93), "joints": env.joints.reshape(20, -1, 3),
+               "r_skate": rt[0], "r_floor": rt[1], "r_face_target": rt[2], "r_look_target": rt[3], "r_goal": rt[4], "r_target_dist": rt[5],
+               "r_pene": rt[6], "r_vp": rt[7], "reward": rew[0], "terminated": term[0], "after_state": env.state[0],
+               "after_seed": env.seed[0].cpu(), "after_R0": env.R0[0], "after_T0": env.T0[0].cpu(), "after_dist": env.dist.cpu(),
+               "obs_ego": obs["egosensing"][0], "obs_dist": obs["dist"].cpu(), "obs_time": obs["time"].cpu()}
+        _check_step_common(g, sp, got)
