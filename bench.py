@@ -49,9 +49,11 @@ sys.path.insert(0, ROOT)
 FLOP_PER_BODY = 2.0 * 469 * 31425          # blend GEMM only: K = 10 betas + 9 x 51 movable joints (jaw/eye columns are exactly 0)
 # of which the kernel evaluates the vertex tiles that hold a picked vertex or a vertex of the penetration count (the count
 # excludes the feet, crowd_env_2f.py:163-175): `flop_per_body` of the roofline object is 2 * 469 * 3 * that vertex count
+BLEND_NAME = {0: "f32", 1: "bf16x3", 2: "bf16x2", 3: "f16mix"}
 PEAK_F32_MFMA_TFLOPS = 157.3               # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 MFMA peak (same guide)
-BLEND_PRODUCTS = {0: None, 1: 6, 2: 3}     # bf16 partial products per fp32 product of the split blend modes
+BLEND_PRODUCTS = {0: None, 1: 6, 2: 3, 3: 34.0 / 30.0}   # 16-bit MFMA products per fp32 product of the split blend modes (3 = f16mix:
+#                                             two k-steps of 30 with three bf16 products, 28 with one fp16 product)
 
 
 def get_args():
@@ -74,7 +76,7 @@ def get_args():
                    help="synthetic body: iid = SURVEY 8(d)'s (i.i.d. noise blend shapes; the headline), structured = blend shapes with "
                         "the structure of a learned model (smooth shape fields, local pose correctives): SDF work items can be culled")
     p.add_argument("--lbs-cull", type=int, default=0, help="free-space culling of SDF work items (opt-in; models whose bound is tight)")
-    p.add_argument("--lbs-blend", type=str, default="", choices=["", "f32", "bf16x3", "bf16x2"],
+    p.add_argument("--lbs-blend", type=str, default="", choices=["", "f32", "bf16x3", "bf16x2", "f16mix"],
                    help="arithmetic of the LBS blend GEMM (default: the library's default, two bf16 planes)")
     p.add_argument("--update-prec", type=str, default="bf16x2", choices=["f32", "bf16x2", "bf16"],
                    help="arithmetic of the PPO update's products (GAMMAPPOPolicy update_precision): three / two / one bf16 terms per operand")
@@ -574,7 +576,7 @@ def main():
         bm, _ = sw.load_body_model("male", seed=0, num_verts=args.num_verts)
     body = BodyModelHandle(bm, synth.marker_ids(args.num_verts), synth.feet_vids(args.num_verts))
     if args.lbs_blend:
-        _lib.check(lib.egx_lbs_set_blend_mode({"f32": 0, "bf16x3": 1, "bf16x2": 2}[args.lbs_blend]), "egx_lbs_set_blend_mode")
+        _lib.check(lib.egx_lbs_set_blend_mode({"f32": 0, "bf16x3": 1, "bf16x2": 2, "f16mix": 3}[args.lbs_blend]), "egx_lbs_set_blend_mode")
     _lib.check(lib.egx_policy_set_precision({"f32": 0, "bf16x2": 2, "bf16": 1}[args.policy_prec]), "egx_policy_set_precision")
     ops = (body, sw.build_motion_prior(seed=0), sw.build_vposer(seed=0))
     scene = sw.build_scene(args.scene, sdf_res=args.sdf_res, seed=0)
@@ -591,7 +593,8 @@ def main():
     # applies only to the configuration that pass was taken on
     traffic = None
     try:
-        for name in (f"r04_lbs_pmc_mode{blend}.json", f"r03_lbs_pmc_mode{blend}.json", f"r02_lbs_pmc_mode{blend}.json"):   # newest round first
+        for name in (f"r05_lbs_pmc_mode{blend}.json", f"r04_lbs_pmc_mode{blend}.json", f"r03_lbs_pmc_mode{blend}.json",
+                     f"r02_lbs_pmc_mode{blend}.json"):   # newest round first
             f = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(f):
                 continue
@@ -607,14 +610,14 @@ def main():
     verts_eval = bm_handle.lbs_vertices["sdf" if m["env"].sdf is not None else "picks"]
     FLOP_PER_BODY = 2.0 * 469 * 3 * verts_eval     # noqa: N806 - the work this call form needs (see the module constant)
     achieved = FLOP_PER_BODY * bodies / (lbs_ms * 1e-3) / 1e12
-    if blend in (1, 2):
+    if blend in (1, 2, 3):
         # n-term bf16 split: BLEND_PRODUCTS bf16 MFMA products per fp32 product -> the matrix-pipe ceiling of the
         # ALGORITHMIC fp32 flops is the dense bf16 peak / that count
         npr = BLEND_PRODUCTS[blend]
         kernel_name, peak = "egx_lbs_fused3_kernel", PEAK_BF16_MFMA_TFLOPS / npr
-        peak_note = (f"dense bf16 MFMA peak 2500 TFLOP/s / {npr} partial products per fp32 product "
-                     f"(bf16x{3 if blend == 1 else 2} split, fp32 accumulate)")
-        executed = npr * 2.0 * 480 * (328 * 32 * 3) * bodies / (lbs_ms * 1e-3) / 1e12 if args.num_verts == 10475 else None
+        peak_note = (f"dense 16-bit MFMA peak 2500 TFLOP/s / {npr:.3g} products per fp32 product "
+                     f"({BLEND_NAME[blend]}, fp32 accumulate)")
+        executed = npr * 2.0 * 480 * (328 * 32 * 3) * bodies / (lbs_ms * 1e-3) / 1e12 if args.num_verts == 10475 else None   # all 328 tiles: upper bound
     else:
         kernel_name, peak, peak_note, executed = "egx_lbs_fused_kernel", PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA peak", None
     def _cull_stats():
@@ -636,8 +639,8 @@ def main():
     if in_scene is not None:
         in_scene["achieved"] = FLOP_PER_BODY * bodies / (in_scene["avg_launch_ms"] * 1e-3) / 1e12
         in_scene["frac"] = in_scene["achieved"] / peak
-        if blend in (1, 2):  # the same launch in the other split mode (three planes <-> two planes), for the record
-            alt = 3 - blend
+        if blend in (1, 2, 3):  # the same launch in another split mode (three planes <-> two planes), for the record
+            alt = 3 - blend if blend in (1, 2) else 2
             _lib.check(lib.egx_lbs_set_blend_mode(alt), "egx_lbs_set_blend_mode")
             try:
                 o = _lbs_in_scene_ms(m["env"], lib)
@@ -645,7 +648,7 @@ def main():
                 _lib.check(lib.egx_lbs_set_blend_mode(blend), "egx_lbs_set_blend_mode")
             o_peak = PEAK_BF16_MFMA_TFLOPS / BLEND_PRODUCTS[alt]
             o["achieved"] = FLOP_PER_BODY * bodies / (o["avg_launch_ms"] * 1e-3) / 1e12
-            other_mode = {"blend": f"bf16x{3 if alt == 1 else 2}", "in_scene_avg_launch_ms": o["avg_launch_ms"], "achieved": o["achieved"],
+            other_mode = {"blend": BLEND_NAME[alt], "in_scene_avg_launch_ms": o["avg_launch_ms"], "achieved": o["achieved"],
                           "peak": o_peak, "frac": o["achieved"] / o_peak}
 
     total_agents = A * world
@@ -663,10 +666,11 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": ("f32" if blend == 0 else f"f32 (blend GEMM operands as {3 if blend == 1 else 2}-term bf16 splits, fp32 accumulate)")
+        "dtype": ("f32" if blend == 0 else ("f32 (blend GEMM: shape/template columns as 2-term bf16 splits, pose correctives as one fp16 product, "
+                                            "fp32 accumulate)" if blend == 3 else f"f32 (blend GEMM operands as {3 if blend == 1 else 2}-term bf16 splits, fp32 accumulate)"))
                  + {"f32": "", "bf16x2": "; PPO update products on 2-term bf16 splits", "bf16": "; PPO update products on bf16 operands"}[args.update_prec]
                  + {"f32": "", "bf16x2": "; rollout policy layers on 2-term bf16 splits", "bf16": "; rollout policy layers on bf16 operands"}[args.policy_prec],
-        "precision": {"lbs_blend": {0: "f32", 1: "bf16x3", 2: "bf16x2"}[blend], "ppo_update": args.update_prec, "rollout_policy": args.policy_prec,
+        "precision": {"lbs_blend": BLEND_NAME[blend], "ppo_update": args.update_prec, "rollout_policy": args.policy_prec,
                       "motion_prior": "f32 (3-term bf16 splits, 2^-24)", "accumulate": "f32",
                       "note": "bf16xN = every fp32 operand carried as N bf16 terms (8 N significant bits), partial products on the bf16 "
                               "MFMA, fp32 accumulation; the strictly fp32-equivalent configuration (--lbs-blend bf16x3 --update-prec f32 "

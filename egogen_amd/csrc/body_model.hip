@@ -77,6 +77,25 @@ __host__ __device__ inline void egx_bf16_split3(float x, unsigned short* h) {
   const float r2 = r1 - egx_bf16_to_f32(h[1]);  // exact
   h[2] = egx_bf16_rne(r2);
 }
+// Mixed blend (LBS blend mode 3): the two k-steps that hold metre-scale or shape columns - k-step 0 (10 betas + 6 pose
+// columns) and k-step 29 (pose columns, template, template residual) - keep the two-plane bf16 split (three products); the 28
+// k-steps in between hold pose-corrective columns only (centimetre-scale offsets) and run as ONE v_mfma_f32_32x32x16_f16 product
+// on operands rounded to fp16 (11 significant bits: 2^-12 per operand; fp16's range covers both the bases, |x| < 1, and the
+// features R - I in [-2, 2]).  Against float64 that moves a vertex by ~4 um rms / ~22 um worst case on the synthetic body
+// (offsets 1.3 cm rms, 7 cm max) - 2e-5 of a metre-scale coordinate, a fifth of north_star's 1e-4 - for 204 instead of 540
+// MFMAs per wave and item and a third of the operand bytes.  Operand images are sequences of 1 KiB PIECES:
+//   bases    [vt][96 pieces][64 lanes] 8 x 16 bit: k-step 0 (plane, coord) 0..5 | k-steps 1..28 coord 6..89 | k-step 29 (plane, coord) 90..95
+//   features [bt][32 pieces][64 lanes]            : k-step 0 planes 0, 1         | k-steps 1..28 2..29        | k-step 29 planes 30, 31
+constexpr int M4_BASE_PIECES = 96, M4_FEAT_PIECES = 32;
+constexpr int M4_FKS = 4;                       // fp16 k-steps per stage (7 stages) between the two precise stages
+__host__ __device__ inline int egx_m4_feat_piece(int s, int pl) { return s == 0 ? pl : (s <= 28 ? s + 1 : 30 + pl); }
+__host__ __device__ inline int egx_m4_base_piece(int s, int pl, int c) { return s == 0 ? pl * 3 + c : (s <= 28 ? 6 + (s - 1) * 3 + c : 90 + pl * 3 + c); }
+__host__ __device__ inline unsigned short egx_f16_rne(float x) {
+  const _Float16 h = (_Float16)x;
+  unsigned short u;
+  __builtin_memcpy(&u, &h, 2);
+  return u;
+}
 __host__ __device__ inline int egx_compact_joint(int j) { return (j - 1) - (j > 24 ? 3 : 0); }  // j in 1..54, j != 22..24
 constexpr int NLMK = 51, NEXTRA = 21;
 constexpr int BODY_PAD = 256;          // bodies per workgroup of the fused kernel
@@ -97,6 +116,7 @@ struct egx_body_model {
   int V = 0, NVT = 0, NW = 0, M = 0, NP = 0;
   f32x4* dirs = nullptr;       // [NVT][59][3][64] float4 (fp32 blend)
   bf16x8* dirs3 = nullptr;     // [NVT][30 k-steps][3 planes][3 coords][64 lanes] 8 x bf16 (bf16x3 blend)
+  bf16x8* dirs4 = nullptr;     // [NVT][96 pieces][64 lanes] 8 x 16 bit (mixed blend, mode 3: see M4_BASE_PIECES)
   int* tj_off = nullptr;       // [NVT+1] offsets into the per-tile joint lists
   int* tj_idx = nullptr;       // [tj_off[NVT]] joints with a non-zero skinning weight on some vertex of the tile
   float* tj_w = nullptr;       // [tj_off[NVT]][32] dense weights of the tile's 32 vertices for that joint
@@ -118,6 +138,7 @@ struct egx_body_model {
   float* cull_E = nullptr;     // [NVT][64]: [0,10) shape terms, [10,61) pose terms per movable joint (compact order), rest 0
   float* cull_D0 = nullptr;    // [tj_off[NVT]]: rest distance bound per (tile, joint of its list)
   int cull_ok = 0;             // skinning weights are a convex combination (>= 0, rows sum to 1): the bound holds
+  int sdf_lead_picks = 0;      // sdf_tiles starts with pick_tiles (in the same order)
   float rest_pelvis[3] = {0.f, 0.f, 0.f};   // root joint of the mean shape (host copy)
   float cull_ref_margin = 0.f;              // blend-shape margin of the median tile at the reference pose (metres)
 };
@@ -133,6 +154,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
                                                              f32x4* __restrict__ A4,     // [bt][55][3][32]
                                                              float* __restrict__ out_joints, int joints_ld,
                                                              float template_lo_feat /* 1 in the two-plane blend mode */,
+                                                             unsigned short* __restrict__ feat4 /* mixed-blend image (mode 3) or null */,
                                                              int* __restrict__ zero_counts /* [B] cleared here, or null */,
                                                              const int* __restrict__ agent_of_slot /* culled launches: slot order */,
                                                              float* __restrict__ fvec /* [64][Bp] |beta|, ||R_j - I||_F or null */,
@@ -142,6 +164,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
   __shared__ float sJ[4][NJ][3];
   __shared__ float sG[4][NJ][12];
   __shared__ __attribute__((aligned(16))) unsigned short sF3[4][3][KS3 * 16];  // bf16x3 planes of the 4 bodies of the block
+  __shared__ __attribute__((aligned(16))) unsigned short sF4[4][KS3 * 16];     // fp16 values (mixed blend, k-steps 1..28)
   const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
   // a block works on four SLOTS of the operand buffers; slot s holds body agent_of_slot[s / fpa] * fpa + s % fpa (identity
   // without the table): inputs and per-body outputs are addressed by body, the GEMM operands by slot
@@ -166,6 +189,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       egx_bf16_split3(v, h);
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) sF3[w][pl][k] = h[pl];
+      if (feat4) sF4[w][k] = egx_f16_rne(v);   // the mixed blend reads k-steps 1..28 as one fp16 plane
     }
   };
   float R[9], Jr[3];
@@ -241,6 +265,20 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       }
     }
   }
+  if (feat3 && feat4) {
+    // the mixed image: 32 pieces per body tile (two bf16 planes of k-steps 0 and 29, one fp16 plane of k-steps 1..28)
+    for (int c = threadIdx.x; c < M4_FEAT_PIECES * 2 * 4; c += 256) {
+      const int wb = c & 3, hf = (c >> 2) & 1, piece = c >> 3;
+      const int sidx = piece < 2 ? 0 : (piece < 30 ? piece - 1 : 29), pl = piece < 2 ? piece : (piece < 30 ? 0 : piece - 30);
+      const int body = blockIdx.x * 4 + wb;   // slot
+      if (body < B) {
+        const unsigned short* src = (piece >= 2 && piece < 30) ? &sF4[wb][sidx * 16 + hf * 8] : &sF3[wb][pl][sidx * 16 + hf * 8];
+        const int4 frag = *reinterpret_cast<const int4*>(src);
+        unsigned short* dst = feat4 + (((size_t)(body >> 5) * M4_FEAT_PIECES + piece) * 64 + hf * 32 + (body & 31)) * 8;
+        *reinterpret_cast<int4*>(dst) = frag;
+      }
+    }
+  }
 
   const int par = (j < NJ) ? pc->parents[j] : -1;
   const int dep = (j < NJ) ? pc->depth[j] : -1;
@@ -306,6 +344,9 @@ struct LbsParams {
   const int* vorig;    // original vertex id per sorted row
   const bf16x8* dirs3; // bf16x3 bases (blend mode 1)
   const bf16x8* feat3; // [bt][30][3 planes][64] 8 x bf16
+  const bf16x8* dirs4; // mixed-blend bases (mode 3), [vt][96 pieces][64]
+  const bf16x8* feat4; // mixed-blend features, [bt][32 pieces][64]
+  int n_precise;       // mode 3: the first n_precise entries of `tiles` (the tiles that hold picked vertices) use the two-plane split
   const f32x4* feat;   // [bt][59][64] float4
   const f32x4* A4;     // [bt][55][3][32] float4
   const float* xb;     // transl = xb[b*93 + 0..2]
@@ -443,8 +484,13 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
     }
     __builtin_amdgcn_wave_barrier();
   };
-  const unsigned pick_mask = p.picked ? s_masks[0] : 0u;
-  const unsigned sdf_mask = s_masks[1];
+  // both masks are properties of the TILE: wave-uniform, kept in SGPRs (readfirstlane), so "does this tile hold picked
+  // vertices" (8 of 328 tiles) is a scalar branch; the lane's share is one shift by 4 * half, after which every row test is a
+  // compile-time bit position.  (Round 4 tested `mask >> row` with row = f(r, half): the compiler hoisted sixteen per-lane
+  // `1 << row` constants out of the persistent loop and spilled eleven of them - scratch reloads, each with a vmcnt(0) that
+  // drained the transform prefetch.)
+  const unsigned pick_mask = p.picked ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_masks[0]) : 0u;
+  const unsigned sdf_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)s_masks[1]);
 #ifdef EGX_LBS_TIMING
   unsigned long long et[4] = {0, 0, 0, 0};
 #endif
@@ -548,7 +594,11 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
           }
         }
       }
-      if (cnt != 0) atomicAdd(&s_cnt[q * 32 + n], cnt);
+      if (cnt != 0) {
+        int nn = n;                       // address formed here (see run_item: no loop-invariant per-lane address to keep alive)
+        asm volatile("" : "+v"(nn));
+        atomicAdd(&s_cnt[q * 32 + nn], cnt);
+      }
       if (WRITE_VERTS) { sdf_flush(qn); qn = 0; }  // the queue shares its LDS with the vertex transpose buffer
     }
 #ifdef EGX_LBS_TIMING
@@ -556,12 +606,14 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
     const unsigned long long q2 = LBS_NOW();
     et[1] += q2 - q1;
 #endif
-    if (pick_mask != 0 && bvalid[q]) {
+    if (pick_mask != 0) {   // scalar branch
+      const unsigned pmine = bvalid[q] ? (pick_mask >> (4 * half)) : 0u;   // bit (r&3)+8(r>>2) = this lane's row r
+      const int* slot_h = s_slot + 4 * half;
+      float* pbase = p.picked + (size_t)body[q] * p.NP * 3;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if ((pick_mask >> row) & 1u) {
-          float* op = p.picked + ((size_t)body[q] * p.NP + s_slot[row]) * 3;
+        if ((pmine >> ((r & 3) + 8 * (r >> 2))) & 1u) {
+          float* op = pbase + slot_h[(r & 3) + 8 * (r >> 2)] * 3;
           op[0] = o[r][0]; op[1] = o[r][1]; op[2] = o[r][2];
         }
       }
@@ -761,6 +813,7 @@ __device__ __forceinline__ void lbs_blend_split(const LbsParams& p, f32x16 (&acc
   using Cfg = Wg4Cfg<NPL>;
   constexpr int NB = LBS_NB, SKS = Cfg::STAGE_KS, SP = Cfg::STAGE_PIECES;
   const int num_bt = (p.B + 31) >> 5;
+  asm volatile("" : "+v"(lane));   // per-lane operand addresses are formed per item (not kept alive as invariants of the persistent loop)
   const bf16x8* dpv = p.dirs3 + (size_t)vt * KS3 * 9 * 64 + lane;  // piece (s, plane, coord) at ((s*3 + plane)*3 + coord)*64
   const bf16x8* fq[NB];
 #pragma unroll
@@ -830,11 +883,89 @@ __device__ __forceinline__ void lbs_blend_split(const LbsParams& p, f32x16 (&acc
   }
 }
 
+// Mixed blend (mode 3, see M4_BASE_PIECES): nine stages per item - the precise k-step 0, seven stages of four fp16 k-steps, the
+// precise k-step 29 - each a burst (this wave's share of the stage's base pieces + its own feature pieces), s_waitcnt, the base
+// pieces through the two-deep LDS ring, one barrier, then only MFMAs (the in-flight-load hazard of lbs_blend_f32).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int M4_RING_PIECES = 3 * M4_FKS;      // 12 KiB per ring slot (a precise stage uses 6)
+static_assert(28 % M4_FKS == 0, "fp16 stages cover k-steps 1..28 exactly");
+
+template <bool PRECISE>
+__device__ __forceinline__ void lbs_mixed_stage(const bf16x8* __restrict__ dpv, const bf16x8* const (&fq)[LBS_NB], int dp0, int fp0,
+                                                f32x16 (&acc)[3][LBS_NB], int wave, int lane, bf16x8* buf) {
+  constexpr int NB = LBS_NB;
+  constexpr int NP = PRECISE ? 6 : 3 * M4_FKS;    // base pieces of the stage
+  constexpr int NF = PRECISE ? 2 : M4_FKS;        // feature pieces per body tile
+  constexpr int NGA = (NP + 3) / 4;
+  bf16x8 ga[NGA], b[NF][NB];
+#pragma unroll
+  for (int i = 0; i < NGA; ++i) {
+    const int piece = wave + 4 * i;
+    if (piece < NP) ga[i] = dpv[(size_t)(dp0 + piece) * 64];
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int q = 0; q < NB; ++q) b[f][q] = fq[q][(size_t)(fp0 + f) * 64];
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NGA; ++i) {
+    const int piece = wave + 4 * i;
+    if (piece < NP) buf[piece * 64 + lane] = ga[i];
+  }
+  __syncthreads();  // stage visible; also: everyone is done reading the other ring slot's previous contents
+  if (PRECISE) {
+    bf16x8 a[2][3];   // [plane][coord]
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[pl][c] = buf[(pl * 3 + c) * 64 + lane];
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {   // hi.mid, mid.hi, hi.hi: small partial products first, product-major
+      const int pa = (pr == 1) ? 1 : 0, pb = (pr == 0) ? 1 : 0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][c], b[pb][q], acc[c][q], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < M4_FKS; ++ks) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[c] = buf[(ks * 3 + c) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[c]), __builtin_bit_cast(f16x8, b[ks][q]),
+                                                             acc[c][q], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void lbs_blend_mixed(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave, bf16x8* sA) {
+  constexpr int NB = LBS_NB;
+  const int num_bt = (p.B + 31) >> 5;
+  asm volatile("" : "+v"(lane));   // per-lane operand addresses are formed per item
+  const bf16x8* dpv = p.dirs4 + (size_t)vt * M4_BASE_PIECES * 64 + lane;
+  const bf16x8* fq[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) fq[q] = p.feat4 + (size_t)min(bt0 + q, num_bt - 1) * M4_FEAT_PIECES * 64 + lane;
+  lbs_mixed_stage<true>(dpv, fq, 0, 0, acc, wave, lane, sA);
+  for (int st = 0; st < 28 / M4_FKS; ++st)
+    lbs_mixed_stage<false>(dpv, fq, 6 + st * 3 * M4_FKS, 2 + st * M4_FKS, acc, wave, lane, sA + ((st + 1) & 1) * M4_RING_PIECES * 64);
+  lbs_mixed_stage<true>(dpv, fq, 90, 30, acc, wave, lane, sA + ((28 / M4_FKS + 1) & 1) * M4_RING_PIECES * 64);
+}
+
 template <int NPL, bool DO_SDF>
 __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
   constexpr int NB = LBS_NB;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id: an SGPR
   bf16x8* sA = reinterpret_cast<bf16x8*>(smem_raw);
   char* meta = smem_raw + 2 * 18 * 1024;
   char* my = smem_raw + LBS3_SHARED_BYTES + wave * LBS3_WAVE_BYTES;
@@ -887,7 +1018,11 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
     __syncthreads();  // previous item: every wave is done with the metadata and with the stage ring
     const int j_lo = p.tj_off[vt];
     const int JT = p.tj_off[vt + 1] - j_lo;
-    for (int idx = threadIdx.x * 4; idx < JT * 32; idx += 1024)
+    // (the thread index goes through an empty asm so that per-lane addresses derived from it are formed here, per item: as
+    // invariants of the persistent loop they were kept alive across the whole item and spilled to scratch)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    for (int idx = tid * 4; idx < JT * 32; idx += 1024)
       *reinterpret_cast<f32x4*>(&w.s_W[idx]) = *reinterpret_cast<const f32x4*>(&p.tj_w[(size_t)j_lo * 32 + idx]);
     if (wave == 0) {
       if (lane < JT) w.s_jl[lane] = p.tj_idx[j_lo + lane];
@@ -904,8 +1039,15 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
       for (int q = 0; q < NB; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
-    if (!(p.dbg & 2)) lbs_blend_split<NPL>(p, acc, vt, bt0, lane, wave, sA, tacc);
-    else __syncthreads();  // the blend's barriers also publish the metadata
+    if (!(p.dbg & 2)) {
+      if constexpr (NPL == 4) {      // NPL 4 = the mixed blend (mode 3)
+        // the tiles that hold the PICKED vertices (markers, vertex joints, landmark corners: the 8 leading tiles of 328) keep the
+        // two-plane split: what the environment reads as positions - and differentiates into directions (the eye landmarks are
+        // centimetres apart and aim 7 m rays) - stays at the 1e-6 m level; the fp16 product only feeds the penetration COUNT
+        if (vti < p.n_precise) lbs_blend_split<2>(p, acc, vt, bt0, lane, wave, sA, tacc);
+        else lbs_blend_mixed(p, acc, vt, bt0, lane, wave, sA);
+      } else lbs_blend_split<NPL>(p, acc, vt, bt0, lane, wave, sA, tacc);
+    } else __syncthreads();  // the blend's barriers also publish the metadata
     if (p.dbg & 1) {
       float sum = 0.f;
 #pragma unroll
@@ -919,24 +1061,26 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
     }
     lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP>(p, w, acc, vt, bt0, JT);
   };
-  if (p.items) {
-    // culled launch: this XCD's list of active items (egx_lbs_compact_kernel: an item whose 256 bodies are provably in free
-    // space for the whole vertex tile is not on it), dealt round-robin to the XCD's workgroups
-    const int xcd = blockIdx.x & 7, ns = gridDim.x >> 3, st = blockIdx.x >> 3;
-    const int cnt = p.item_counts[xcd];
-    const int* list = p.items + (size_t)xcd * p.items_stride;
-    for (int i = st; i < cnt; i += ns) {
-      const int code = list[i];
-      const int vti = code / p.nbg;
-      run_item(vti, code - vti * p.nbg);
-    }
-  } else {
-    for (int item = stream; item < n_items; item += n_streams) {
+  // one loop for both item sources (the body is inlined once): a culled launch walks this XCD's list of active items
+  // (egx_lbs_compact_kernel: an item whose 256 bodies are provably in free space for the whole vertex tile is not on it), dealt
+  // round-robin to the XCD's workgroups; otherwise the blocked (tile, body group) order above
+  const int* list = p.items ? p.items + (size_t)(blockIdx.x & 7) * p.items_stride : nullptr;
+  const int i_lo = list ? (int)(blockIdx.x >> 3) : stream, i_step = list ? (int)(gridDim.x >> 3) : n_streams;
+  const int i_hi = list ? p.item_counts[blockIdx.x & 7] : n_items;
+  for (int item = i_lo; item < i_hi; item += i_step) {
+    int vti, bg;
+    if (list) {
+      const int code = list[item];
+      vti = code / p.nbg;
+      bg = code - vti * p.nbg;
+    } else {
       const int blk = item / (nvt * PB);
       const int pb = min(PB, nper - blk * PB);
       const int r = item - blk * nvt * PB;
-      run_item(vt_lo + r / pb, bg_lo + blk * PB + r % pb);
+      vti = vt_lo + r / pb;
+      bg = bg_lo + blk * PB + r % pb;
     }
+    run_item(vti, bg);
   }
 #ifdef EGX_LBS_TIMING
   if (lane == 0)
@@ -1277,6 +1421,24 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
           }
         }
 
+  // the mixed-blend image (mode 3): the same values, k-steps 0 and 29 as two bf16 planes, k-steps 1..28 as one fp16 plane
+  std::vector<unsigned short> dirs4((size_t)NVT * M4_BASE_PIECES * 64 * 8, 0);
+  for (int vt = 0; vt < NVT; ++vt)
+    for (int sidx = 0; sidx < KS3; ++sidx)
+      for (int c = 0; c < 3; ++c)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 8; ++e) {
+            const size_t src = (((((size_t)vt * KS3 + sidx) * 3 + 0) * 3 + c) * 64 + l) * 8 + e;      // plane 0 of dirs3
+            const size_t pstride = (size_t)3 * 64 * 8;                                               // plane stride in dirs3
+            if (sidx == 0 || sidx == KS3 - 1) {
+              for (int pl = 0; pl < 2; ++pl)
+                dirs4[(((size_t)vt * M4_BASE_PIECES + egx_m4_base_piece(sidx, pl, c)) * 64 + l) * 8 + e] = dirs3[src + pl * pstride];
+            } else {
+              const float val = egx_bf16_to_f32(dirs3[src]) + egx_bf16_to_f32(dirs3[src + pstride]) + egx_bf16_to_f32(dirs3[src + 2 * pstride]);
+              dirs4[(((size_t)vt * M4_BASE_PIECES + egx_m4_base_piece(sidx, 0, c)) * 64 + l) * 8 + e] = egx_f16_rne(val);
+            }
+          }
+
   // skinning weights -> per-tile joint lists: the joints any of the tile's 32 vertices is bound to, with the dense
   // [32] weight column of each.  The epilogue walks this list once per body tile (one transform fetch per joint
   // instead of one per vertex and weight).
@@ -1401,6 +1563,11 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
     }
     if (std::fabs(sum - 1.0) > 1e-4) convex = false;
   }
+  {
+    bool lead = pick_tiles.size() <= sdf_tiles.size();
+    for (size_t i = 0; i < pick_tiles.size() && lead; ++i) lead = sdf_tiles[i] == pick_tiles[i];
+    m->sdf_lead_picks = lead ? 1 : 0;
+  }
   // the culled launch treats the first n_pick_tiles entries of the SDF tile list as "always evaluated"
   for (size_t i = 0; i < pick_tiles.size() && convex; ++i) convex = i < sdf_tiles.size() && sdf_tiles[i] == pick_tiles[i];
   m->cull_ok = convex ? 1 : 0;
@@ -1466,6 +1633,9 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
     unsigned short* d3 = nullptr;
     if ((rc = upload(&d3, dirs3))) { egx_body_model_destroy(m); return rc; }
     m->dirs3 = reinterpret_cast<bf16x8*>(d3);
+    unsigned short* d4 = nullptr;
+    if ((rc = upload(&d4, dirs4))) { egx_body_model_destroy(m); return rc; }
+    m->dirs4 = reinterpret_cast<bf16x8*>(d4);
   }
   if ((rc = upload(&m->vorig, perm)) || (rc = upload(&m->pick_tiles, pick_tiles)) ||
       (rc = upload(&m->sdf_tiles, sdf_tiles))) { egx_body_model_destroy(m); return rc; }
@@ -1482,7 +1652,7 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
 
 extern "C" void egx_body_model_destroy(egx_body_model* m) {
   if (!m) return;
-  (void)hipFree(m->dirs); (void)hipFree(m->dirs3); (void)hipFree(m->tj_off); (void)hipFree(m->tj_idx); (void)hipFree(m->tj_w);
+  (void)hipFree(m->dirs); (void)hipFree(m->dirs3); (void)hipFree(m->dirs4); (void)hipFree(m->tj_off); (void)hipFree(m->tj_idx); (void)hipFree(m->tj_w);
   (void)hipFree(m->pick_slot); (void)hipFree(m->pick_tiles); (void)hipFree(m->sdf_tiles); (void)hipFree(m->vflags); (void)hipFree(m->vorig); (void)hipFree(m->pc); (void)hipFree(m->marker_slot);
   (void)hipFree(m->extra_slot); (void)hipFree(m->lmk_slot); (void)hipFree(m->lmk_bary);
   (void)hipFree(m->cull_E); (void)hipFree(m->cull_D0);
@@ -1510,13 +1680,13 @@ int blend_mode() {
   if (m < 0) {
     const char* e = getenv("EGX_LBS_BLEND");
     const std::string v = e ? e : "";
-    m = (v == "f32" || v == "0") ? 0 : ((v == "bf16x3" || v == "1") ? 1 : 2);
+    m = (v == "f32" || v == "0") ? 0 : ((v == "bf16x3" || v == "1") ? 1 : ((v == "bf16x2" || v == "2") ? 2 : 3));   // default: f16mix
     g_blend_mode.store(m);
   }
   return m;
 }
 struct WsLayout {
-  size_t feat, A4, picked, total;
+  size_t feat, feat4, A4, picked, total;
   // culled SDF launches
   size_t fvec, jpos, order, flags, items, counts;
   size_t Bp;
@@ -1527,7 +1697,8 @@ WsLayout ws_layout(const egx_body_model* m, int B) {
   WsLayout w;
   w.Bp = Bp;
   w.feat = 0;
-  w.A4 = egx_align_up(w.feat + Bp * std::max<size_t>(KDIM * sizeof(float), (size_t)KS3 * 16 * 3 * 2), 256);
+  w.feat4 = egx_align_up(w.feat + Bp * std::max<size_t>(KDIM * sizeof(float), (size_t)KS3 * 16 * 3 * 2), 256);   // mixed-blend features (mode 3)
+  w.A4 = egx_align_up(w.feat4 + Bp * ((size_t)M4_FEAT_PIECES * 64 * 16 / 32), 256);   // 32 KiB per 32-body tile
   w.picked = egx_align_up(w.A4 + Bp * NJ * 12 * sizeof(float), 256);
   w.fvec = egx_align_up(w.picked + (size_t)B * m->NP * 3 * sizeof(float), 256);
   w.jpos = egx_align_up(w.fvec + 64 * Bp * sizeof(float), 256);
@@ -1596,7 +1767,7 @@ extern "C" int egx_lbs_timing_read(unsigned long long* out16, int reset) {
 #endif
 
 extern "C" int egx_lbs_set_blend_mode(int mode) {
-  EGX_REQUIRE(mode >= 0 && mode <= 2, "blend mode must be 0 (fp32 MFMA), 1 (bf16x3 split) or 2 (bf16x2 split)");
+  EGX_REQUIRE(mode >= 0 && mode <= 3, "blend mode must be 0 (fp32 MFMA), 1 (bf16x3 split), 2 (bf16x2 split) or 3 (bf16x2 shape / template + fp16 pose correctives)");
   g_blend_mode.store(mode);
   return EGX_OK;
 }
@@ -1619,7 +1790,7 @@ extern "C" int egx_lbs_joints(const egx_body_model* m, const float* xb, const fl
   char* ws = static_cast<char*>(workspace);
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream_), m->pc, xb,
                      betas, B, fpa, static_cast<float*>(nullptr), static_cast<unsigned short*>(nullptr),
-                     reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ, 0.f, static_cast<int*>(nullptr),
+                     reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ, 0.f, static_cast<unsigned short*>(nullptr), static_cast<int*>(nullptr),
                      static_cast<const int*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
@@ -1642,6 +1813,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   char* ws = static_cast<char*>(workspace);
   float* feat = reinterpret_cast<float*>(ws + wl.feat);
+  unsigned short* feat4 = reinterpret_cast<unsigned short*>(ws + wl.feat4);
   f32x4* A4 = reinterpret_cast<f32x4*>(ws + wl.A4);
   const bool need_picks = out_joints || out_markers;
   float* picked = need_picks ? reinterpret_cast<float*>(ws + wl.picked) : nullptr;
@@ -1677,7 +1849,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   }
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, stream, m->pc, xb, betas, B, fpa,
                      split3 ? nullptr : feat, split3 ? reinterpret_cast<unsigned short*>(feat) : nullptr, A4, out_joints,
-                     EGX_NUM_JOINTS_OUT, (split3 && mode == 2) ? 1.f : 0.f, sdf ? out_pene_count : nullptr,
+                     EGX_NUM_JOINTS_OUT, (split3 && mode >= 2) ? 1.f : 0.f, (split3 && mode == 3) ? feat4 : nullptr, sdf ? out_pene_count : nullptr,
                      static_cast<const int*>(order), fvec, jpos, (int)wl.Bp);
   if (cull) {
     const int n_np = m->n_sdf_tiles - m->n_pick_tiles;
@@ -1691,6 +1863,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     LbsParams p;
     p.dirs = m->dirs; p.tj_off = m->tj_off; p.tj_idx = m->tj_idx; p.tj_w = m->tj_w; p.pick_slot = m->pick_slot;
     p.dirs3 = m->dirs3; p.feat3 = reinterpret_cast<const bf16x8*>(feat);
+    p.dirs4 = m->dirs4; p.feat4 = reinterpret_cast<const bf16x8*>(feat4);
     p.vorig = m->vorig;
     p.vflags = m->vflags; p.feat = reinterpret_cast<const f32x4*>(feat); p.A4 = A4; p.xb = xb;
     p.B = B; p.V = m->V; p.NVT = m->NVT; p.NW = m->NW; p.NP = m->NP; p.fpa = fpa;
@@ -1709,6 +1882,8 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     // (with SDF counts: nor the tiles made of feet vertices only, which the count excludes)
     p.tiles = out_verts ? nullptr : (sdf ? m->sdf_tiles : m->pick_tiles);
     p.n_tiles = out_verts ? m->NVT : (sdf ? m->n_sdf_tiles : m->n_pick_tiles);
+    // mode 3: the tile lists start with the tiles that hold picked vertices (checked at load: sdf_lead_picks)
+    p.n_precise = sdf ? (m->sdf_lead_picks ? m->n_pick_tiles : m->n_sdf_tiles) : m->n_pick_tiles;
     p.sdf = sd;   // out_pene_count was cleared by the pose kernel above
     // one persistent workgroup per CU; per-device launch facts (CU count, raised dynamic-LDS caps) are set up once per device
     constexpr size_t lds_meta = (size_t)8 * LBS_META_BYTES, lds_verts = (size_t)8 * (LBS_META_BYTES + LBS_VERT_BYTES),
@@ -1732,6 +1907,8 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<3, false>), lds3a));
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<2, true>), lds3a));
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<2, false>), lds3a));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<4, true>), lds3a));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<4, false>), lds3a));
         di.num_cu = prop.multiProcessorCount;
       }
     }
@@ -1754,7 +1931,10 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
       constexpr size_t lds3 = (size_t)LBS3_SHARED_BYTES + 4 * LBS3_WAVE_BYTES;
       int grid3 = std::max(1, std::min(2 * num_cu, n_items));
       if (grid3 >= 8) grid3 &= ~7;   // a multiple of 8: the kernel's XCD partition (body groups, or vertex tiles when groups are few)
-      if (mode == 2) {
+      if (mode == 3) {
+        if (sdf) hipLaunchKernelGGL((egx_lbs_fused3_kernel<4, true>), dim3(grid3), dim3(256), lds3, stream, p);
+        else hipLaunchKernelGGL((egx_lbs_fused3_kernel<4, false>), dim3(grid3), dim3(256), lds3, stream, p);
+      } else if (mode == 2) {
         if (sdf) hipLaunchKernelGGL((egx_lbs_fused3_kernel<2, true>), dim3(grid3), dim3(256), lds3, stream, p);
         else hipLaunchKernelGGL((egx_lbs_fused3_kernel<2, false>), dim3(grid3), dim3(256), lds3, stream, p);
       } else {

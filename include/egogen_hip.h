@@ -112,15 +112,22 @@ int egx_lbs_cull_stats(const egx_body_model* m, const void* workspace, int num_b
 
 /* Bytes of scratch egx_lbs_forward needs for `num_bodies` bodies. */
 /* Blend-GEMM arithmetic of egx_lbs_forward calls that do not write full vertices (process-wide switch; the environment
- * variable EGX_LBS_BLEND=f32|bf16x3|bf16x2 selects it at first use):
+ * variable EGX_LBS_BLEND=f32|bf16x3|bf16x2|f16mix selects it at first use):
  *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32); always used when vertices are written
  *   1  3-term bf16 split of both operands, six partial products per fp32 product on v_mfma_f32_32x32x16_bf16 with fp32
  *      accumulation: 2^-24-level accuracy (indistinguishable from mode 0) at a third of the matrix-pipe time
  *   2  2-term bf16 split, three partial products (hi.hi + hi.mid + mid.hi: 16 significant bits per operand) - and a third
- *      term for the template column, carried by a padding column of K - at a sixth of the matrix-pipe time.  Default: the
+ *      term for the template column, carried by a padding column of K - at a sixth of the matrix-pipe time.  The
  *      offsets it rounds are centimetres, so vertices move by <= 1.1e-6 m against the float64 oracle (mode 0: 3.7e-7) and
  *      the fused penetration counts do not change (tests/test_lbs_gpu.py::test_lbs_blend_mode_accuracy_report); all three
  *      modes are held to the same parity tolerances (north_star: 1e-4 relative).
+ *   3  "f16mix" (DEFAULT): the vertex tiles that hold PICKED vertices (markers, vertex joints, landmark corners - everything the
+ *      caller reads as a position) run exactly as in mode 2; the other tiles, which only feed the penetration COUNT, keep the
+ *      shape / template k-steps as in mode 2 and run the 28 k-steps that hold only pose-corrective columns (centimetre-scale
+ *      offsets) as ONE v_mfma_f32_32x32x16_f16 product on operands rounded to fp16 (2^-12 per operand): 204 instead of 540
+ *      MFMAs per wave and work item, a third of the operand bytes.  Those vertices move by ~4e-6 m rms / ~2.2e-5 m worst case
+ *      against float64 on the synthetic body (2e-5 of a metre-scale coordinate, inside north_star's 1e-4), i.e. a count may
+ *      differ by the vertices within that distance of the level set (parity tests: 6e-5 m band); positions are unaffected.
  * (No reference counterpart: smplx evaluates the blend shapes as fp32 einsum/matmul, lbs.py [upstream smplx 0.1.28].) */
 int egx_lbs_set_blend_mode(int mode);
 int egx_lbs_get_blend_mode(void);

@@ -333,7 +333,7 @@ class OracleCrowdEnv:
             sv[:, :, self.feet_vids] = 0.0
             inside = sv.lt(0.0)
             cnt = inside.sum(dim=-1)                                      # [A,20]
-            near = sv.abs() < 2e-5                                        # test diagnostics: vertices within fp32 round-off of
+            near = sv.abs() < getattr(self, "level_set_band", 2e-5)       # test diagnostics: vertices within fp32 round-off of
             near[:, :, self.feet_vids] = False                            # the zero level set (their sign is not reproducible)
             self.last["pene_near_zero"] = near.sum(dim=-1)
             num_inside = cnt.sum(dim=1).to(dt) / T_ALL / 10

@@ -249,6 +249,9 @@ def record_step(ret, loc, env, pre, box=False):
         near = loc["sdf_values"][0].abs() < 2e-5        # vertices within fp32 round-off of the zero level set: their sign is not
         near[:, env.feet_vids] = False                  # reproducible by another fp32 evaluation order (tests bound |d count| by it)
         out[pre + "pene_near_zero"] = t2n(near.sum(-1)).astype(np.int64)
+        near6 = loc["sdf_values"][0].abs() < 6e-5       # the band of the library's mixed blend mode (fp16 pose-corrective product on the
+        near6[:, env.feet_vids] = False                 # tiles that only feed this count)
+        out[pre + "pene_near_6e5"] = t2n(near6.sum(-1)).astype(np.int64)
     out[pre + "Y_gen"] = t2n(loc["Y_gen"][:, 0])                       # [18,201]
     out[pre + "pred_params"] = t2n(loc["pred_params"][0])             # [20,93] (after _blend_params)
     out[pre + "joints"] = t2n(loc["pred_output"].joints.reshape(NB, 20, -1, 3)[0])

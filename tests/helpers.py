@@ -108,4 +108,14 @@ def build_world(V=1536, A=6, scene_kind="sdf", sdf_res=48, n_pairs=64, n_scenes=
         vp.cuda().eval()
         w["env"] = VecCrowdEnv(A, h, combo, vp, finetuning=finetuning, seed=seed, **gkw)
         w["handle"] = h
+        w["oracle"].level_set_band = level_set_band()   # band of `pene_near_zero` (the HIP path's counts are compared inside it)
     return w
+
+
+def level_set_band():
+    """Distance from the SDF's zero level set (metres) inside which a penetration count of the HIP path may differ from a CPU
+    evaluation: 2e-5 (fp32 round-off of the vertex chain) in the blend modes that are fp32-equivalent on the offsets, 6e-5 in
+    mode 3 ("f16mix", the library default: the tiles that only feed the count run their pose-corrective columns as one fp16
+    product, ~4 um rms / ~22 um worst case; tests/test_lbs_gpu.py::test_lbs_blend_mode_accuracy_report)."""
+    from egogen_amd import _lib
+    return 6e-5 if int(_lib.load().egx_lbs_get_blend_mode()) == 3 else 2e-5

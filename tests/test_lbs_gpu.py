@@ -9,14 +9,24 @@ from tests.helpers import load_golden, max_abs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["f32", "bf16x3", "bf16x2"])
+def _band(mode):
+    """Distance from the zero level set (metres) inside which a penetration count may differ from the oracle's: 2e-5 = fp32
+    round-off of the vertex chain for the modes that are fp32-equivalent on the blend offsets; 6e-5 for "f16mix", whose
+    pose-corrective columns are ONE fp16 product on the tiles that only feed the count (2^-12 per operand: ~4 um rms, ~22 um
+    worst case on this body's centimetre-scale offsets).  Positions (markers, joints, landmarks: the tiles with picked vertices
+    keep the two-plane split in that mode) are held to 2e-5 m in EVERY mode."""
+    return 6e-5 if mode == "f16mix" else 2e-5
+
+
+@pytest.fixture(params=["f32", "bf16x3", "bf16x2", "f16mix"])
 def blend_mode(request):
-    """Both arithmetic modes of the blend GEMM (include/egogen_hip.h: egx_lbs_set_blend_mode) under the same tolerances."""
+    """Every arithmetic mode of the blend GEMM (include/egogen_hip.h: egx_lbs_set_blend_mode)."""
     from egogen_amd import _lib
     lib = _lib.load()
-    _lib.check(lib.egx_lbs_set_blend_mode({"f32": 0, "bf16x3": 1, "bf16x2": 2}[request.param]), "egx_lbs_set_blend_mode")
+    old = int(lib.egx_lbs_get_blend_mode())
+    _lib.check(lib.egx_lbs_set_blend_mode({"f32": 0, "bf16x3": 1, "bf16x2": 2, "f16mix": 3}[request.param]), "egx_lbs_set_blend_mode")
     yield request.param
-    _lib.check(lib.egx_lbs_set_blend_mode(2), "egx_lbs_set_blend_mode")
+    _lib.check(lib.egx_lbs_set_blend_mode(old), "egx_lbs_set_blend_mode")
 
 
 def _setup(V, seed=0):
@@ -99,7 +109,7 @@ def test_lbs_ragged_batches(A, T, blend_mode):
     sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
     s = calc_sdf(v, sd)
     s[:, torch.as_tensor(feet).long()] = 1.0  # feet are excluded: neither counted nor "near zero"
-    ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
+    ref, near = s.lt(0).sum(-1), (s.abs() < _band(blend_mode)).sum(-1)
     got = out["pene_count"].cpu().long()
     assert ref.max() > 10
     assert ((got - ref).abs() <= near).all(), (got - ref).abs().max()
@@ -141,7 +151,7 @@ def test_lbs_sdf_fused_counts(blend_mode):
     got = out["pene_count"].cpu().long()
     assert ref.max() > 50, "test should exercise penetration"
     # integer counts: exact except for vertices within fp32 round-off of the zero level set
-    near = (s.abs() < 2e-5).sum(-1)
+    near = (s.abs() < _band(blend_mode)).sum(-1)
     assert ((got - ref).abs() <= near).all(), (got - ref).abs().max()
     # and without the vertex write (hot path, selected blend mode)
     out2 = h.forward(xb.cuda(), betas.cuda(), T, sdf=SdfScene(scene), R0=R0.cuda(), T0=T0.cuda())
@@ -172,7 +182,7 @@ def test_lbs_sdf_counts_outside_grid(blend_mode):
     sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
     s = calc_sdf(vw.reshape(A * T, V, 3), sd)
     s[:, torch.as_tensor(feet).long()] = 1.0  # feet are excluded: neither counted nor "near zero"
-    ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
+    ref, near = s.lt(0).sum(-1), (s.abs() < _band(blend_mode)).sum(-1)
     got = out["pene_count"].cpu().long()
     assert ref.reshape(A, T)[4:].min() == V - len(feet), "bodies outside the room count as penetrating everywhere"
     assert near.reshape(A, T)[4:].max() == 0
@@ -298,7 +308,7 @@ def test_lbs_long_joint_lists(nnz, blend_mode):
     sd = {k: torch.as_tensor(np.asarray(scene[k])) for k in ("sdf", "center", "scale")}
     s = calc_sdf(v, sd)
     s[:, torch.as_tensor(feet).long()] = 1.0
-    ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
+    ref, near = s.lt(0).sum(-1), (s.abs() < _band(blend_mode)).sum(-1)
     for o_ in (out, out2):
         assert ((o_["pene_count"].cpu().long() - ref).abs() <= near).all()
 
@@ -329,7 +339,7 @@ def test_lbs_full_size_many_body_groups_vs_oracle(blend_mode):
         worst_m = max(worst_m, max_abs(out["markers"][s0:s0 + 200].cpu(), v[:, mkl]))
         s = calc_sdf(v, sd)
         s[:, ftl] = 1.0
-        ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
+        ref, near = s.lt(0).sum(-1), (s.abs() < _band(blend_mode)).sum(-1)
         any_pene = max(any_pene, int(ref.max()))
         assert ((got[s0:s0 + 200] - ref).abs() <= near).all(), (s0, (got[s0:s0 + 200] - ref).abs().max())
     assert worst_j < 2e-5 and worst_m < 2e-5, (worst_j, worst_m)
@@ -357,19 +367,21 @@ def test_lbs_blend_mode_accuracy_report():
     ref, near = s.lt(0).sum(-1), (s.abs() < 2e-5).sum(-1)
     mkl = torch.as_tensor(mk).long()
     rows = []
+    old_mode = int(lib.egx_lbs_get_blend_mode())
     try:
-        for name, mode in (("f32", 0), ("bf16x3", 1), ("bf16x2", 2)):
+        for name, mode in (("f32", 0), ("bf16x3", 1), ("bf16x2", 2), ("f16mix", 3)):
             _lib.check(lib.egx_lbs_set_blend_mode(mode), "mode")
             out = h.forward(xb.cuda(), betas.cuda(), T, sdf=SdfScene(scene))
             torch.cuda.synchronize()
             e_m = max_abs(out["markers"].cpu().double(), v[:, mkl])
             e_j = max_abs(out["joints"].cpu().double(), j)
             dc = (out["pene_count"].cpu().long() - ref).abs()
-            rows.append((name, e_m, e_j, int(dc.max()), int(dc.sum()), int(near.sum())))
-            assert e_m < 2e-5 and e_j < 2e-5 and (dc <= near).all()
+            band = (s.abs() < _band(name)).sum(-1)
+            rows.append((name, e_m, e_j, int(dc.max()), int(dc.sum()), int(band.sum())))
+            assert e_m < 2e-5 and e_j < 2e-5 and (dc <= band).all()
     finally:
-        _lib.check(lib.egx_lbs_set_blend_mode(2), "mode")
-    print("\nmode     max|d marker|  max|d joint|  max|d count|  sum|d count|  vertices within 2e-5 of the level set")
+        _lib.check(lib.egx_lbs_set_blend_mode(old_mode), "mode")
+    print("\nmode     max|d marker|  max|d joint|  max|d count|  sum|d count|  vertices within the mode's band of the level set")
     for r in rows:
         print("%-7s  %.2e       %.2e      %5d         %5d         %d" % r)
     # the two-plane mode stays within a factor of a few of fp32 round-off thanks to the template's third term
@@ -413,7 +425,7 @@ def test_lbs_tile_lists_skip_only_what_contributes_nothing(blend_mode):
     s = calc_sdf(full["vertices"].reshape(A * T, V, 3), sd)
     s[:, torch.as_tensor(feet).long().cuda()] = 1.0
     ref = s.lt(0).sum(-1).cpu()
-    near = (s.abs() < 2e-5).sum(-1).cpu()
+    near = (s.abs() < _band(blend_mode)).sum(-1).cpu()
     assert ((with_sdf["pene_count"].cpu().long() - ref).abs() <= near).all()
     assert int(with_sdf["pene_count"].max()) > 20
 
