@@ -397,8 +397,14 @@ struct LbsWave {
   float* lds;          // vertex transpose buffer (vertex-writing variants)
   f32x4* s_queue;      // undecided SDF points (voxel x, y, z, counter slot)
   int qn;              // queued points (wave-uniform)
+#ifdef EGX_LBS_TIMING
+  unsigned long long et[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per-wave cycle totals, written out once when the kernel ends
+#endif
 };
 constexpr int LBS_NB = 2;  // 32-body MFMA column tiles per wave
+#ifndef EGX_LBS_PF
+#define EGX_LBS_PF 1       // joint transforms fetched this many joints ahead in the skinning loop
+#endif
 
 template <bool WRITE_VERTS, bool DO_SDF>
 __device__ __forceinline__ LbsWave lbs_wave_init(char* my, int lane) {
@@ -492,7 +498,7 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
   const unsigned pick_mask = p.picked ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_masks[0]) : 0u;
   const unsigned sdf_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)s_masks[1]);
 #ifdef EGX_LBS_TIMING
-  unsigned long long et[4] = {0, 0, 0, 0};
+  unsigned long long (&et)[8] = w.et;
 #endif
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
@@ -508,8 +514,19 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
       const int j = s_jl[0];
       a0 = Aq[(j * 3 + 0) * 32]; a1 = Aq[(j * 3 + 1) * 32]; a2 = Aq[(j * 3 + 2) * 32];
     }
+#if EGX_LBS_PF >= 2
+    f32x4 b0, b1, b2;   // the joint after next: two transform fetches in flight (development variant)
+    {
+      const int j = s_jl[min(1, JT - 1)];
+      b0 = Aq[(j * 3 + 0) * 32]; b1 = Aq[(j * 3 + 1) * 32]; b2 = Aq[(j * 3 + 2) * 32];
+    }
+#endif
     for (int jj = 0; jj < JT; ++jj) {
+#if EGX_LBS_PF >= 2
+      const int jn = s_jl[min(jj + 2, JT - 1)];
+#else
       const int jn = s_jl[min(jj + 1, JT - 1)];
+#endif
       const f32x4 n0 = Aq[(jn * 3 + 0) * 32], n1 = Aq[(jn * 3 + 1) * 32], n2 = Aq[(jn * 3 + 2) * 32];
       f32x4 wq[4];
 #pragma unroll
@@ -532,7 +549,12 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
           o[r][2] = lbs_fma(wv, pz, o[r][2]);
         }
       }
+#if EGX_LBS_PF >= 2
+      a0 = b0; a1 = b1; a2 = b2;
+      b0 = n0; b1 = n1; b2 = n2;
+#else
       a0 = n0; a1 = n1; a2 = n2;
+#endif
     }
 #ifdef EGX_LBS_TIMING
     __builtin_amdgcn_sched_barrier(0);
@@ -566,33 +588,36 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
       const float hx = (float)(p.sdf.d0 - 1), hy = (float)(p.sdf.d1 - 1), hz = (float)(p.sdf.d2 - 1);
       const unsigned mine = bvalid[q] ? (sdf_mask >> (4 * half)) : 0u;  // bit (r&3)+8(r>>2) = this lane's row r
       int cnt = 0;
+      // all sixteen bracket lookups of the lane's rows are issued before the first one is used: one L2 round trip per body
+      // tile instead of one per batch of RB rows (round 4; the epilogue is a latency chain - two waves per SIMD - and these
+      // gathers were four of its eight round trips per item).  The world coordinates are not kept: the rare undecided point
+      // recomputes its own (12 FMAs) inside the queue branch.
+      auto world = [&](int r, int a) { return fmaf(Mw[a * 3 + 0], o[r][0], fmaf(Mw[a * 3 + 1], o[r][1], fmaf(Mw[a * 3 + 2], o[r][2], tw[a]))); };
+      constexpr int LB = WRITE_VERTS ? RB : 16;   // rows per lookup burst (the vertex-writing variant has no registers to spare)
 #pragma unroll
-      for (int r0 = 0; r0 < 16; r0 += RB) {
-        float wp[RB][3];
-        float2 mm[RB];
+      for (int rb0 = 0; rb0 < 16; rb0 += LB) {
+      float2 mm[LB];
+#pragma unroll
+      for (int r = rb0; r < rb0 + LB; ++r) mm[r - rb0] = egx_sdf_coarse_at_raw(p.sdf, world(r, 0), world(r, 1), world(r, 2));
+#pragma unroll
+      for (int r0 = rb0; r0 < rb0 + LB; r0 += RB) {
         if (qn + RB * 64 > QCAP) { sdf_flush(qn); qn = 0; }  // room for one batch: RB rows x 64 lanes
 #pragma unroll
         for (int r = r0; r < r0 + RB; ++r) {
-          wp[r - r0][0] = fmaf(Mw[0], o[r][0], fmaf(Mw[1], o[r][1], fmaf(Mw[2], o[r][2], tw[0])));
-          wp[r - r0][1] = fmaf(Mw[3], o[r][0], fmaf(Mw[4], o[r][1], fmaf(Mw[5], o[r][2], tw[1])));
-          wp[r - r0][2] = fmaf(Mw[6], o[r][0], fmaf(Mw[7], o[r][1], fmaf(Mw[8], o[r][2], tw[2])));
-          mm[r - r0] = egx_sdf_coarse_at_raw(p.sdf, wp[r - r0][0], wp[r - r0][1], wp[r - r0][2]);
-        }
-#pragma unroll
-        for (int r = r0; r < r0 + RB; ++r) {
           const bool on = (mine >> ((r & 3) + 8 * (r >> 2))) & 1u;
-          const bool inside = mm[r - r0].x > 0.f;
+          const bool inside = mm[r - rb0].x > 0.f;
           cnt += (on && inside) ? 1 : 0;
-          const bool und = on && !inside && !(mm[r - r0].y < 0.f);
+          const bool und = on && !inside && !(mm[r - rb0].y < 0.f);
           const unsigned long long bm = __ballot(und);
           if (bm != 0) {
             const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
             if (und)
-              s_queue[pos] = f32x4{__builtin_amdgcn_fmed3f(wp[r - r0][0], 0.f, hx), __builtin_amdgcn_fmed3f(wp[r - r0][1], 0.f, hy),
-                                   __builtin_amdgcn_fmed3f(wp[r - r0][2], 0.f, hz), __int_as_float(q * 32 + n)};
+              s_queue[pos] = f32x4{__builtin_amdgcn_fmed3f(world(r, 0), 0.f, hx), __builtin_amdgcn_fmed3f(world(r, 1), 0.f, hy),
+                                   __builtin_amdgcn_fmed3f(world(r, 2), 0.f, hz), __int_as_float(q * 32 + n)};
             qn += __popcll(bm);
           }
         }
+      }
       }
       if (cnt != 0) {
         int nn = n;                       // address formed here (see run_item: no loop-invariant per-lane address to keep alive)
@@ -666,7 +691,7 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
 #ifdef EGX_LBS_TIMING
   __builtin_amdgcn_sched_barrier(0);
   et[2] += LBS_NOW() - f0;
-  if (lane == 0) { atomicAdd(&g_lbs_t[9], et[0]); atomicAdd(&g_lbs_t[10], et[1]); atomicAdd(&g_lbs_t[11], et[2]); atomicAdd(&g_lbs_t[12], 1ull); }
+  et[3] += 1;
 #endif
   w.qn = qn;
 }
@@ -890,64 +915,24 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int M4_RING_PIECES = 3 * M4_FKS;      // 12 KiB per ring slot (a precise stage uses 6)
 static_assert(28 % M4_FKS == 0, "fp16 stages cover k-steps 1..28 exactly");
 
-template <bool PRECISE>
-__device__ __forceinline__ void lbs_mixed_stage(const bf16x8* __restrict__ dpv, const bf16x8* const (&fq)[LBS_NB], int dp0, int fp0,
-                                                f32x16 (&acc)[3][LBS_NB], int wave, int lane, bf16x8* buf) {
-  constexpr int NB = LBS_NB;
-  constexpr int NP = PRECISE ? 6 : 3 * M4_FKS;    // base pieces of the stage
-  constexpr int NF = PRECISE ? 2 : M4_FKS;        // feature pieces per body tile
-  constexpr int NGA = (NP + 3) / 4;
-  bf16x8 ga[NGA], b[NF][NB];
-#pragma unroll
-  for (int i = 0; i < NGA; ++i) {
-    const int piece = wave + 4 * i;
-    if (piece < NP) ga[i] = dpv[(size_t)(dp0 + piece) * 64];
-  }
-#pragma unroll
-  for (int f = 0; f < NF; ++f)
-#pragma unroll
-    for (int q = 0; q < NB; ++q) b[f][q] = fq[q][(size_t)(fp0 + f) * 64];
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < NGA; ++i) {
-    const int piece = wave + 4 * i;
-    if (piece < NP) buf[piece * 64 + lane] = ga[i];
-  }
-  __syncthreads();  // stage visible; also: everyone is done reading the other ring slot's previous contents
-  if (PRECISE) {
-    bf16x8 a[2][3];   // [plane][coord]
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) a[pl][c] = buf[(pl * 3 + c) * 64 + lane];
-#pragma unroll
-    for (int pr = 0; pr < 3; ++pr) {   // hi.mid, mid.hi, hi.hi: small partial products first, product-major
-      const int pa = (pr == 1) ? 1 : 0, pb = (pr == 0) ? 1 : 0;
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][c], b[pb][q], acc[c][q], 0, 0, 0);
-    }
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < M4_FKS; ++ks) {
-      bf16x8 a[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) a[c] = buf[(ks * 3 + c) * 64 + lane];
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[c]), __builtin_bit_cast(f16x8, b[ks][q]),
-                                                             acc[c][q], 0, 0, 0);
-    }
-  }
-}
+// Operand registers of one stage: this wave's share of the stage's base pieces (on their way to the LDS ring) and its own
+// feature pieces.
+struct M4Regs {
+  bf16x8 ga[(3 * M4_FKS + 3) / 4];
+  bf16x8 b[M4_FKS][LBS_NB];
+};
+constexpr int M4_STAGES = 2 + 28 / M4_FKS;     // precise k-step 0, the fp16 stages, precise k-step 29
+__device__ __forceinline__ constexpr bool m4_precise(int st) { return st == 0 || st == M4_STAGES - 1; }
+__device__ __forceinline__ constexpr int m4_base0(int st) { return st == 0 ? 0 : (st == M4_STAGES - 1 ? 90 : 6 + (st - 1) * 3 * M4_FKS); }
+__device__ __forceinline__ constexpr int m4_feat0(int st) { return st == 0 ? 0 : (st == M4_STAGES - 1 ? 30 : 2 + (st - 1) * M4_FKS); }
 
-__device__ __forceinline__ void lbs_blend_mixed(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave, bf16x8* sA) {
+// The nine stages of an item as a software pipeline of depth one: the burst of stage st + 1 is issued as soon as stage st's
+// operands have arrived - before stage st's barrier and MFMAs - so a stage costs max(operand latency, LDS + barrier + MFMAs)
+// instead of their sum.  (The in-flight-load hazard of lbs_blend_f32 halves the MFMA rate of this wave meanwhile; here the
+// MFMAs are a quarter of the GEMM half - 204 per item - and the operand latency, bases streaming from the Infinity Cache, is
+// what the half waits for: 0.414 ms with the epilogue skipped against 0.10 ms of matrix time, profiles/r05_lbs_mixed.md.)
+__device__ __forceinline__ void lbs_blend_mixed(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave, bf16x8* sA,
+                                                unsigned long long* tacc) {
   constexpr int NB = LBS_NB;
   const int num_bt = (p.B + 31) >> 5;
   asm volatile("" : "+v"(lane));   // per-lane operand addresses are formed per item
@@ -955,10 +940,78 @@ __device__ __forceinline__ void lbs_blend_mixed(const LbsParams& p, f32x16 (&acc
   const bf16x8* fq[NB];
 #pragma unroll
   for (int q = 0; q < NB; ++q) fq[q] = p.feat4 + (size_t)min(bt0 + q, num_bt - 1) * M4_FEAT_PIECES * 64 + lane;
-  lbs_mixed_stage<true>(dpv, fq, 0, 0, acc, wave, lane, sA);
-  for (int st = 0; st < 28 / M4_FKS; ++st)
-    lbs_mixed_stage<false>(dpv, fq, 6 + st * 3 * M4_FKS, 2 + st * M4_FKS, acc, wave, lane, sA + ((st + 1) & 1) * M4_RING_PIECES * 64);
-  lbs_mixed_stage<true>(dpv, fq, 90, 30, acc, wave, lane, sA + ((28 / M4_FKS + 1) & 1) * M4_RING_PIECES * 64);
+  M4Regs R[2];
+  auto issue = [&](M4Regs& r, int st) {
+    const int np = m4_precise(st) ? 6 : 3 * M4_FKS, nf = m4_precise(st) ? 2 : M4_FKS;
+#pragma unroll
+    for (int i = 0; i < (3 * M4_FKS + 3) / 4; ++i) {
+      const int piece = wave + 4 * i;
+      if (piece < np) r.ga[i] = dpv[(size_t)(m4_base0(st) + piece) * 64];
+    }
+#pragma unroll
+    for (int f = 0; f < M4_FKS; ++f)
+      if (f < nf) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) r.b[f][q] = fq[q][(size_t)(m4_feat0(st) + f) * 64];
+      }
+  };
+  issue(R[0], 0);
+#pragma unroll
+  for (int st = 0; st < M4_STAGES; ++st) {
+    M4Regs& r = R[st & 1];
+    bf16x8* buf = sA + (st & 1) * M4_RING_PIECES * 64;
+    [[maybe_unused]] const unsigned long long t0 = LBS_NOW();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stage st's operands (issued a stage ago)
+    __builtin_amdgcn_sched_barrier(0);
+    [[maybe_unused]] const unsigned long long t1 = LBS_NOW();
+    const int np = m4_precise(st) ? 6 : 3 * M4_FKS;
+#pragma unroll
+    for (int i = 0; i < (3 * M4_FKS + 3) / 4; ++i) {
+      const int piece = wave + 4 * i;
+      if (piece < np) buf[piece * 64 + lane] = r.ga[i];
+    }
+    if (st + 1 < M4_STAGES) issue(R[(st + 1) & 1], st + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // stage visible; also: everyone is done reading the other ring slot's previous contents
+    [[maybe_unused]] const unsigned long long t2 = LBS_NOW();
+    if (m4_precise(st)) {
+      bf16x8 a[2][3];   // [plane][coord]
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[pl][c] = buf[(pl * 3 + c) * 64 + lane];
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr) {   // hi.mid, mid.hi, hi.hi: small partial products first, product-major
+        const int pa = (pr == 1) ? 1 : 0, pb = (pr == 0) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+            acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][c], r.b[pb][q], acc[c][q], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < M4_FKS; ++ks) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[c] = buf[(ks * 3 + c) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+            acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[c]), __builtin_bit_cast(f16x8, r.b[ks][q]),
+                                                               acc[c][q], 0, 0, 0);
+      }
+    }
+#ifdef EGX_LBS_TIMING
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t3 = LBS_NOW();
+      LBS_T(0, t1 - t0); LBS_T(1, t2 - t1); LBS_T(2, t3 - t2); LBS_T(3, 1);
+    }
+#endif
+  }
 }
 
 template <int NPL, bool DO_SDF>
@@ -1013,6 +1066,7 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
   unsigned long long tacc[4] = {0, 0, 0, 0};
   (void)tacc;
   auto run_item = [&](int vti, int bg) {
+    [[maybe_unused]] const unsigned long long item_t0 = LBS_NOW();
     const int vt = p.tiles ? p.tiles[vti] : vti;
     const int bt0 = bg * 8 + wave * NB;
     __syncthreads();  // previous item: every wave is done with the metadata and with the stage ring
@@ -1045,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
         // two-plane split: what the environment reads as positions - and differentiates into directions (the eye landmarks are
         // centimetres apart and aim 7 m rays) - stays at the 1e-6 m level; the fp16 product only feeds the penetration COUNT
         if (vti < p.n_precise) lbs_blend_split<2>(p, acc, vt, bt0, lane, wave, sA, tacc);
-        else lbs_blend_mixed(p, acc, vt, bt0, lane, wave, sA);
+        else lbs_blend_mixed(p, acc, vt, bt0, lane, wave, sA, tacc);
       } else lbs_blend_split<NPL>(p, acc, vt, bt0, lane, wave, sA, tacc);
     } else __syncthreads();  // the blend's barriers also publish the metadata
     if (p.dbg & 1) {
@@ -1060,6 +1114,9 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
       return;
     }
     lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP>(p, w, acc, vt, bt0, JT);
+#ifdef EGX_LBS_TIMING
+    w.et[4] += LBS_NOW() - item_t0; w.et[5] += 1;
+#endif
   };
   // one loop for both item sources (the body is inlined once): a culled launch walks this XCD's list of active items
   // (egx_lbs_compact_kernel: an item whose 256 bodies are provably in free space for the whole vertex tile is not on it), dealt
@@ -1083,8 +1140,11 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
     run_item(vti, bg);
   }
 #ifdef EGX_LBS_TIMING
-  if (lane == 0)
+  if (lane == 0) {
     for (int i = 0; i < 4; ++i) atomicAdd(&g_lbs_t[i], tacc[i]);
+    atomicAdd(&g_lbs_t[9], w.et[0]); atomicAdd(&g_lbs_t[10], w.et[1]); atomicAdd(&g_lbs_t[11], w.et[2]); atomicAdd(&g_lbs_t[12], w.et[3]);
+    atomicAdd(&g_lbs_t[13], w.et[4]); atomicAdd(&g_lbs_t[14], w.et[5]);
+  }
 #endif
 }
 
@@ -1884,6 +1944,9 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     p.n_tiles = out_verts ? m->NVT : (sdf ? m->n_sdf_tiles : m->n_pick_tiles);
     // mode 3: the tile lists start with the tiles that hold picked vertices (checked at load: sdf_lead_picks)
     p.n_precise = sdf ? (m->sdf_lead_picks ? m->n_pick_tiles : m->n_sdf_tiles) : m->n_pick_tiles;
+#ifdef EGX_LBS_DEVELOPMENT
+    if (const char* e = getenv("EGX_LBS_PRECISE")) p.n_precise = atoi(e);
+#endif
     p.sdf = sd;   // out_pene_count was cleared by the pose kernel above
     // one persistent workgroup per CU; per-device launch facts (CU count, raised dynamic-LDS caps) are set up once per device
     constexpr size_t lds_meta = (size_t)8 * LBS_META_BYTES, lds_verts = (size_t)8 * (LBS_META_BYTES + LBS_VERT_BYTES),
