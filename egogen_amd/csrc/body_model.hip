@@ -511,30 +511,30 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
     for (int r = 0; r < 16; ++r) { o[r][0] = tr[q][0]; o[r][1] = tr[q][1]; o[r][2] = tr[q][2]; }
     f32x4 a0, a1, a2;
     {
-      const int j = s_jl[0];
+      const int j = s_jl[0] & 0xff;   // entries: joint | row-group mask << 8
       a0 = Aq[(j * 3 + 0) * 32]; a1 = Aq[(j * 3 + 1) * 32]; a2 = Aq[(j * 3 + 2) * 32];
     }
 #if EGX_LBS_PF >= 2
     f32x4 b0, b1, b2;   // the joint after next: two transform fetches in flight (development variant)
     {
-      const int j = s_jl[min(1, JT - 1)];
+      const int j = s_jl[min(1, JT - 1)] & 0xff;
       b0 = Aq[(j * 3 + 0) * 32]; b1 = Aq[(j * 3 + 1) * 32]; b2 = Aq[(j * 3 + 2) * 32];
     }
 #endif
     for (int jj = 0; jj < JT; ++jj) {
 #if EGX_LBS_PF >= 2
-      const int jn = s_jl[min(jj + 2, JT - 1)];
+      const int jn = s_jl[min(jj + 2, JT - 1)] & 0xff;
 #else
-      const int jn = s_jl[min(jj + 1, JT - 1)];
+      const int jn = s_jl[min(jj + 1, JT - 1)] & 0xff;
 #endif
       const f32x4 n0 = Aq[(jn * 3 + 0) * 32], n1 = Aq[(jn * 3 + 1) * 32], n2 = Aq[(jn * 3 + 2) * 32];
-      f32x4 wq[4];
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) wq[rg] = *reinterpret_cast<const f32x4*>(&s_W[jj * 32 + 8 * rg + 4 * half]);
+      // which row groups this joint touches: a property of the tile, precomputed at load (round 4 derived it from the weights
+      // with four compares, three ORs and a ballot per group, joint and body tile)
+      const int gmask = __builtin_amdgcn_readfirstlane(s_jl[jj]) >> 8;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const f32x4 w4 = wq[rg];
-        if (__builtin_amdgcn_ballot_w64((w4[0] != 0.f) | (w4[1] != 0.f) | (w4[2] != 0.f) | (w4[3] != 0.f)) == 0) continue;
+        if (!((gmask >> rg) & 1)) continue;   // scalar branch
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_W[jj * 32 + 8 * rg + 4 * half]);
         // plain v_fma_f32 on purpose (lbs_fma): packed fp32 FMAs beside another wave's MFMAs cost more than they save on
         // gfx950 (MI355X_MICROARCH.md, price of a filler), and the row pairs they need cost two v_mov per operand
 #pragma unroll
@@ -593,12 +593,23 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
       // gathers were four of its eight round trips per item).  The world coordinates are not kept: the rare undecided point
       // recomputes its own (12 FMAs) inside the queue branch.
       auto world = [&](int r, int a) { return fmaf(Mw[a * 3 + 0], o[r][0], fmaf(Mw[a * 3 + 1], o[r][1], fmaf(Mw[a * 3 + 2], o[r][2], tw[a]))); };
+      // the bracket lookup wants CELL coordinates r / 4 + 1: the same affine map scaled by 1/4 (exact) with the +1 folded into
+      // its constant - three FMAs per point instead of six; a point within round-off of a cell border may land in the
+      // neighbouring cell, which egx_sdf_coarse_at_raw already allows for
+      float Mc[9], tc[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) Mc[a * 3 + e] = 0.25f * Mw[a * 3 + e];
+        tc[a] = fmaf(0.25f, tw[a], 1.f);
+      }
+      auto cell = [&](int r, int a) { return fmaf(Mc[a * 3 + 0], o[r][0], fmaf(Mc[a * 3 + 1], o[r][1], fmaf(Mc[a * 3 + 2], o[r][2], tc[a]))); };
       constexpr int LB = WRITE_VERTS ? RB : 16;   // rows per lookup burst (the vertex-writing variant has no registers to spare)
 #pragma unroll
       for (int rb0 = 0; rb0 < 16; rb0 += LB) {
       float2 mm[LB];
 #pragma unroll
-      for (int r = rb0; r < rb0 + LB; ++r) mm[r - rb0] = egx_sdf_coarse_at_raw(p.sdf, world(r, 0), world(r, 1), world(r, 2));
+      for (int r = rb0; r < rb0 + LB; ++r) mm[r - rb0] = egx_sdf_coarse_at_cell(p.sdf, cell(r, 0), cell(r, 1), cell(r, 2));
 #pragma unroll
       for (int r0 = rb0; r0 < rb0 + LB; r0 += RB) {
         if (qn + RB * 64 > QCAP) { sdf_flush(qn); qn = 0; }  // room for one batch: RB rows x 64 lanes
@@ -1279,7 +1290,7 @@ __global__ __launch_bounds__(256) void egx_lbs_cull_kernel(const int* __restrict
     float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
     const int jj_lo = __builtin_amdgcn_readfirstlane(tj_off[vt]), jj_hi = __builtin_amdgcn_readfirstlane(tj_off[vt + 1]);
     for (int jj = jj_lo; jj < jj_hi; ++jj) {
-      const int j = __builtin_amdgcn_readfirstlane(tj_idx[jj]);
+      const int j = __builtin_amdgcn_readfirstlane(tj_idx[jj]) & 0xff;
       const float rho = (D0[jj] + margin) * 1.0001f;
       const float c0 = jpos[(size_t)(j * 3 + 0) * Bp + ss], c1 = jpos[(size_t)(j * 3 + 1) * Bp + ss], c2 = jpos[(size_t)(j * 3 + 2) * Bp + ss];
 #pragma unroll
@@ -1521,7 +1532,11 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
         any |= col[r] != 0.f;
       }
       if (any) {
-        tj_idx.push_back(j);
+        // bits 8..11: which groups of eight rows (rows 8g .. 8g+7 = the four rows of row group g in both lane halves of the
+        // epilogue) hold a non-zero weight of this joint - the epilogue skips the others with a scalar test
+        int gmask = 0;
+        for (int r = 0; r < 32; ++r) gmask |= (col[r] != 0.f) ? (1 << (r >> 3)) : 0;
+        tj_idx.push_back(j | (gmask << 8));
         tj_w.insert(tj_w.end(), col, col + 32);
       }
     }
@@ -1638,7 +1653,7 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
       const int v = perm[vt * 32 + r];
       if (v < 0) continue;
       for (int jj = tj_off[vt]; jj < tj_off[vt + 1]; ++jj) {
-        const int j = tj_idx[jj];
+        const int j = tj_idx[jj] & 0xff;
         if (d->lbs_weights_host[(size_t)v * NJ + j] != 0.f) {
           double q = 0.0;
           for (int c = 0; c < 3; ++c) {

@@ -100,6 +100,21 @@ __device__ __forceinline__ float2 egx_sdf_coarse_at_raw(const SdfDev& s, float r
   return s.coarse[idx];
 }
 
+// The same lookup from CELL coordinates c = r / 4 + 1 (the caller folds the 1/4 and the +1 into its affine map).  The table
+// index is formed in fp32 - exact while the padded table has fewer than 2^24 entries (a 256^3 grid: 66^3) - and converted
+// once: two FMAs and one conversion instead of three conversions, two integer multiplies (quarter rate) and two adds.
+__device__ __forceinline__ float2 egx_sdf_coarse_at_cell(const SdfDev& s, float cx, float cy, float cz) {
+  const float jx = __builtin_amdgcn_fmed3f(floorf(cx), 0.f, (float)(s.c0 + 1));
+  const float jy = __builtin_amdgcn_fmed3f(floorf(cy), 0.f, (float)(s.c1 + 1));
+  const float jz = __builtin_amdgcn_fmed3f(floorf(cz), 0.f, (float)(s.c2 + 1));
+  unsigned idx;
+  if ((unsigned)(s.c0 + 2) * (unsigned)(s.c1 + 2) * (unsigned)(s.c2 + 2) < (1u << 24))   // uniform
+    idx = (unsigned)fmaf(fmaf(jx, (float)(s.c1 + 2), jy), (float)(s.c2 + 2), jz);
+  else
+    idx = ((unsigned)jx * (unsigned)(s.c1 + 2) + (unsigned)jy) * (unsigned)(s.c2 + 2) + (unsigned)jz;
+  return s.coarse[idx];
+}
+
 struct __attribute__((packed, aligned(4))) EgxF2 { float x, y; };  // two z-neighbours, 4-byte aligned
 
 // -trilinear(grid) at clamped voxel coordinates: aten grid_sampler_3d corner order and rounding.  The two z-neighbours

@@ -711,6 +711,62 @@ def test_train_step_matches_oracle_fp64(mode):
     print("\n".join(lines))
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x2"])
+def test_train_step_gradients_on_all_rows_report(mode):
+    """The same comparison WITHOUT the leaky-ReLU margin filter of the test above: the first 256 candidate transitions as they
+    come - what a user's minibatch looks like.  A pre-activation within the arithmetic's round-off of zero takes the other side of
+    the kink in ONE of two correct evaluations; each such element changes one row of one weight gradient by O(1) of that row, in
+    the chain and in torch-fp32 alike, so the bound here is the fp32 yardstick's own size on the same rows (the chain may be at
+    most 3x further from float64 than fp32 autograd is, plus 1e-4).  EGX_P3_TABLE=<file> appends the table
+    (profiles/r05_p3_yardstick.txt: rel-L2 per parameter, unfiltered, next to the yardstick)."""
+    from egogen_amd import setup_world as sw
+    a = _Args()
+    a.update_precision = mode
+    pol = sw.build_policy(a)
+    with torch.no_grad():
+        for p_ in pol.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.05 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(p_.numel())).cuda())
+        pol.actor.pnet.out_fc.bias[128:160] += 4.0
+        pol.actor.pnet.out_fc.bias[160:192] -= 4.0
+    N = 256
+    b = _filled_batch(1, 8 * N, 0, pol)       # the candidate pool of _unambiguous_rows (same seed): its FIRST 256 rows
+    idx = torch.arange(N, device="cuda")
+    sel = lambda t: t.reshape((-1,) + tuple(t.shape[2:]))[idx.to(t.device)]
+    obs = {k: v[idx] for k, v in b.obs_flat().items()}
+    args = (obs, sel(b.act), sel(b.adv), sel(b.returns), sel(b.logp_old))
+    t64, g64, zs = _oracle_p3(pol.state_dict(), *args, torch.float64)
+    t32, g32, _ = _oracle_p3(pol.state_dict(), *args, torch.float32)
+    band = {"f32": 1e-5, "bf16x2": 2e-4}[mode]
+    near = sum(int(((z.abs() / z.pow(2).mean().sqrt()) < band).sum()) for z in zs)
+    pol._ensure_flat_grads()
+    assert pol._flat_optimizer_ready()
+    log = torch.zeros(6, device="cuda")
+    assert pol._train_handle(N) is not None
+    assert pol._fwd_bwd(b, idx, None, log) == "chain"
+    torch.cuda.synchronize()
+    lines = [f"# mode {mode}: the first 256 candidate rows, NO margin filter ({near} of {sum(z.numel() for z in zs)} leaky-ReLU arguments within "
+             f"{band} x rms of zero)",
+             f"# {'parameter':<46s} {'||g64||':>10s} {'rel-L2 fp32':>12s} {'rel-L2 chain':>12s} {'ratio':>7s}"]
+    worst = 0.0
+    for n_, p_ in pol.named_parameters():
+        if n_.startswith("_actor_critic."):
+            continue
+        ref = g64[n_].cuda()
+        nrm = float(ref.norm()) + 1e-300
+        r32 = float((g32[n_].cuda() - ref).norm()) / nrm
+        rch = float((p_.grad.double() - ref).norm()) / nrm
+        worst = max(worst, rch)
+        lines.append(f"  {n_:<46s} {nrm:10.3e} {r32:12.3e} {rch:12.3e} {rch / max(r32, 1e-7):7.2f}")
+        assert rch <= 3.0 * r32 + (1e-4 if mode == "f32" else 2e-3), (n_, rch, r32)
+    lines.append(f"# worst rel-L2 of the chain on unfiltered rows: {worst:.3e}")
+    out = os.environ.get("EGX_P3_TABLE")
+    if out:
+        with open(out, "a") as f:
+            f.write("\n".join(lines) + "\n\n")
+    print("\n".join(lines))
+
+
 def test_learn_matches_oracle_fp64_parameters():
     """End to end: two passes of `learn()` (8 optimiser steps, replayed graphs) in every update mode against the same schedule
     done in float64 with the oracle's loss (torch AdamW + clip_grad_norm_ on float64 copies, the reference's optimiser calls,
