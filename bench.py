@@ -400,7 +400,7 @@ def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_
             env.profile_events = list(evs)
     if world > 1:  # events around every gradient all-reduce of the timed region
         policy.allreduce_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                                   for _ in range(steps * n_mb + 8)]
+                                   for _ in range(2 * (steps * n_mb + 8))]      # two buckets per optimiser step
         policy._allreduce_done = []
 
     def timed_region():
@@ -457,11 +457,16 @@ def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_
         torch.cuda.synchronize()
         alone_ms = (time.perf_counter() - t1) / 10 * 1e3
         nbytes = flat.numel() * 4
-        ar = {"bytes": nbytes, "calls_per_step": n_mb, "in_loop_avg_ms": float(np.mean(in_loop)) if in_loop else None,
+        n_buckets = len(policy._grad_buckets())
+        ar = {"bytes": nbytes, "buckets": n_buckets, "bucket_bytes": [int(b.numel()) * 4 for b in policy._grad_buckets()],
+              "overlapped_with_backward": bool(policy.overlap_allreduce and n_buckets == 2 and args.update_graph),
+              "calls_per_step": n_mb * (n_buckets if (policy.overlap_allreduce and args.update_graph) else 1),
+              "in_loop_avg_ms": float(np.mean(in_loop)) if in_loop else None,
               "in_loop_ms_per_step": float(np.sum(in_loop)) / steps if in_loop else None, "standalone_ms": alone_ms,
               "standalone_algbw_GBps": nbytes / (alone_ms * 1e-3) / 1e9,
               "standalone_busbw_GBps": nbytes / (alone_ms * 1e-3) / 1e9 * 2 * (world - 1) / world,
-              "note": "in_loop includes the wait for the slowest rank; busbw = algbw * 2(N-1)/N (ring all-reduce)"}
+              "note": "in_loop = sum over the buckets, measured on the communication stream (bucket 0 overlaps the encoders' backward), includes "
+                      "the wait for the slowest rank; busbw = algbw * 2(N-1)/N (ring all-reduce)"}
     graphs_ok = bool(args.update_graph) and not any(v.get("failed") for v in policy._graph_cache.values())
     forced = env.forced_accepts() if hasattr(env, "forced_accepts") else 0
     if world > 1:

@@ -192,6 +192,8 @@ SIGNATURES = {
     "egx_policy_train_packed": (C.c_int, [C.c_void_p, C.POINTER(PolicyPacked3)]),
     "egx_policy_train_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "egx_policy_train_step": (C.c_int, [C.c_void_p] * 9 + [C.c_float] * 6 + [C.c_void_p, C.c_void_p]),
+    "egx_policy_train_step_heads": (C.c_int, [C.c_void_p] * 9 + [C.c_float] * 6 + [C.c_void_p, C.c_void_p]),
+    "egx_policy_train_step_encoders": (C.c_int, [C.c_void_p, C.c_void_p]),
     "egx_policy_train_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "egx_pack3_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "egx_pack3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

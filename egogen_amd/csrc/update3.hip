@@ -490,11 +490,41 @@ extern "C" int egx_policy_train_bind(egx_policy_train* h, const float* state, co
   return EGX_OK;
 }
 
+static int train_step_parts(egx_policy_train* h, const float* dist, const float* time, const float* act, const float* adv,
+                            const float* ret, const float* logp_old, const float* adv_stats, const float* scale, float adv_eps,
+                            float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef, float* out_terms,
+                            void* stream_, int parts);
+
 extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, const float* time, const float* act, const float* adv,
                                      const float* ret, const float* logp_old, const float* adv_stats, const float* scale,
                                      float adv_eps, float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef,
                                      float* out_terms, void* stream_) {
-  EGX_REQUIRE(h && dist && time && act && adv && ret && logp_old && scale && out_terms, "null argument");
+  return train_step_parts(h, dist, time, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef,
+                          ent_coef, out_terms, stream_, 3);
+}
+
+// The same chain in two halves, for data-parallel training: `egx_policy_train_step_heads` ends when the last weight gradient of
+// the actor and critic blocks has been enqueued (forward, loss, their whole backward: the 10.3 M-parameter prefix of the flat
+// gradient is final), `egx_policy_train_step_encoders` runs the rest (the two GRU encoders' backward).  The caller all-reduces
+// the first bucket on a side stream while the second half runs (egogen_amd/ppo_policy.py).
+extern "C" int egx_policy_train_step_heads(egx_policy_train* h, const float* dist, const float* time, const float* act, const float* adv,
+                                           const float* ret, const float* logp_old, const float* adv_stats, const float* scale,
+                                           float adv_eps, float min_logvar, float max_logvar, float eps_clip, float vf_coef,
+                                           float ent_coef, float* out_terms, void* stream_) {
+  return train_step_parts(h, dist, time, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef,
+                          ent_coef, out_terms, stream_, 1);
+}
+extern "C" int egx_policy_train_step_encoders(egx_policy_train* h, void* stream_) {
+  EGX_REQUIRE(h, "null handle");
+  return train_step_parts(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr,
+                          stream_, 2);
+}
+
+static int train_step_parts(egx_policy_train* h, const float* dist, const float* time, const float* act, const float* adv,
+                            const float* ret, const float* logp_old, const float* adv_stats, const float* scale, float adv_eps,
+                            float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef, float* out_terms,
+                            void* stream_, int parts) {
+  EGX_REQUIRE(h && (!(parts & 1) || (dist && time && act && adv && ret && logp_old && scale && out_terms)), "null argument");
   EGX_REQUIRE(h->tab_inputs, "egx_policy_train_bind has not been called");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int n = h->n, Sn = h->Sn;
@@ -510,6 +540,8 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
     return egx_launch_gru3_pair(s_, g0, g1);
   };
 
+  int rc = EGX_OK;
+  if (parts & 1) {
   // ================= forward =================
   run_table(st, h->tab_inputs, h->n_inputs, h->frags_inputs, planes_of(h->prec));
   egx_launch_posenc3(st, dist, time, n, h->catf + 2 * HD, CAT, h->cat_r, S_CAT, 2 * S_HD, h->catT, Sn, 2 * HD);
@@ -571,7 +603,7 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
     launch_n(st, L, 2);
   }
   // ================= loss and its gradient w.r.t. the two heads (ppo_policy.py:189-241) =================
-  int rc = egx_ppo_loss_packed(h->br[0].head, h->br[1].head, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_logvar, max_logvar,
+  rc = egx_ppo_loss_packed(h->br[0].head, h->br[1].head, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_logvar, max_logvar,
                                eps_clip, vf_coef, ent_coef, n, h->br[0].ghead, h->br[1].ghead, out_terms, st);
   if (rc) return rc;
   run_table(st, h->tab_loss, h->n_loss, h->frags_loss, planes_of(h->prec));
@@ -638,8 +670,10 @@ extern "C" int egx_policy_train_step(egx_policy_train* h, const float* dist, con
     launch_n(sw, WL, 4);
     launch_n(sw, WL + 4, 4);
   }
+  }   // parts & 1: every gradient of the actor and critic blocks is enqueued
   // ---- the two GRU encoders (dhx = actor's + critic's)
-  {
+  if (parts & 2) {
+    hipStream_t sw = st;
     GruBwd2 two;
     const int blocks = (n / 32) * (HD / 32);
     two.blocks0 = blocks;

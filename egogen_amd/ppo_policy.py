@@ -117,6 +117,9 @@ class GAMMAPPOPolicy(nn.Module):
         self._layout = None
         self._graph_cache: dict = {}
         self.use_update_graph = bool(_ignored.get("use_update_graph", False))
+        # data parallel + replayed graphs: all-reduce the actor + critic bucket beside the encoders' backward (EGX_DP_OVERLAP=0:
+        # one all-reduce of the whole flat gradient between the two graphs, the round-4 form - the parity tests compare the two)
+        self.overlap_allreduce = os.environ.get("EGX_DP_OVERLAP", "1") != "0"
         self.use_fused_loss = bool(_ignored.get("use_fused_loss", True))
         self._scale_cache = {}
         # the minibatch as a fixed chain of hand-written launches (csrc/update3.hip); EGX_TRAIN_STEP=0: the autograd nodes
@@ -393,10 +396,15 @@ class GAMMAPPOPolicy(nn.Module):
         for hs in self._train_handles.values():
             _lib.check(lib.egx_policy_train_refresh(hs["h"], st), "egx_policy_train_refresh")
 
-    def _fwd_bwd_train_step(self, hs, batch, idx, gstats, log_out):
-        """gather + forward + loss + backward of one minibatch: 2 + ~21 launches, gradients written into the flat buffer."""
+    def _fwd_bwd_train_step(self, hs, batch, idx, gstats, log_out, part: str = "all"):
+        """gather + forward + loss + backward of one minibatch: 2 + ~21 launches, gradients written into the flat buffer.
+        `part`: "all"; "heads" = everything up to the last actor / critic weight gradient (data-parallel training all-reduces that
+        bucket while "encoders" - the GRU encoders' backward - runs)."""
         from .fused_ops import gather_rows
         lib, st = _lib.load(), _lib.current_stream_ptr()
+        if part == "encoders":
+            _lib.check(lib.egx_policy_train_step_encoders(hs["h"], st), "egx_policy_train_step_encoders")
+            return
         N = batch.n * batch.A
         obs_all = batch.obs_flat()
         b = hs["bufs"]
@@ -414,10 +422,11 @@ class GAMMAPPOPolicy(nn.Module):
         else:
             hs["stats"].copy_(torch.stack([gstats[0], gstats[1]]).float())
             scale = (1.0 / gstats[2]).reshape(1).float()
-        rc = lib.egx_policy_train_step(hs["h"], _lib.ptr(b[2]), _lib.ptr(b[3]), _lib.ptr(b[4]), _lib.ptr(b[5]), _lib.ptr(b[6]), _lib.ptr(b[7]),
-                                       _lib.ptr(hs["stats"]), _lib.ptr(scale), float(_EPS), float(self.actor.min_logvar),
-                                       float(self.actor.max_logvar), float(self._eps_clip), float(self._weight_vf), float(self._weight_ent),
-                                       _lib.ptr(log_out), st)
+        fn = lib.egx_policy_train_step_heads if part == "heads" else lib.egx_policy_train_step
+        rc = fn(hs["h"], _lib.ptr(b[2]), _lib.ptr(b[3]), _lib.ptr(b[4]), _lib.ptr(b[5]), _lib.ptr(b[6]), _lib.ptr(b[7]),
+                _lib.ptr(hs["stats"]), _lib.ptr(scale), float(_EPS), float(self.actor.min_logvar),
+                float(self.actor.max_logvar), float(self._eps_clip), float(self._weight_vf), float(self._weight_ent),
+                _lib.ptr(log_out), st)
         _lib.check(rc, "egx_policy_train_step")
 
     def _fwd_bwd(self, batch, idx, gstats, log_out) -> str:
@@ -555,17 +564,32 @@ class GAMMAPPOPolicy(nn.Module):
         var = (mom[:, 1] - ng * mean * mean) / (ng - 1)            # unbiased, like Tensor.std()
         return torch.stack([mean, var.clamp(min=0).sqrt(), ng], dim=1).float()
 
-    def _all_reduce_grad(self):
-        """Sum of the flat gradient over the ranks, in place (RCCL over xGMI; every rank already scaled its loss by
-        1 / n_global, so the sum IS the gradient of the global minibatch mean).  Timed by bench.py through
-        `allreduce_events`."""
+    def _grad_buckets(self):
+        """The flat gradient as two contiguous buckets: [0, n_clip) = actor + critic (what crowd_ppo clips; final when the heads'
+        half of the chain is enqueued) and [n_clip, total) = the shared GRU encoders."""
+        n = getattr(self, "_n_clip", None)
+        g = self._flat_grad
+        if n is None or n <= 0 or n >= g.numel():
+            return [g]
+        return [g[:n], g[n:]]
+
+    def _all_reduce_grad(self, bucket=None):
+        """Sum of the flat gradient (or one bucket of it) over the ranks, in place (RCCL over xGMI; every rank already scaled its
+        loss by 1 / n_global, so the sum IS the gradient of the global minibatch mean) on the CURRENT stream.  Timed by bench.py
+        through `allreduce_events` (events on the issuing stream)."""
         ev = self.allreduce_events.pop() if self.allreduce_events else None
         if ev is not None:
             ev[0].record()
-        dist.all_reduce(self._flat_grad)
+        dist.all_reduce(self._flat_grad if bucket is None else bucket)
         if ev is not None:
             ev[1].record()
             self._allreduce_done.append(ev)
+
+    def _comm_stream(self):
+        s = getattr(self, "_comm_s", None)
+        if s is None:
+            s = self._comm_s = torch.cuda.Stream()
+        return s
 
     def _graphs_for(self, batch: RolloutBatch, local_bs: int):
         """Capture (gather + forward + loss + backward) and (clip + AdamW) for a fixed minibatch size.  With one rank
@@ -599,8 +623,19 @@ class GAMMAPPOPolicy(nn.Module):
                     st["path"] = self._fwd_bwd(batch, st["idx"], gs(), st["log"])
                     self._clip_and_step()
             else:
-                with torch.cuda.graph(g1):
-                    st["path"] = self._fwd_bwd(batch, st["idx"], gs(), st["log"])
+                hs = self._train_handle(local_bs) if st["idx"].is_cuda else None
+                if hs is not None and len(self._grad_buckets()) == 2 and self.overlap_allreduce:
+                    # the chain in two halves: after g1 (heads) the actor + critic bucket is final and its all-reduce runs on a
+                    # side stream beside g1b (the encoders' backward)
+                    with torch.cuda.graph(g1):
+                        self._fwd_bwd_train_step(hs, batch, st["idx"], gs(), st["log"], part="heads")
+                    g1b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1b, pool=g1.pool()):
+                        self._fwd_bwd_train_step(hs, batch, st["idx"], gs(), st["log"], part="encoders")
+                    st["g1b"], st["path"] = g1b, "chain"
+                else:
+                    with torch.cuda.graph(g1):
+                        st["path"] = self._fwd_bwd(batch, st["idx"], gs(), st["log"])
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, pool=g1.pool()):
                     self._clip_and_step()
@@ -712,7 +747,21 @@ class GAMMAPPOPolicy(nn.Module):
                         st["gstats"].copy_(gstats_all[i])
                     st["g1"].replay()
                     if dp:
-                        self._all_reduce_grad()
+                        if st.get("g1b") is not None:
+                            # bucket 0 (actor + critic: 78 % of the bytes) is reduced on the communication stream while the
+                            # encoders' backward runs on this one; bucket 1 follows it there; clip + AdamW wait for both
+                            main, comm = torch.cuda.current_stream(), self._comm_stream()
+                            b0, b1 = self._grad_buckets()
+                            comm.wait_stream(main)
+                            with torch.cuda.stream(comm):
+                                self._all_reduce_grad(b0)
+                            st["g1b"].replay()
+                            comm.wait_stream(main)
+                            with torch.cuda.stream(comm):
+                                self._all_reduce_grad(b1)
+                            main.wait_stream(comm)
+                        else:
+                            self._all_reduce_grad()
                         st["g2"].replay()
                     last_log = st["log"].clone()
                     self.update_paths[st["path"] + "+graph"] = self.update_paths.get(st["path"] + "+graph", 0) + 1

@@ -381,6 +381,16 @@ int egx_policy_train_step(egx_policy_train* h, const float* dist, const float* t
                           const float* ret, const float* logp_old, const float* adv_stats, const float* scale, float adv_eps,
                           float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef, float* out_terms,
                           void* stream);
+/* The same chain in two halves, for data-parallel training (no reference counterpart: the reference trains on one device).
+ * `_heads` = forward, loss (ppo_policy.py:189-241) and the whole backward of the actor and critic blocks: when it has been
+ * enqueued, the prefix of the flat gradient that crowd_ppo clips (actor + critic, 10.3 M of 13.2 M parameters) is final, so its
+ * all-reduce can start on a side stream; `_encoders` = the backward of the two GRU encoders (the remaining 2.8 M).  Calling both
+ * in order is egx_policy_train_step. */
+int egx_policy_train_step_heads(egx_policy_train* h, const float* dist, const float* time, const float* act, const float* adv,
+                                const float* ret, const float* logp_old, const float* adv_stats, const float* scale, float adv_eps,
+                                float min_logvar, float max_logvar, float eps_clip, float vf_coef, float ent_coef, float* out_terms,
+                                void* stream);
+int egx_policy_train_step_encoders(egx_policy_train* h, void* stream);
 /* Arithmetic of every product of the chain (forward, input gradients, weight gradients): 0 = each fp32 operand as three bf16
  * terms, six partial products (2^-24 relative: fp32-equivalent; default), 2 = two terms, three products (16 significant bits
  * per operand, the arithmetic of the LBS blend GEMM's default mode), 1 = operands rounded to bf16, one product ("bf16 MFMA"
