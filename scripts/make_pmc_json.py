@@ -24,6 +24,13 @@ if "TCC_HIT_sum" in per:
     dv["l2_hit_rate"] = per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
 if "SQ_VALU_MFMA_BUSY_CYCLES" in per and "SQ_BUSY_CU_CYCLES" in per:
     dv["mfma_pipe_utilisation"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * per["SQ_BUSY_CU_CYCLES"]) if per["SQ_BUSY_CU_CYCLES"] else None
+if "TCP_TCC_READ_REQ_sum" in per:
+    dv["l2_to_l1_bytes_per_launch"] = int(per["TCP_TCC_READ_REQ_sum"] * 128)
+    dv["l2_to_l1_note"] = "TCP_TCC_READ_REQ_sum x 128 B (request size calibrated on the kernel's own operand traffic); scripts/ubench/l2_bw.hip sustains 32 TB/s from L2"
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in per:
+        dv["l1_hit_rate"] = 1.0 - per["TCP_TCC_READ_REQ_sum"] / per["TCP_TOTAL_CACHE_ACCESSES_sum"]
+if "SQ_INSTS_VALU" in per:
+    dv["valu_wave_instructions_per_simd"] = per["SQ_INSTS_VALU"] / 1024.0
 dv["algorithmic_bytes_per_launch"] = int(alg)
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", f"{rnd}_lbs_pmc_mode{mode}.json")
 json.dump(d, open(out, "w"), indent=1)

@@ -21,7 +21,7 @@ lbs = max((r for r in rows if "egx_lbs_fused3" in r["Name"]), key=lambda r: floa
 L = [f"# Round {int(RND[1:])} final profile (1x MI355X)", "",
      f"Command: `bash scripts/run_profile.sh` = `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --extra-configs 0 --steps 10`",
      f"(per-cycle figures below divide by {ncyc}).  Un-profiled run of `python bench.py`: `{RND}_final_bench.json`.", "",
-     f"* un-profiled: **{b['value']:.0f} env-steps/s**, {b['ms_per_step']:.2f} ms per 2048-transition cycle; fused LBS kernel {b['roofline']['avg_launch_ms']:.3f} ms per launch (HIP events) = {b['roofline']['achieved']:.1f} TFLOP/s fp32-equivalent, frac {b['roofline']['frac']:.3f} of {b['roofline']['peak']:.1f} ({b['roofline']['peak_note']}); traffic {b['roofline']['traffic']/1e9:.2f} GB per launch (PMC)",
+     f"* un-profiled: **{b['value']:.0f} env-steps/s**, {b['ms_per_step']:.2f} ms per 2048-transition cycle; fused LBS kernel {b['roofline']['avg_launch_ms']:.3f} ms per launch (HIP events) = {b['roofline']['achieved']:.1f} TFLOP/s fp32-equivalent, frac {b['roofline']['frac']:.3f} of {b['roofline']['peak']:.1f} ({b['roofline'].get('peak_note', '16-bit MFMA peak / products per fp32 product')}); traffic {b['roofline']['traffic']/1e9:.2f} GB per launch (PMC)",
      f"* under rocprofv3: {u['value']:.0f} env-steps/s; LBS kernel: rocprofv3 average {float(lbs['AverageNs'])/1e6:.3f} ms over {lbs['Calls']} launches, HIP-event average in the same run {u['roofline']['avg_launch_ms']:.3f} ms",
      f"* cpu_baseline: {b['cpu_baseline']['value']:.2f} env-steps/s on {b['cpu_baseline']['cores']} threads ({b['cpu_baseline']['sample']})", "",
      "| share | ms / cycle | launches / cycle | avg us | kernel |", "|---|---|---|---|---|"]
