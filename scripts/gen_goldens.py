@@ -590,11 +590,14 @@ def gen_lbs_skin():
     spec = importlib.util.spec_from_file_location("hood_lbs", os.path.join(REF, "..", "experiments", "HOOD", "utils", "lbs.py"))
     hood = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(hood)
-    V, B = 192, 5
+    # V = 2048 (64 vertex tiles), 257 bodies (one past a 256-body group of the fused kernel), non-zero translations; the fixture
+    # keeps every 13th vertex plus the marker vertices of all 257 bodies (the full tensor would be 6.3 MB)
+    V, B = 2048, 257
     bm = synth.make_body_model(3, num_verts=V)
     ob = BodyModel(bm)
     g = torch.Generator().manual_seed(31)
     xb = torch.zeros(B, 93)
+    xb[:, 0:3] = torch.randn(B, 3, generator=g) * 1.5 + torch.tensor([0.0, 0.0, 0.9])
     xb[:, 3:6] = torch.randn(B, 3, generator=g) * 0.8
     xb[:, 6:69] = torch.randn(B, 63, generator=g) * 0.4
     xb[:, 69:] = torch.randn(B, 24, generator=g) * 0.5
@@ -607,9 +610,13 @@ def gen_lbs_skin():
     ref_verts, _ = hood.pose_garment(betas, full_pose, mid["v_shaped"], ob.shapedirs, ob.posedirs, ob.lbs_weights,
                                      joints[:, :55], mid["A"], pose2rot=True, A_POSE=torch.zeros(B, 165),
                                      A_joint_transforms=torch.eye(4).repeat(B, 55, 1, 1))
-    print("lbs_skin_ref", ref_verts.shape, "max |hood - oracle|", float((ref_verts - verts).abs().max()))
+    # pose_garment returns the skinned vertices; smplx adds the translation afterwards (`vertices += transl.unsqueeze(1)`, lbs
+    # caller in smplx/body_models.py [upstream]) - that one addition is done here
+    ref_verts = ref_verts + xb[:, None, 0:3]
+    keep = np.unique(np.concatenate([np.arange(0, V, 13), np.asarray(synth.marker_ids(V), np.int64)]))
+    print("lbs_skin_ref", ref_verts.shape, "kept", keep.size, "max |hood - oracle|", float((ref_verts - verts).abs().max()))
     np.savez_compressed(os.path.join(OUT, "lbs_skin_ref.npz"), body_seed=3, num_verts=V, xb=xb.numpy(), betas=betas.numpy(),
-                        verts=ref_verts.numpy())
+                        vertex_ids=keep, verts=ref_verts.numpy()[:, keep])
 
 
 if __name__ == "__main__":

@@ -4,8 +4,8 @@
 #   gpurun --timeout 4500 -- 'bash scripts/run_final_checks.sh'
 set -u
 mkdir -p gpurun_out/final
-export EGX_P3_TABLE=$PWD/gpurun_out/final/p3_table.txt EGX_C5_HIST=$PWD/gpurun_out/final/c5_hist.txt
-rm -f $EGX_P3_TABLE
+export EGX_P3_TABLE=$PWD/gpurun_out/final/p3_table.txt EGX_C5_HIST=$PWD/gpurun_out/final/c5_hist.txt EGX_TOL_REPORT=$PWD/gpurun_out/final/env_tolerance_usage.txt
+rm -f $EGX_P3_TABLE $EGX_TOL_REPORT
 EGX_DRIFT_TABLE=gpurun_out/final/drift_table.txt timeout 3000 python -m pytest tests -x -q -m gpu < /dev/null > gpurun_out/final/gpu_tests.log 2>&1
 echo "gpu tests rc=$?"; tail -4 gpurun_out/final/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" < /dev/null > gpurun_out/final/smoke.log 2>&1

@@ -83,10 +83,12 @@ def test_lbs_vertices_match_in_tree_skinning_golden(blend_mode):
     h = BodyModelHandle(bm, synth.marker_ids(V), synth.feet_vids(V))
     xb, betas = torch.from_numpy(g["xb"]).cuda(), torch.from_numpy(g["betas"]).cuda()
     out = h.forward(xb, betas, 1, want_verts=True)
-    assert max_abs(out["vertices"].cpu(), g["verts"]) < 2e-5
-    mk = torch.as_tensor(synth.marker_ids(V)).long()
+    keep = g["vertex_ids"]               # V = 2048 (64 vertex tiles), 257 translated bodies: the fixture holds 220 vertices of each
+    assert max_abs(out["vertices"].cpu()[:, keep], g["verts"]) < 2e-5
+    mk = np.asarray(synth.marker_ids(V))
+    col = {int(v): i for i, v in enumerate(keep)}
     picks = h.forward(xb, betas, 1)      # the hot path (selected blend mode): markers are rows of the same vertices
-    assert max_abs(picks["markers"].cpu(), g["verts"][:, mk.numpy()]) < 2e-5
+    assert max_abs(picks["markers"].cpu(), g["verts"][:, [col[int(v)] for v in mk]]) < 2e-5
 
 
 @pytest.mark.parametrize("A,T", [(1, 1), (257, 1), (105, 20)])
