@@ -84,8 +84,8 @@ def get_args():
                    help="arithmetic of the rollout policy's dense layers (egx_policy_set_precision)")
     p.add_argument("--repeats", type=int, default=3, help="timed regions of --steps cycles each; value = the median region")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=20.0, help="time cap of each secondary CPU-baseline leg")
-    p.add_argument("--cpu-repeats", type=int, default=3, help="repeats of the headline CPU leg (min / median reported)")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="time cap of each secondary CPU-baseline leg")
+    p.add_argument("--cpu-repeats", type=int, default=2, help="repeats of the headline CPU leg (min / median reported)")
     p.add_argument("--cpu-agent-steps", type=int, default=200, help="agent-steps of each sequential CPU-baseline leg (or the time cap)")
     p.add_argument("--extra-configs", type=int, default=1,
                    help="N = 1: 1 = also time configs[2], the strictly fp32-equivalent arithmetic and the reference-default shape (scalars of "
