@@ -454,9 +454,8 @@ __device__ unsigned long long g_lbs_t[16];
 #endif
 
 // Epilogue of one work item: each lane owns 16 vertices (rows) x 2 bodies (column n of tiles bt0, bt0+1).
-template <bool WRITE_VERTS, bool DO_SDF, int RB, int QCAP>
-__device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int JT) {
-  constexpr int NB = LBS_NB;
+template <bool WRITE_VERTS, bool DO_SDF, int RB, int QCAP, int NB = LBS_NB>
+__device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32x16 (&acc)[3][NB], int vt, int bt0, int JT) {
   const int lane = w.lane, n = w.n, half = w.half;
   float* s_W = w.s_W; int* s_jl = w.s_jl; int* s_slot = w.s_slot; unsigned* s_masks = w.s_masks; int* s_cnt = w.s_cnt;
   float* lds = w.lds; f32x4* s_queue = w.s_queue;
@@ -693,7 +692,7 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
     const int c = s_cnt[lane];            // lane = q*32 + n: one global atomic per body and item
     s_cnt[lane] = 0;
     const int sd = (bt0 + (lane >> 5)) * 32 + (lane & 31);
-    if (c != 0 && sd < p.B) {
+    if (c != 0 && sd < p.B && lane < 32 * NB) {
       const int bd = p.agent_of_slot ? p.agent_of_slot[sd / p.fpa] * p.fpa + sd % p.fpa : sd;
       atomicAdd(p.pene + bd, c);
     }
@@ -928,9 +927,10 @@ static_assert(28 % M4_FKS == 0, "fp16 stages cover k-steps 1..28 exactly");
 
 // Operand registers of one stage: this wave's share of the stage's base pieces (on their way to the LDS ring) and its own
 // feature pieces.
+template <int NB>
 struct M4Regs {
   bf16x8 ga[(3 * M4_FKS + 3) / 4];
-  bf16x8 b[M4_FKS][LBS_NB];
+  bf16x8 b[M4_FKS][NB];
 };
 constexpr int M4_STAGES = 2 + 28 / M4_FKS;     // precise k-step 0, the fp16 stages, precise k-step 29
 __device__ __forceinline__ constexpr bool m4_precise(int st) { return st == 0 || st == M4_STAGES - 1; }
@@ -942,17 +942,17 @@ __device__ __forceinline__ constexpr int m4_feat0(int st) { return st == 0 ? 0 :
 // instead of their sum.  (The in-flight-load hazard of lbs_blend_f32 halves the MFMA rate of this wave meanwhile; here the
 // MFMAs are a quarter of the GEMM half - 204 per item - and the operand latency, bases streaming from the Infinity Cache, is
 // what the half waits for: 0.414 ms with the epilogue skipped against 0.10 ms of matrix time, profiles/r05_lbs_mixed.md.)
-__device__ __forceinline__ void lbs_blend_mixed(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave, bf16x8* sA,
+template <int NB>
+__device__ __forceinline__ void lbs_blend_mixed(const LbsParams& p, f32x16 (&acc)[3][NB], int vt, int bt0, int lane, int wave, bf16x8* sA,
                                                 unsigned long long* tacc) {
-  constexpr int NB = LBS_NB;
   const int num_bt = (p.B + 31) >> 5;
   asm volatile("" : "+v"(lane));   // per-lane operand addresses are formed per item
   const bf16x8* dpv = p.dirs4 + (size_t)vt * M4_BASE_PIECES * 64 + lane;
   const bf16x8* fq[NB];
 #pragma unroll
   for (int q = 0; q < NB; ++q) fq[q] = p.feat4 + (size_t)min(bt0 + q, num_bt - 1) * M4_FEAT_PIECES * 64 + lane;
-  M4Regs R[2];
-  auto issue = [&](M4Regs& r, int st) {
+  M4Regs<NB> R[2];
+  auto issue = [&](M4Regs<NB>& r, int st) {
     const int np = m4_precise(st) ? 6 : 3 * M4_FKS, nf = m4_precise(st) ? 2 : M4_FKS;
 #pragma unroll
     for (int i = 0; i < (3 * M4_FKS + 3) / 4; ++i) {
@@ -969,7 +969,7 @@ __device__ __forceinline__ void lbs_blend_mixed(const LbsParams& p, f32x16 (&acc
   issue(R[0], 0);
 #pragma unroll
   for (int st = 0; st < M4_STAGES; ++st) {
-    M4Regs& r = R[st & 1];
+    M4Regs<NB>& r = R[st & 1];
     bf16x8* buf = sA + (st & 1) * M4_RING_PIECES * 64;
     [[maybe_unused]] const unsigned long long t0 = LBS_NOW();
     __builtin_amdgcn_sched_barrier(0);
@@ -1025,14 +1025,76 @@ __device__ __forceinline__ void lbs_blend_mixed(const LbsParams& p, f32x16 (&acc
   }
 }
 
-template <int NPL, bool DO_SDF>
-__global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
-  constexpr int NB = LBS_NB;
+// The two-plane split (mode 2 arithmetic) for the tiles that hold picked vertices, on the small LDS ring of the three-workgroups-
+// per-CU kernel: stages of two k-steps (12 base pieces: 2 k-steps x 2 planes x 3 coordinates), burst -> wait -> ring -> barrier ->
+// 3 products per k-step.  8 of ~320 tiles: simple, not pipelined.
+template <int NB>
+__device__ __forceinline__ void lbs_blend_split2_small(const LbsParams& p, f32x16 (&acc)[3][NB], int vt, int bt0, int lane, int wave,
+                                                       bf16x8* sA) {
+  const int num_bt = (p.B + 31) >> 5;
+  asm volatile("" : "+v"(lane));
+  const bf16x8* dpv = p.dirs3 + (size_t)vt * KS3 * 9 * 64 + lane;  // piece (s, plane, coord) at ((s*3 + plane)*3 + coord)*64
+  const bf16x8* fq[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) fq[q] = p.feat3 + (size_t)min(bt0 + q, num_bt - 1) * KS3 * 3 * 64 + lane;
+  static_assert(KS3 % 2 == 0, "stages of two k-steps");
+  for (int st = 0; st < KS3 / 2; ++st) {
+    bf16x8 ga[3], b[2][2][NB];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int piece = wave + 4 * i;                 // (ks, plane, coord) of the stage: ks = piece / 6, plane = piece % 6 / 3
+      ga[i] = dpv[(size_t)((st * 2 + piece / 6) * 9 + (piece % 6)) * 64];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int q = 0; q < NB; ++q) b[ks][pl][q] = fq[q][((st * 2 + ks) * 3 + pl) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8* buf = sA + (st & 1) * M4_RING_PIECES * 64;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) buf[(wave + 4 * i) * 64 + lane] = ga[i];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[pl][c] = buf[((ks * 2 + pl) * 3 + c) * 64 + lane];
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr) {
+        const int pa = (pr == 1) ? 1 : 0, pb = (pr == 0) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+            acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][c], b[ks][pb][q], acc[c][q], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// LDS of the fused3 kernels: [operand ring][tile metadata 7424 B][4 x (counters 256 B + queue)].  NBW = 32-body tiles per wave:
+// 2 = the round-2..4 shape (a workgroup item = 32 vertices x 256 bodies, two workgroups per CU, 256 registers per wave);
+// 1 (mixed blend only, round 5) = 32 vertices x 128 bodies, THREE workgroups per CU: 48 accumulators instead of 96 fit a wave in
+// 168 registers, and the third wave per SIMD is what the latency chain of this kernel was missing - one workgroup per CU runs
+// the launch in 1.07 ms, two in 0.70 (profiles/r05_lbs_mixed.md section 5).
+template <int NBW> constexpr int lbs3_ring_bytes() { return NBW == 1 ? 2 * M4_RING_PIECES * 1024 : 2 * 18 * 1024; }
+template <int NBW> constexpr size_t lbs3_lds_bytes() { return (size_t)lbs3_ring_bytes<NBW>() + 7424 + 4 * LBS3_WAVE_BYTES; }
+
+template <int NPL, bool DO_SDF, int NBW = LBS_NB>
+__global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void egx_lbs_fused3_kernel(LbsParams p) {
+  constexpr int NB = NBW;
+  static_assert(NBW == LBS_NB || NPL == 4, "the small wave tile exists for the mixed blend only");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id: an SGPR
   bf16x8* sA = reinterpret_cast<bf16x8*>(smem_raw);
-  char* meta = smem_raw + 2 * 18 * 1024;
-  char* my = smem_raw + LBS3_SHARED_BYTES + wave * LBS3_WAVE_BYTES;
+  char* meta = smem_raw + lbs3_ring_bytes<NBW>();
+  char* my = meta + 7424 + wave * LBS3_WAVE_BYTES;
   LbsWave w;
   w.lane = lane; w.n = lane & 31; w.half = lane >> 5;
   w.s_W = reinterpret_cast<float*>(meta);                    // tile metadata is shared by the four waves here
@@ -1079,7 +1141,7 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
   auto run_item = [&](int vti, int bg) {
     [[maybe_unused]] const unsigned long long item_t0 = LBS_NOW();
     const int vt = p.tiles ? p.tiles[vti] : vti;
-    const int bt0 = bg * 8 + wave * NB;
+    const int bt0 = bg * (4 * NB) + wave * NB;   // a body group of this kernel = 4 waves x NB tiles of 32 bodies
     __syncthreads();  // previous item: every wave is done with the metadata and with the stage ring
     const int j_lo = p.tj_off[vt];
     const int JT = p.tj_off[vt + 1] - j_lo;
@@ -1109,9 +1171,11 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
         // the tiles that hold the PICKED vertices (markers, vertex joints, landmark corners: the 8 leading tiles of 328) keep the
         // two-plane split: what the environment reads as positions - and differentiates into directions (the eye landmarks are
         // centimetres apart and aim 7 m rays) - stays at the 1e-6 m level; the fp16 product only feeds the penetration COUNT
-        if (vti < p.n_precise) lbs_blend_split<2>(p, acc, vt, bt0, lane, wave, sA, tacc);
-        else lbs_blend_mixed(p, acc, vt, bt0, lane, wave, sA, tacc);
-      } else lbs_blend_split<NPL>(p, acc, vt, bt0, lane, wave, sA, tacc);
+        if (vti < p.n_precise) {
+          if constexpr (NBW == LBS_NB) lbs_blend_split<2>(p, acc, vt, bt0, lane, wave, sA, tacc);
+          else lbs_blend_split2_small<NB>(p, acc, vt, bt0, lane, wave, sA);
+        } else lbs_blend_mixed<NB>(p, acc, vt, bt0, lane, wave, sA, tacc);
+      } else if constexpr (NBW == LBS_NB) lbs_blend_split<NPL>(p, acc, vt, bt0, lane, wave, sA, tacc);
     } else __syncthreads();  // the blend's barriers also publish the metadata
     if (p.dbg & 1) {
       float sum = 0.f;
@@ -1124,7 +1188,7 @@ __global__ __launch_bounds__(256, 2) void egx_lbs_fused3_kernel(LbsParams p) {
       if (sum == 123.456f) p.pene[0] = 1;
       return;
     }
-    lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP>(p, w, acc, vt, bt0, JT);
+    lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP, NB>(p, w, acc, vt, bt0, JT);
 #ifdef EGX_LBS_TIMING
     w.et[4] += LBS_NOW() - item_t0; w.et[5] += 1;
 #endif
@@ -1987,6 +2051,8 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<2, false>), lds3a));
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<4, true>), lds3a));
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<4, false>), lds3a));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<4, true, 1>), lbs3_lds_bytes<1>()));
+        EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<4, false, 1>), lbs3_lds_bytes<1>()));
         di.num_cu = prop.multiProcessorCount;
       }
     }
@@ -2007,9 +2073,29 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     if (split3) {
       // two persistent 4-wave workgroups per CU: one's VALU epilogue runs under the other's MFMA stages
       constexpr size_t lds3 = (size_t)LBS3_SHARED_BYTES + 4 * LBS3_WAVE_BYTES;
-      int grid3 = std::max(1, std::min(2 * num_cu, n_items));
+      int wg_per_cu = 2;
+#ifdef EGX_LBS_DEVELOPMENT
+      if (const char* e = getenv("EGX_LBS_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));   // occupancy sensitivity (1 = one wave per SIMD)
+#endif
+      int grid3 = std::max(1, std::min(wg_per_cu * num_cu, n_items));
       if (grid3 >= 8) grid3 &= ~7;   // a multiple of 8: the kernel's XCD partition (body groups, or vertex tiles when groups are few)
-      if (mode == 3) {
+      // mixed blend without culling, launches of at most 20 body groups of 256 (<= 256 agents x 20 frames): the small wave tile
+      // (32 vertices x 32 bodies per wave, 128 bodies per workgroup item, three workgroups per CU) - finer items balance the
+      // XCDs better and a third wave per SIMD helps where the launch is short: 640 bodies 0.086 -> 0.073 ms, 1 280 0.150 -> 0.116,
+      // 2 560 0.250 -> 0.209, 5 120 0.461 -> 0.355; at 10 240 bodies the larger tile wins (0.686 against 0.734: the halved
+      // item repeats the bases traffic and the barriers), profiles/r05_lbs_mixed.md section 5.  EGX_LBS_WAVE_TILE=1 | 2 forces one.
+      static const int forced_tile = []() { const char* e = getenv("EGX_LBS_WAVE_TILE"); return e ? atoi(e) : 0; }();
+      const bool small_tile = forced_tile == 1 || (forced_tile != 2 && p.nbg <= 20);
+      if (mode == 3 && small_tile && !p.items) {
+        LbsParams q = p;
+        q.nbg = egx_ceil_div(B, 128);
+        q.bg_block = 2 * p.bg_block;
+        const int n_items1 = q.nbg * q.n_tiles;
+        int g1 = std::max(1, std::min(3 * num_cu, n_items1));
+        if (g1 >= 8) g1 &= ~7;
+        if (sdf) hipLaunchKernelGGL((egx_lbs_fused3_kernel<4, true, 1>), dim3(g1), dim3(256), lbs3_lds_bytes<1>(), stream, q);
+        else hipLaunchKernelGGL((egx_lbs_fused3_kernel<4, false, 1>), dim3(g1), dim3(256), lbs3_lds_bytes<1>(), stream, q);
+      } else if (mode == 3) {
         if (sdf) hipLaunchKernelGGL((egx_lbs_fused3_kernel<4, true>), dim3(grid3), dim3(256), lds3, stream, p);
         else hipLaunchKernelGGL((egx_lbs_fused3_kernel<4, false>), dim3(grid3), dim3(256), lds3, stream, p);
       } else if (mode == 2) {

@@ -12,7 +12,8 @@ h = BodyModelHandle(bm, synth.marker_ids(), synth.feet_vids())
 scene = SdfScene(synth.make_sdf_scene(256))
 lib0 = _lib.load()
 modes = [int(m) for m in os.environ.get("EGX_BENCH_MODES", "1,2,0").split(",")]
-for mode, A in [(m, a) for m in modes for a in (64, 512)]:
+agents = [int(a) for a in os.environ.get("EGX_BENCH_AGENTS", "64,512").split(",")]
+for mode, A in [(m, a) for m in modes for a in agents]:
     lib0.egx_lbs_set_blend_mode(mode)
     T = 20
     B = A * T
