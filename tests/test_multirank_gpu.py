@@ -127,11 +127,17 @@ def _single_process_reference(world, n_local, n_steps, n_learn):
     return pol, losses, grads
 
 
+_DP_RUNS = {}   # (world, n_local, n_steps, n_learn, overlap) -> per-rank results: tests that use the same two-rank run share ONE spawn
+
+
 def _run_dp(tmp_path, world, n_local, n_steps, n_learn, overlap=True):
-    out = str(tmp_path / f"dp{int(overlap)}.pt")
-    mp.spawn(_dp_worker, args=(world, 29500 + (os.getpid() + 311 * int(overlap)) % 2000, n_local, n_steps, n_learn, out, overlap),
-             nprocs=world, join=True)
-    return [torch.load(out + f".{r}") for r in range(world)]
+    key = (world, n_local, n_steps, n_learn, bool(overlap))
+    if key not in _DP_RUNS:
+        out = str(tmp_path / f"dp{int(overlap)}.pt")
+        mp.spawn(_dp_worker, args=(world, 29500 + (os.getpid() + 311 * int(overlap)) % 2000, n_local, n_steps, n_learn, out, overlap),
+                 nprocs=world, join=True)
+        _DP_RUNS[key] = [torch.load(out + f".{r}") for r in range(world)]
+    return _DP_RUNS[key]
 
 
 def test_bucketed_overlapped_all_reduce_equals_single_all_reduce(tmp_path):
