@@ -407,6 +407,7 @@ class OracleCrowdEnv:
             r_pene = torch.where(penetration, torch.zeros_like(num_pene), torch.full_like(num_pene, 0.05))
             weight_pene = cfg["weight_pene"]
             self.last["num_pene"] = num_pene
+            self.last["local_map"] = local_map
         else:
             weight_pene = 0.1 if self.finetuning else 1.0                 # :268-271
 

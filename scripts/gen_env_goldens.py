@@ -9,6 +9,8 @@
   models/baseops.py::SMPLXParser (forward_smplx / get_new_coordinate / update_transl_glorot / calc_calibrate_offset)
   models/models_GAMMA_primitive.py::GAMMAPrimitiveCombo.sample_prior                (the reference classes, seeded weights)
   crowd_ppo/ppo_policy.py::GAMMAPPOPolicy.learn (:182-265)                          -> ppo_learn_ref.npz  (`learn`)
+  crowd_ppo/crowd_env_crowd_eval.py::CrowdEnv (:44-454, :742-837) x 4 under crowd_ppo/dummy_vector_env.py::DummyCrowdVectorEnv,
+      bodies from environments.py::CrowdMotion.next_body (:1041-1157)               -> env_crowd_ref.npz  (`crowd`)
 
 What is substituted, and by what (the packages are absent from this image):
   smplx.create(...)                      -> adapter around oracle/smplx_lbs.py on the synthetic full-size body (V = 10 475)
@@ -18,6 +20,8 @@ What is substituted, and by what (the packages are absent from this image; SURVE
   CrowdEnv._calc_egosensing (shapely)    -> oracle/env.py::calc_egosensing (the only METHOD of the env that is replaced)
   trimesh.load / the navmesh             -> a (vertices, faces) namespace of the synthetic scene
   tianshou.policy.PPOPolicy / Batch / to_torch_as (learn only) -> a 40-line stand-in holding the attributes `learn` reads
+  shapely Polygon / union_all / Point (crowd only) -> RectPolygon: exact for the floor square + box holes that env builds
+  tianshou.env.DummyVectorEnv (crowd only) -> a stand-in whose workers step at `send`, like tianshou's DummyEnvWorker
   device spellings ('cuda', torch.cuda.FloatTensor, Tensor.cuda()) -> CPU
 The fixtures therefore pin the env / loss COMPOSITE's own arithmetic - reward block and its thresholds (40 vertices, 0.075,
 0.02, 11), termination, state / seed / frame bookkeeping, the sampler's rotations, the loss terms and the clip quirk - on top of
@@ -595,6 +599,249 @@ def gen_box():
     print("env_box_ref", os.path.getsize(os.path.join(OUT, "env_box_ref.npz")), "bytes")
 
 
+
+# ------------------------------------------------------------------------------------------------------------------
+class RectPolygon:
+    """The part of shapely.geometry.Polygon that crowd_env_crowd_eval.py touches (`:797-820`, `_get_dynamic_map :742-764`), for the
+    only geometry that env ever builds: an axis-aligned floor square with the other members' axis-aligned marker boxes as holes.
+    `contains(point)` follows shapely's definition - interior only: a point on the shell or on a hole's ring is NOT contained."""
+    is_valid = True
+
+    def __init__(self, shell, holes=None):
+        def rect(ring):
+            a = np.asarray(ring, np.float64).reshape(-1, 2)
+            lo, hi = a.min(0), a.max(0)
+            assert all(((abs(q[0] - lo[0]) < 1e-12) or (abs(q[0] - hi[0]) < 1e-12)) and ((abs(q[1] - lo[1]) < 1e-12) or (abs(q[1] - hi[1]) < 1e-12))
+                       for q in a), "not an axis-aligned rectangle"
+            return lo, hi
+        self.ring = [tuple(map(float, q)) for q in np.asarray(shell, np.float64).reshape(-1, 2)]
+        self.lo, self.hi = rect(shell)
+        self.hole_rects = [rect(h) for h in (holes or [])]
+        self.exterior = types.SimpleNamespace(coords=list(self.ring))
+
+    def contains(self, pt):
+        x, y = pt.xy
+        if not (self.lo[0] < x < self.hi[0] and self.lo[1] < y < self.hi[1]):
+            return False
+        return not any(lo[0] <= x <= hi[0] and lo[1] <= y <= hi[1] for lo, hi in self.hole_rects)
+
+    def edges(self):
+        """[E,4] segments of the shell and of every hole ring: what oracle.env.calc_egosensing casts its rays against."""
+        es = []
+        for lo, hi in [(self.lo, self.hi)] + self.hole_rects:
+            c = [(lo[0], lo[1]), (hi[0], lo[1]), (hi[0], hi[1]), (lo[0], hi[1])]
+            es += [[c[q][0], c[q][1], c[(q + 1) % 4][0], c[(q + 1) % 4][1]] for q in range(4)]
+        return np.asarray(es, np.float64)
+
+
+class RectMulti:
+    """shapely.geometry.MultiPolygon as `union_all` returns it for several boxes (`:798-802` only walks `.geoms[*].exterior`).  The
+    boxes are handed on un-merged: `Polygon(floor, holes).contains` subtracts each of them, which equals subtracting their union."""
+
+    def __init__(self, geoms):
+        self.geoms = list(geoms)
+
+
+class RectPoint:
+    def __init__(self, xy):
+        self.xy = (float(xy[0]), float(xy[1]))
+
+
+def install_crowd_shapely():
+    sh = sys.modules["shapely"]
+    geo = sys.modules["shapely.geometry"]
+    geo.Polygon, geo.Point, geo.MultiPolygon = RectPolygon, RectPoint, RectMulti
+    geo.MultiPoint = geo.LinearRing = geo.mapping = object
+    geo.multipolygon = types.SimpleNamespace(MultiPolygon=RectMulti)
+    geo.polygon = types.SimpleNamespace(Polygon=RectPolygon)
+    sh.geometry = geo
+    sh.union_all = lambda polys: polys[0] if len(polys) == 1 else RectMulti(polys)
+    sh.is_valid = lambda g: True
+    sh.LineString = object
+    pl = types.ModuleType("shapely.plotting")
+    pl.plot_polygon = lambda *a, **k: None
+    sys.modules["shapely.plotting"] = pl
+    sh.plotting = pl
+
+
+def install_vector_env_stub():
+    """tianshou.env.DummyVectorEnv as crowd_ppo/dummy_vector_env.py::DummyCrowdVectorEnv uses it (tianshou 0.5 venvs.py / worker
+    [upstream]): one DummyEnvWorker per env whose `send(action)` runs `env.step` at once and whose `recv()` hands the result back -
+    which is what makes the reference's `for i, j in enumerate(id): update_holes...; workers[j].send(action[i])` loop sequential."""
+    class Worker:
+        def __init__(self, fn):
+            self.env, self.result = fn(), None
+
+        def send(self, action):
+            self.result = self.env.reset() if action is None else self.env.step(action)
+
+        def recv(self):
+            return list(self.result)
+
+    class DummyVectorEnv:
+        def __init__(self, env_fns, **kw):
+            self._env_fns = env_fns
+            self.workers = [Worker(fn) for fn in env_fns]
+            self.env_num, self.is_async, self.is_closed = len(env_fns), False, False
+
+        def _assert_is_not_closed(self):
+            assert not self.is_closed
+
+        def _wrap_id(self, id=None):
+            return list(range(self.env_num)) if id is None else ([id] if np.isscalar(id) else list(id))
+
+        def get_env_attr(self, key, id=None):
+            return [getattr(self.workers[j].env, key) for j in self._wrap_id(id)]
+
+        def set_env_attr(self, key, value, id=None):
+            for j in self._wrap_id(id):
+                setattr(self.workers[j].env, key, value)
+
+        def reset(self, id=None):
+            return [self.workers[j].env.reset() for j in self._wrap_id(id)]
+    te = types.ModuleType("tianshou.env")
+    te.DummyVectorEnv = DummyVectorEnv
+    tu = types.ModuleType("tianshou.env.utils")
+    tu.ENV_TYPE, tu.gym_new_venv_step_type = object, tuple
+    tw = types.ModuleType("tianshou.env.worker")
+    tw.DummyEnvWorker = tw.EnvWorker = tw.RayEnvWorker = tw.SubprocEnvWorker = Worker
+    ts = sys.modules.get("tianshou") or types.ModuleType("tianshou")
+    ts.env = te
+    sys.modules.update({"tianshou": ts, "tianshou.env": te, "tianshou.env.utils": tu, "tianshou.env.worker": tw})
+
+
+def crowd_ego_hook(self, joint):
+    """Stands in for crowd_env_crowd_eval.CrowdEnv._calc_egosensing (shapely ray casting, identical to crowd_env_2f's): the rays are
+    cast against the rings of the polygon `_get_feature` has just built (floor + the holes this member sees NOW); snapshots the
+    caller's locals like ego_hook, plus the holes."""
+    from oracle.env import calc_egosensing
+    fr = sys._getframe(1)
+    if fr.f_code.co_name == "step":
+        _STEP_LOCALS.clear()
+        _STEP_LOCALS.update(fr.f_locals)
+        _STEP_LOCALS["holes_seen"] = np.asarray(self.holes, np.float64).copy()
+    return calc_egosensing(joint, self.scene_poly.edges()).float()
+
+
+def gen_crowd():
+    """BASELINE config 5's plumbing, executed: four `crowd_env_crowd_eval.CrowdEnv` members (constructor box `:54-75`, `reset
+    :384-454`, `step :102-382` with `_get_feature :766-837` / `_get_dynamic_map :742-764`) built from `CrowdMotion.next_body`
+    (`environments.py:1041-1157`) and driven through the reference's own `DummyCrowdVectorEnv` (`dummy_vector_env.py:29-128`: the
+    holes of every member are refreshed before EACH member's step).  -> tests/golden/env_crowd_ref.npz"""
+    from egogen_amd import synth
+    from tests.helpers import seeded_vposer_state_dict
+    rec = {}
+    install(rec)
+    install_crowd_shapely()
+    install_vector_env_stub()
+    cwd = os.getcwd()
+    os.chdir(REF)
+    reference_first()
+    try:
+        with cpu_world():
+            from crowd_ppo import crowd_env_crowd_eval as cc
+            from crowd_ppo.dummy_vector_env import DummyCrowdVectorEnv
+            from exp_GAMMAPrimitive.utils import environments as envs
+            from models import baseops, models_GAMMA_primitive as mgp
+            cfg = AttrDict(load_yaml("MPVAEPolicy_samp_collision_2.yaml"))      # main_crowd_eval.py:224 load_model(box=True)
+            cfg["args"] = {"gpu_index": 0}
+            bm, (p1, p2, pmp) = body_and_parsers(baseops, sys.modules["smplx"])
+            fmi, markers = feet_marker_idx_and_markers()
+            genop = build_combo(mgp)
+            vsd = {k: v.float() for k, v in seeded_vposer_state_dict().items()}
+            sampler = object.__new__(envs.CrowdMotion)
+            sampler.bm_male = sampler.bm_female = FakeSMPLX(bm, 2)
+            motion = np.load(os.path.join(REF, "data", "locomotion", "subseq_00343.npz"))
+            cc.CrowdEnv._calc_egosensing = crowd_ego_hook
+            G = 4
+            out = {"body_model_seed": np.int64(0), "prior_seed": np.int64(PRIOR_SEED), "prior_gains": np.asarray(PRIOR_GAINS, np.float64),
+                   "G": np.int64(G)}
+            cases = []
+
+            def run_case(name, radius, phase, n_rounds, seed):
+                # main_crowd_eval.py:276-283: four points on a circle, every member walks to the opposite one
+                t = np.linspace(phase, phase + 2 * np.pi, G, endpoint=False)
+                pts = np.zeros((G, 3))
+                pts[:, 0], pts[:, 1] = radius * np.cos(t), radius * np.sin(t)
+                start_target = [(pts[k], pts[(k + 2) % G]) for k in range(G)]
+                torch.manual_seed(seed)
+                rec["euler_z"] = []
+                datas = sampler.next_body(start_target=start_target, fixed_seed=True, num_agents=G)
+                pre = f"{name}_"
+                c = {pre + "start_target": np.asarray(start_target, np.float32)}
+                for k, d in enumerate(datas):
+                    bp = t2n(d["motion_seed"]["body_pose"])
+                    start = [s_ for s_ in range(len(motion["poses"]) - 1) if np.allclose(motion["poses"][s_:s_ + 2, 3:66], bp, atol=1e-6)]
+                    assert len(start) == 1
+                    c[f"{pre}m{k}_start_frame"] = np.int64(start[0])
+                    c[f"{pre}m{k}_yaw_jitter"] = np.float64(rec["euler_z"][k])
+                    c[f"{pre}m{k}_transl"], c[f"{pre}m{k}_glorot"] = t2n(d["motion_seed"]["transl"]), t2n(d["motion_seed"]["global_orient"])
+                    c[f"{pre}m{k}_wpath"] = t2n(d["wpath"])
+                assert len(rec["euler_z"]) == G
+                members = [cc.CrowdEnv([cfg, genop, genop, "data/smplx/models", datas[k], p1, p2, pmp, fmi, markers, FakeVPoser(vsd), str(k), name],
+                                       save_rollout=False, render=False) for k in range(G)]
+                for k, m in enumerate(members):
+                    c[f"{pre}m{k}_init_bbox"] = np.asarray(m.bbox, np.float64)
+                venv = DummyCrowdVectorEnv([(lambda m=m: m) for m in members])
+                for k, m in enumerate(members):
+                    c[f"{pre}m{k}_init_holes"] = np.asarray(m.holes, np.float64)
+                obs = venv.reset()
+                for k, (o, _) in enumerate(obs):
+                    m = members[k]
+                    c.update({f"{pre}m{k}_reset_obs_state": t2n(o["state"]), f"{pre}m{k}_reset_obs_ego": t2n(o["egosensing"]),
+                              f"{pre}m{k}_reset_obs_dist": t2n(o["dist"]).reshape(-1), f"{pre}m{k}_reset_obs_time": t2n(o["time"]).reshape(-1),
+                              f"{pre}m{k}_betas": t2n(m.betas).reshape(-1)})
+                    c.update(record_state(m, f"{pre}m{k}_reset_"))
+                g = torch.Generator().manual_seed(seed + 1000)
+                zs = torch.randn(n_rounds, G, 128, generator=g)
+                c[pre + "z"] = t2n(zs)
+                # the reference's vector step, with the members' step wrapped so that each one's locals are kept
+                caught = {}
+                for k, m in enumerate(members):
+                    def wrapped(action, m=m, k=k, orig=m.step):
+                        _STEP_LOCALS.clear()
+                        ret = orig(action)
+                        caught[k] = (ret, dict(_STEP_LOCALS))
+                        return ret
+                    m.step = wrapped
+                alive = True
+                for r in range(n_rounds):
+                    caught.clear()
+                    o_, rew_, term_, trunc_, info_ = venv.step(t2n(zs[r]))
+                    for k in range(G):
+                        ret, loc = caught[k]
+                        sp = f"{pre}r{r}_m{k}_"
+                        c.update(record_step(ret, loc, members[k], sp, box=True))
+                        c[sp + "holes_seen"] = loc["holes_seen"]
+                        c[sp + "bbox_after"] = np.asarray(members[k].bbox, np.float64)
+                        c[sp + "local_map"] = t2n(loc["local_map"][0])
+                        assert float(rew_[k]) == float(ret[1]) and bool(term_[k]) == bool(ret[2])
+                    if term_.any():
+                        alive = False
+                        c[pre + "n_rounds"] = np.int64(r + 1)
+                        break
+                if alive:
+                    c[pre + "n_rounds"] = np.int64(n_rounds)
+                cases.append(name)
+                out.update(c)
+
+            run_case("ring", 1.2, 0.3, 2, 31)       # close: rays hit the others' boxes, marker boxes overlap walk-map cells late
+            run_case("tight", 0.55, 1.1, 2, 57)     # shoulder to shoulder: the others' boxes cover cells of the local map
+            out["cases"] = np.array(cases)
+            out["cfg_json"] = np.array(json.dumps({k: cfg[k] for k in ("modelconfig", "lossconfig", "trainconfig")}))
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "env_crowd_ref.npz"), **out)
+    for name in cases:
+        for r in range(int(out[name + "_n_rounds"])):
+            for k in range(G):
+                sp = f"{name}_r{r}_m{k}_"
+                print(f"{name:6s} round {r} member {k} reward {float(out[sp + 'reward']):+.4f} term {bool(out[sp + 'terminated'])} "
+                      f"num_pene {float(out[sp + 'num_pene'])} r_pene {float(out[sp + 'r_pene'])} ego min {float(out[sp + 'obs_ego'].min()):+.3f} "
+                      f"map -1 cells {int((out[sp + 'local_map'] < 0).sum())}")
+    print("env_crowd_ref", os.path.getsize(os.path.join(OUT, "env_crowd_ref.npz")), "bytes")
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def install_tianshou_stub(record):
     """The attributes of tianshou 0.5 that GAMMAPPOPolicy.__init__ / learn read (policy/base.py, modelfree/pg.py, a2c.py, ppo.py,
@@ -740,4 +987,4 @@ def gen_learn():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sdf"]
     for w in which:
-        {"sdf": gen_sdf, "box": gen_box, "learn": gen_learn}[w]()
+        {"sdf": gen_sdf, "box": gen_box, "learn": gen_learn, "crowd": gen_crowd}[w]()

@@ -414,3 +414,142 @@ def test_hip_box_env_matches_reference_execution(box_world, case):
                "after_seed": env.seed[0].cpu(), "after_R0": env.R0[0], "after_T0": env.T0[0].cpu(), "after_dist": env.dist.cpu(),
                "obs_ego": obs["egosensing"][0], "obs_dist": obs["dist"].cpu(), "obs_time": obs["time"].cpu()}
         _check_step_common(g, sp, got)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5's plumbing (main_crowd_eval.py): tests/golden/env_crowd_ref.npz = four crowd_env_crowd_eval.CrowdEnv members
+# built from CrowdMotion.next_body and driven through the reference's OWN DummyCrowdVectorEnv (scripts/gen_env_goldens.py crowd):
+# constructor boxes, holes, reset observations, and per round and member the holes it saw, the walkability map, the step's
+# quantities and the box it published.
+CROWD_CASES = ["ring", "tight"]
+
+
+@pytest.fixture(scope="module")
+def crowd_world():
+    from egogen_amd import synth
+    g = load_golden("env_crowd_ref.npz")
+    return {"g": g, "bm": synth.make_body_model(0), "mk": synth.marker_ids(), "feet": synth.feet_vids(), "fmi": synth.feet_marker_idx(),
+            "prior_sd": seeded_prior_state_dict(int(g["prior_seed"]), *[float(v) for v in g["prior_gains"]]),
+            "cfg": json.loads(str(g["cfg_json"])), "G": int(g["G"])}
+
+
+def _ring_box(ring):
+    """the reference's 5-point box ring(s) [..., 5, 2] -> (minx, miny, maxx, maxy)"""
+    r = np.asarray(ring, np.float64)
+    return np.concatenate([r.min(-2), r.max(-2)], -1)
+
+
+def _others(boxes, k):
+    return np.stack([boxes[j] for j in range(len(boxes)) if j != k])[None]      # [S=1, G-1, 4]
+
+
+@pytest.mark.parametrize("case", CROWD_CASES)
+def test_oracle_crowd_env_matches_reference_execution(crowd_world, case):
+    """Four oracle members run their OWN state from the recorded sampler inputs; each sees the others' boxes as they stand when it
+    steps (members 0..k-1 of this round, k+1.. of the previous one) - the ordering the reference's vector env produced."""
+    from oracle.env import OracleCrowdEnv
+    from oracle.smplx_lbs import BodyModel
+    w = crowd_world
+    g, G = w["g"], w["G"]
+    pre = case + "_"
+    st = g[pre + "start_target"]                                       # [G,2,3]
+    ms, boxes = [], np.zeros((G, 4))
+    for k in range(G):
+        o = OracleCrowdEnv(BodyModel(w["bm"]), w["prior_sd"], _vposer_sd(1.0), w["mk"], w["feet"], w["fmi"], scene_kind="crowd")
+        c = w["cfg"]
+        assert o.cfg["pene_type"] == c["lossconfig"]["pene_type"] and o.cfg["pene_thres"] == c["trainconfig"]["pene_thres"]
+        assert o.cfg["max_depth"] == c["trainconfig"]["max_depth"] and o.cfg["map_res"] == c["modelconfig"]["map_res"]
+        mp = f"{pre}m{k}_"
+        poses, trans, betas = _motion_seed(int(g[mp + "start_frame"]))
+        tr, go, bp, wpath = o.next_body(torch.as_tensor(st[k, 0:1]), torch.as_tensor(st[k, 1:2]), poses, trans, betas,
+                                        yaw_jitter=torch.tensor([float(g[mp + "yaw_jitter"])]))
+        _close(tr[0], g[mp + "transl"], "m", mp + "sampler transl")
+        _aa_close(go[0], g[mp + "glorot"], mp + "sampler glorot")
+        _close(wpath[0], g[mp + "wpath"], "m", mp + "sampler wpath")
+        o.set_crowd_boxes(np.zeros((1, G - 1, 4)))
+        o.reset_from(tr, go, bp, betas, wpath)
+        boxes[k] = o.own_bbox().numpy()[0]
+        _close(boxes[k], _ring_box(g[mp + "init_bbox"]), "m", mp + "constructor box")
+        ms.append((o, (tr, go, bp, betas, wpath)))
+    for k, (o, args) in enumerate(ms):       # DummyCrowdVectorEnv.__init__ hands every member the others' boxes, THEN reset()
+        mp = f"{pre}m{k}_"
+        _close(_others(boxes, k)[0], _ring_box(g[mp + "init_holes"]), "m", mp + "initial holes")
+        o.set_crowd_boxes(_others(boxes, k))
+        obs, _ = o.reset_from(*args)
+        _close(o.state[0], g[mp + "reset_state"], "unit", mp + "reset state")
+        _close(o.R0[0], g[mp + "reset_R0"], "unit", mp + "reset R0")
+        _close(o.T0[0].reshape(-1), g[mp + "reset_T0"].reshape(-1), "m", mp + "reset T0")
+        _close(o.dist, g[mp + "reset_dist"], "m", mp + "reset dist")
+        _close(obs["egosensing"][0], g[mp + "reset_obs_ego"], "ego", mp + "reset egosensing")
+        _close(obs["dist"].reshape(-1), g[mp + "reset_obs_dist"], "unit", mp + "reset obs dist")
+    saw_cells = 0
+    for r in range(int(g[pre + "n_rounds"])):
+        for k, (o, _) in enumerate(ms):
+            sp = f"{pre}r{r}_m{k}_"
+            _close(_others(boxes, k)[0], _ring_box(g[sp + "holes_seen"]), "m", sp + "holes at step time")
+            o.set_crowd_boxes(_others(boxes, k))
+            obs, rew, term = o.step(torch.as_tensor(g[pre + "z"][r, k])[None])
+            _check_step_common(g, sp, _box_got(o.last, rew, term, o, obs))
+            assert np.array_equal(o.last["local_map"][0].numpy(), g[sp + "local_map"]), sp + "walkability map"
+            assert float(o.last["num_pene"][0]) == float(g[sp + "num_pene"])
+            assert bool(o.last["penetration"][0]) == bool(g[sp + "penetration"])
+            boxes[k] = o.own_bbox().numpy()[0]
+            _close(boxes[k], _ring_box(g[sp + "bbox_after"]), "m", sp + "published box")
+            saw_cells += int((g[sp + "local_map"] < 0).sum())
+    assert saw_cells > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CROWD_CASES)
+def test_hip_crowd_group_matches_reference_execution(crowd_world, case):
+    """CrowdGroupEnv (the product's DummyCrowdVectorEnv + crowd_env_crowd_eval.CrowdEnv, S = 1 scene of G = 4 members) through the
+    C ABI against the same recording: reset sequence, then `step` of the whole group per round."""
+    from egogen_amd.body_model import BodyModelHandle
+    from egogen_amd.crowd_env import CrowdGroupEnv
+    from egogen_amd.models import GAMMAPrimitiveCombo, PREDICTOR_CFG, REGRESSOR_CFG, VPoserEncoder
+    w = crowd_world
+    g, G = w["g"], w["G"]
+    pre = case + "_"
+    h = BodyModelHandle(w["bm"], w["mk"], w["feet"])
+    combo = GAMMAPrimitiveCombo(PREDICTOR_CFG, REGRESSOR_CFG)
+    combo.load_state_dict(w["prior_sd"])
+    combo.cuda().eval()
+    vp = VPoserEncoder()
+    vp.load_state_dict(seeded_vposer_state_dict())
+    vp.cuda().eval()
+    st = g[pre + "start_target"].reshape(G, 1, 2, 3)
+    grp = CrowdGroupEnv(1, st, h, combo, vp, seed=0)
+    for k, m in enumerate(grp.members):
+        mp = f"{pre}m{k}_"
+        variant = np.array([m.variant_starts.index(int(g[mp + "start_frame"]))])
+        m.set_candidates(st[k].reshape(1, 1, 2, 3), np.array([float(g[mp + "yaw_jitter"])], np.float32), variant)
+        m._launch_reset(None)                    # publishes the constructor box (CrowdGroupEnv.reset's first pass)
+    for k, m in enumerate(grp.members):
+        mp = f"{pre}m{k}_"
+        _close(grp.bbox[k, 0], _ring_box(g[mp + "init_bbox"]), "m", mp + "constructor box")
+    for k, m in enumerate(grp.members):
+        mp = f"{pre}m{k}_"
+        m._launch_reset(None)                    # second pass: the observation sees every member's box
+        obs = m.obs()
+        _close(m.wpath[0], g[mp + "reset_wpath"], "m", mp + "wpath")
+        _close(m.state[0], g[mp + "reset_state"], "unit", mp + "reset state")
+        _close(m.R0[0], g[mp + "reset_R0"], "unit", mp + "reset R0")
+        _close(m.T0[0], g[mp + "reset_T0"].reshape(-1), "m", mp + "reset T0")
+        _close(m.dist, g[mp + "reset_dist"], "m", mp + "reset dist")
+        _close(obs["egosensing"][0], g[mp + "reset_obs_ego"], "ego", mp + "reset egosensing")
+        _close(obs["dist"].reshape(-1), g[mp + "reset_obs_dist"], "unit", mp + "reset obs dist")
+    for r in range(int(g[pre + "n_rounds"])):
+        z = torch.as_tensor(g[pre + "z"][r]).cuda()
+        # the group's own loop (CrowdGroupEnv.step), member by member so that each member's buffers can be read before the next one
+        # overwrites the shared box table
+        for k, m in enumerate(grp.members):
+            sp = f"{pre}r{r}_m{k}_"
+            obs, rew, term = m.step(z[k:k + 1].contiguous(), auto_reset=False)
+            rt = m.rterms[0].cpu().numpy()
+            got = {"Y_gen": m.Y_gen.reshape(-1, 201), "pred_params": m.pred_params.reshape(20, 93), "joints": m.joints.reshape(20, -1, 3),
+                   "r_skate": rt[0], "r_floor": rt[1], "r_face_target": rt[2], "r_look_target": rt[3], "r_goal": rt[4], "r_target_dist": rt[5],
+                   "r_pene": rt[6], "r_vp": rt[7], "reward": rew[0], "terminated": term[0], "after_state": m.state[0],
+                   "after_seed": m.seed[0].cpu(), "after_R0": m.R0[0], "after_T0": m.T0[0].cpu(), "after_dist": m.dist.cpu(),
+                   "obs_ego": obs["egosensing"][0], "obs_dist": obs["dist"].cpu(), "obs_time": obs["time"].cpu()}
+            _check_step_common(g, sp, got)
+            _close(grp.bbox[k, 0], _ring_box(g[sp + "bbox_after"]), "m", sp + "published box")
