@@ -11,6 +11,7 @@
   crowd_ppo/ppo_policy.py::GAMMAPPOPolicy.learn (:182-265)                          -> ppo_learn_ref.npz  (`learn`)
   crowd_ppo/crowd_env_crowd_eval.py::CrowdEnv (:44-454, :742-837) x 4 under crowd_ppo/dummy_vector_env.py::DummyCrowdVectorEnv,
       bodies from environments.py::CrowdMotion.next_body (:1041-1157)               -> env_crowd_ref.npz  (`crowd`)
+  vis.py::rollout_primitives (:44-78)                                                -> rollout_prims_ref.npz (`rollout`)
 
 What is substituted, and by what (the packages are absent from this image):
   smplx.create(...)                      -> adapter around oracle/smplx_lbs.py on the synthetic full-size body (V = 10 475)
@@ -842,6 +843,60 @@ def gen_crowd():
     print("env_crowd_ref", os.path.getsize(os.path.join(OUT, "env_crowd_ref.npz")), "bytes")
 
 
+
+# ------------------------------------------------------------------------------------------------------------------
+def gen_rollout():
+    """motion/vis.py::rollout_primitives (:44-78; the same function in vis_crowd.py:43 and experiments/gen_egobody_depth.py:27-61),
+    EXECUTED on a seeded motion list of the `log/eval_results/motion_*.pkl` form (three primitives: first, '2-frame', '1-frame').
+    smplx.create -> FakeSMPLX (the function only reads the rest-pose pelvis of the primitive's betas from it); trimesh / pyrender /
+    tqdm are imported by the module and unused by the function.  -> tests/golden/rollout_prims_ref.npz"""
+    from scipy.spatial.transform import Rotation
+    rec = {}
+    install(rec)
+    for name in ("tqdm",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    cwd = os.getcwd()
+    os.chdir(REF)
+    reference_first()
+    try:
+        with cpu_world():
+            from egogen_amd import synth
+            from oracle.smplx_lbs import BodyModel
+            bm = BodyModel(synth.make_body_model(0))
+            sys.modules["smplx"].create = lambda *a, batch_size=1, **k: FakeSMPLX(bm, batch_size)
+            # vis.py is a script (it parses arguments and opens a viewer at import): its head - the imports and the function, up
+            # to the next top-level `def` - is executed as it stands; `model_path` is the global its tail would have set (:417)
+            src = open(os.path.join(REF, "vis.py")).read()
+            head = src[:src.index("\ndef vis_results_new(")]
+            assert "def rollout_primitives(motion_primitives):" in head
+            ns = {"__name__": "vis_head", "model_path": "data/smplx/models"}
+            exec(compile(head, os.path.join(REF, "vis.py"), "exec"), ns)
+            vis = types.SimpleNamespace(rollout_primitives=ns["rollout_primitives"])
+            g = torch.Generator().manual_seed(808)
+            betas = torch.randn(10, generator=g).numpy()
+            mps = []
+            for i, kind in enumerate(("2-frame", "2-frame", "1-frame")):
+                xb = torch.zeros(20, 93)
+                xb[:, :3] = torch.randn(20, 3, generator=g) * 0.5
+                xb[:, 3:6] = torch.randn(20, 3, generator=g) * 0.7
+                xb[:, 6:69] = torch.randn(20, 63, generator=g) * 0.2
+                xb[:, 69:] = torch.randn(20, 24, generator=g) * 0.3
+                R = Rotation.from_euler("zyx", (torch.rand(3, generator=g).numpy() - 0.5) * [6.0, 0.4, 0.4]).as_matrix().astype(np.float32)
+                mps.append({"smplx_params": xb[None].numpy(), "betas": betas, "gender": "male", "transf_rotmat": R,
+                            "transf_transl": (torch.randn(1, 3, generator=g) * 2).numpy(), "mp_type": kind})
+            out = {"n": np.int64(len(mps)), "betas": betas, "body_model_seed": np.int64(0)}
+            for i, mp in enumerate(mps):
+                out[f"p{i}_smplx_params"], out[f"p{i}_rotmat"], out[f"p{i}_transl"] = mp["smplx_params"].copy(), mp["transf_rotmat"], mp["transf_transl"]
+                out[f"p{i}_mp_type"] = np.array(mp["mp_type"])
+            import copy
+            seq = vis.rollout_primitives(copy.deepcopy(mps))       # (it rewrites the primitives' parameter rows in place)
+            out["sequence"] = np.asarray(seq, np.float64)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "rollout_prims_ref.npz"), **out)
+    print("rollout_prims_ref", out["sequence"].shape, os.path.getsize(os.path.join(OUT, "rollout_prims_ref.npz")), "bytes")
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def install_tianshou_stub(record):
     """The attributes of tianshou 0.5 that GAMMAPPOPolicy.__init__ / learn read (policy/base.py, modelfree/pg.py, a2c.py, ppo.py,
@@ -987,4 +1042,4 @@ def gen_learn():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sdf"]
     for w in which:
-        {"sdf": gen_sdf, "box": gen_box, "learn": gen_learn, "crowd": gen_crowd}[w]()
+        {"sdf": gen_sdf, "box": gen_box, "learn": gen_learn, "crowd": gen_crowd, "rollout": gen_rollout}[w]()

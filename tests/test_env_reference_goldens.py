@@ -553,3 +553,44 @@ def test_hip_crowd_group_matches_reference_execution(crowd_world, case):
                    "obs_ego": obs["egosensing"][0], "obs_dist": obs["dist"].cpu(), "obs_time": obs["time"].cpu()}
             _check_step_common(g, sp, got)
             _close(grp.bbox[k, 0], _ring_box(g[sp + "bbox_after"]), "m", sp + "published box")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# vis.py::rollout_primitives (:44-78), executed on a seeded motion list (scripts/gen_env_goldens.py rollout)
+def _rollout_fixture():
+    g = load_golden("rollout_prims_ref.npz")
+    mps = [{"smplx_params": g[f"p{i}_smplx_params"].copy(), "betas": g["betas"], "gender": "male", "transf_rotmat": g[f"p{i}_rotmat"],
+            "transf_transl": g[f"p{i}_transl"], "mp_type": str(g[f"p{i}_mp_type"])} for i in range(int(g["n"]))]
+    return g, mps
+
+
+def _check_rollout(got, ref):
+    from scipy.spatial.transform import Rotation
+    assert got.shape == ref.shape
+    _close(got[:, :3], ref[:, :3], "m", "rolled-out transl")
+    _close(Rotation.from_rotvec(got[:, 3:6]).as_matrix(), Rotation.from_rotvec(ref[:, 3:6]).as_matrix(), "unit", "rolled-out glorot")
+    assert np.array_equal(np.asarray(got[:, 6:], np.float32), np.asarray(ref[:, 6:], np.float32))
+
+
+def test_oracle_rollout_primitives_matches_reference_execution():
+    from egogen_amd import synth
+    from oracle.rollout import rollout_primitives
+    from oracle.smplx_lbs import BodyModel, smplx_forward
+    g, mps = _rollout_fixture()
+    ob = BodyModel(synth.make_body_model(int(g["body_model_seed"])))
+
+    def pelvis_of(b):
+        _, j = smplx_forward(ob, torch.zeros(1, 93), torch.as_tensor(b).reshape(1, 10).float())
+        return j[0, 0].numpy()
+    assert g["sequence"].shape == (20 + 18 + 19, 93)        # first primitive whole, a '2-frame' one drops two rows, a '1-frame' one
+    _check_rollout(rollout_primitives(mps, pelvis_of), g["sequence"])
+
+
+@pytest.mark.gpu
+def test_hip_rollout_primitives_matches_reference_execution():
+    from egogen_amd import synth
+    from egogen_amd.body_model import BodyModelHandle
+    from egogen_amd.utils import rollout_primitives
+    g, mps = _rollout_fixture()
+    h = BodyModelHandle(synth.make_body_model(int(g["body_model_seed"])), synth.marker_ids(), synth.feet_vids())
+    _check_rollout(rollout_primitives(mps, h), g["sequence"])
