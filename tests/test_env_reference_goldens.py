@@ -594,3 +594,136 @@ def test_hip_rollout_primitives_matches_reference_execution():
     g, mps = _rollout_fixture()
     h = BodyModelHandle(synth.make_body_model(int(g["body_model_seed"])), synth.marker_ids(), synth.feet_vids())
     _check_rollout(rollout_primitives(mps, h), g["sequence"])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The EgoBody evaluation (main_egobody_eval.py): tests/golden/env_egobody_ref.npz = two crowd_env_egobody_eval.CrowdEnv members built
+# from Egobody.gen_init_body inside the walkable region of the in-tree room_0 navmesh, under the reference's DummyCrowdVectorEnv
+# (scripts/gen_env_goldens.py egobody).  Cases: two clean rounds; a pose the filter at 14 rejects (`exit(-1)`, :229-234); a pelvis
+# that leaves the region within the first five steps (`exit(-1)`, :208-216).  The fixture cannot pin what shapely does with
+# `Polygon(polygon, holes)` (:824) - the generator's stand-in ASSUMES it returns the polygon (static scene), like the oracle.
+EGO_CASES = ["pair", "pose", "pelvis"]
+_EXIT_FLAG = {"invalid pelvis location": 1, "unrealistic pose": 2}
+
+
+@pytest.fixture(scope="module")
+def ego_world():
+    from egogen_amd import synth
+    g = load_golden("env_egobody_ref.npz")
+    rings = [g[f"ring{i}"] for i in range(int(g["n_rings"]))]
+    return {"g": g, "bm": synth.make_body_model(0), "mk": synth.marker_ids(), "feet": synth.feet_vids(), "fmi": synth.feet_marker_idx(),
+            "prior_sd": seeded_prior_state_dict(int(g["prior_seed"]), *[float(v) for v in g["prior_gains"]]), "rings": rings}
+
+
+def _ego_seed(g, mp):
+    poses, trans, _ = _motion_seed(int(g[mp + "start_frame"]))
+    return poses, trans, torch.as_tensor(g[mp + "betas"], dtype=torch.float32).reshape(1, 10)
+
+
+@pytest.mark.parametrize("case", EGO_CASES)
+def test_oracle_egobody_env_matches_reference_execution(ego_world, case):
+    from egogen_amd import synth
+    from oracle.env import OracleCrowdEnv
+    from oracle.smplx_lbs import BodyModel
+    w = ego_world
+    g, G = w["g"], 2
+    pre = case + "_"
+    st = g[pre + "start_target"]
+    edges = synth.rings_to_edges(w["rings"])
+    ms, boxes = [], np.zeros((G, 4))
+    for k in range(G):
+        o = OracleCrowdEnv(BodyModel(w["bm"]), w["prior_sd"], _vposer_sd(float(g[pre + "vposer_gain"])), w["mk"], w["feet"], w["fmi"],
+                           scene_kind="crowd")
+        o.set_egobody(edges, static=True, vp_thresh=14.0)
+        mp = f"{pre}m{k}_"
+        poses, trans, betas = _ego_seed(g, mp)
+        tr, go, bp, wpath = o.next_body(torch.as_tensor(st[k, 0:1]), torch.as_tensor(st[k, 1:2]), poses, trans, betas,
+                                        yaw_jitter=torch.tensor([float(g[mp + "yaw_jitter"])]))
+        _close(tr[0], g[mp + "transl"], "m", mp + "sampler transl")
+        _aa_close(go[0], g[mp + "glorot"], mp + "sampler glorot")
+        _close(wpath[0], g[mp + "wpath"], "m", mp + "sampler wpath")
+        o.set_crowd_boxes(np.zeros((1, G - 1, 4)))
+        obs, _ = o.reset_from(tr, go, bp, betas, wpath)
+        boxes[k] = o.own_bbox().numpy()[0]
+        _close(boxes[k], _ring_box(g[mp + "init_bbox"]), "m", mp + "constructor box")
+        _close(o.state[0], g[mp + "reset_state"], "unit", mp + "reset state")
+        _close(o.T0[0].reshape(-1), g[mp + "reset_T0"].reshape(-1), "m", mp + "reset T0")
+        _close(obs["egosensing"][0], g[mp + "reset_obs_ego"], "ego", mp + "reset egosensing")     # static scene: nobody else in it
+        _close(obs["dist"].reshape(-1), g[mp + "reset_obs_dist"], "unit", mp + "reset obs dist")
+        ms.append(o)
+    ex_r, ex_k = int(g[pre + "exit_round"]), int(g[pre + "exit_member"])
+    n_rounds = ex_r + 1 if ex_r >= 0 else int(g[pre + "n_rounds"])
+    for r in range(n_rounds):
+        for k, o in enumerate(ms):
+            sp = f"{pre}r{r}_m{k}_"
+            o.set_crowd_boxes(_others(boxes, k))
+            obs, rew, term = o.step(torch.as_tensor(g[pre + "z"][r, k])[None])
+            if (r, k) == (ex_r, ex_k):      # the reference left the process here
+                assert int(o.last["invalid"][0]) & _EXIT_FLAG[str(g[pre + "exit_reason"])], (sp, int(o.last["invalid"][0]))
+                return
+            assert int(o.last["invalid"][0]) == 0, sp
+            _close(_others(boxes, k)[0], _ring_box(g[sp + "holes_seen"]), "m", sp + "holes at step time")
+            _check_step_common(g, sp, _box_got(o.last, rew, term, o, obs))
+            assert np.array_equal(o.last["local_map"][0].numpy(), g[sp + "local_map"]), sp + "walkability map"
+            assert float(o.last["num_pene"][0]) == float(g[sp + "num_pene"]) and not bool(g[sp + "terminated"])
+            boxes[k] = o.own_bbox().numpy()[0]
+            _close(boxes[k], _ring_box(g[sp + "bbox_after"]), "m", sp + "published box")
+    assert ex_r < 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", EGO_CASES)
+def test_hip_egobody_group_matches_reference_execution(ego_world, case):
+    from egogen_amd.body_model import BodyModelHandle
+    from egogen_amd.crowd_env import CrowdGroupEnv
+    from egogen_amd.models import GAMMAPrimitiveCombo, PREDICTOR_CFG, REGRESSOR_CFG, VPoserEncoder
+    w = ego_world
+    g, G = w["g"], 2
+    pre = case + "_"
+    h = BodyModelHandle(w["bm"], w["mk"], w["feet"])
+    combo = GAMMAPrimitiveCombo(PREDICTOR_CFG, REGRESSOR_CFG)
+    combo.load_state_dict(w["prior_sd"])
+    combo.cuda().eval()
+    vp = VPoserEncoder()
+    vp.load_state_dict({k: v for k, v in _vposer_sd(float(g[pre + "vposer_gain"])).items()})
+    vp.cuda().eval()
+    st = g[pre + "start_target"].reshape(G, 1, 2, 3)
+    seeds = []
+    for k in range(G):
+        poses, trans, betas = _ego_seed(g, f"{pre}m{k}_")
+        seeds.append([{"poses": poses[0].numpy().astype(np.float64), "trans": trans[0].numpy().astype(np.float64),
+                       "betas": betas[0].numpy().astype(np.float64)}])
+    grp = CrowdGroupEnv(1, st, h, combo, vp, seed=0, scene_rings=w["rings"], static_scene=True, agent_seeds=seeds, vp_thresh=14.0,
+                        goal_terminates=False)
+    for k, m in enumerate(grp.members):
+        m.set_candidates(st[k].reshape(1, 1, 2, 3), np.array([float(g[f"{pre}m{k}_yaw_jitter"])], np.float32), np.arange(1))
+        m._launch_reset(None)
+    for k, m in enumerate(grp.members):
+        mp = f"{pre}m{k}_"
+        m._launch_reset(None)
+        obs = m.obs()
+        _close(grp.bbox[k, 0], _ring_box(g[mp + "init_bbox"]), "m", mp + "constructor box")
+        _close(m.wpath[0], g[mp + "reset_wpath"], "m", mp + "wpath")
+        _close(m.state[0], g[mp + "reset_state"], "unit", mp + "reset state")
+        _close(m.T0[0], g[mp + "reset_T0"].reshape(-1), "m", mp + "reset T0")
+        _close(obs["egosensing"][0], g[mp + "reset_obs_ego"], "ego", mp + "reset egosensing")
+    ex_r, ex_k = int(g[pre + "exit_round"]), int(g[pre + "exit_member"])
+    n_rounds = ex_r + 1 if ex_r >= 0 else int(g[pre + "n_rounds"])
+    for r in range(n_rounds):
+        z = torch.as_tensor(g[pre + "z"][r]).cuda()
+        for k, m in enumerate(grp.members):
+            sp = f"{pre}r{r}_m{k}_"
+            obs, rew, term = m.step(z[k:k + 1].contiguous(), auto_reset=False)
+            if (r, k) == (ex_r, ex_k):
+                assert int(m.invalid[0]) & _EXIT_FLAG[str(g[pre + "exit_reason"])], (sp, int(m.invalid[0]))
+                return
+            assert int(m.invalid[0]) == 0, sp
+            rt = m.rterms[0].cpu().numpy()
+            got = {"Y_gen": m.Y_gen.reshape(-1, 201), "pred_params": m.pred_params.reshape(20, 93), "joints": m.joints.reshape(20, -1, 3),
+                   "r_skate": rt[0], "r_floor": rt[1], "r_face_target": rt[2], "r_look_target": rt[3], "r_goal": rt[4], "r_target_dist": rt[5],
+                   "r_pene": rt[6], "r_vp": rt[7], "reward": rew[0], "terminated": term[0], "after_state": m.state[0],
+                   "after_seed": m.seed[0].cpu(), "after_R0": m.R0[0], "after_T0": m.T0[0].cpu(), "after_dist": m.dist.cpu(),
+                   "obs_ego": obs["egosensing"][0], "obs_dist": obs["dist"].cpu(), "obs_time": obs["time"].cpu()}
+            _check_step_common(g, sp, got)
+            _close(grp.bbox[k, 0], _ring_box(g[sp + "bbox_after"]), "m", sp + "published box")
+    assert ex_r < 0
