@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from egogen_amd.models import ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase, POLICY_CFG, PolicyHipRunner
 torch.manual_seed(0)
+from egogen_amd import _lib
+_lib.load().egx_policy_set_precision(int(os.environ.get("EGX_POLICY_PREC", "2")))   # 0 f32-equivalent, 2 bf16x2 (drivers' default), 1 bf16
 ac = ActorCritic(GAMMAActor(POLICY_CFG), GAMMACritic(POLICY_CFG), GAMMAPolicyBase(POLICY_CFG)).cuda()
 run = PolicyHipRunner(ac.shared_net, ac.actor, ac.critic)
 for A in (64, 256, 512, 2560):
