@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egogen_amd import setup_world as sw  # noqa: E402
 from egogen_amd import synth  # noqa: E402
 from egogen_amd.body_model import BodyModelHandle  # noqa: E402
-from egogen_amd.trainer import Collector, ScalarLogger, onpolicy_trainer  # noqa: E402
+from egogen_amd.trainer import CheckpointWriter, Collector, ScalarLogger, onpolicy_trainer  # noqa: E402
 
 SCENE_DEFAULT = "room0"
 CFG_NAME = "MPVAEPolicy_samp_collision"
@@ -141,14 +141,16 @@ def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True
     log_path = os.path.join(args.logdir, log_name)
     logger = ScalarLogger(log_path) if rank == 0 else None
 
+    writer = CheckpointWriter()      # file writes on a worker thread (egogen_amd/trainer.py); flushed before main() returns
+
     def save_best_fn(pol):
         state = {"model": pol.state_dict(), "optim": pol.optim_state_dict()} if ckpt_with_optim else {"model": pol.state_dict()}
-        torch.save(state, os.path.join(log_path, "policy.pth"))
+        writer.save(state, os.path.join(log_path, "policy.pth"))
 
     def save_checkpoint_fn(epoch, env_step, gradient_step):
         ckpt_path = os.path.join(log_path, f"checkpoint_{epoch}.pth")
         state = {"model": policy.state_dict(), "optim": policy.optim_state_dict()} if ckpt_with_optim else {"model": policy.state_dict()}
-        torch.save(state, ckpt_path)
+        writer.save(state, ckpt_path)
         return ckpt_path
 
     if not args.watch:
@@ -158,6 +160,7 @@ def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True
                                   args.repeat_per_collect, args.test_num, args.batch_size,
                                   step_per_collect=args.step_per_collect, save_best_fn=save_best_fn, logger=logger,
                                   save_checkpoint_fn=save_checkpoint_fn, save_interval=args.save_interval)
+        writer.flush()               # every checkpoint of the run is on disk from here on
         if rank == 0:
             pprint.pprint(result)
 
@@ -167,6 +170,7 @@ def main(args, scene_kind=SCENE_DEFAULT, cfg_name=CFG_NAME, ckpt_with_optim=True
     result = test_collector.collect_episodes(args.test_num)
     if rank == 0:
         print(f'Final reward: {result["rew"]}, length: {result["len"]}')
+    writer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
