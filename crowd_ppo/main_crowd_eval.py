@@ -56,47 +56,69 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
             st[k, s, 0], st[k, s, 1] = pts[k], pts[(k + G // 2) % G]
     grp = CrowdGroupEnv(S, st, body, prior, vposer, cfg=sw.env_cfg_from_yaml(cfg), seed=args.seed + 100 * local_rank, keep_rollout=True)
     obs = grp.reset()
-    episodes = [[[] for _ in range(S)] for _ in range(G)]
     ep_ret = torch.zeros(G, S, device="cuda")
     done_ret, done_len, done_cnt = [], [], 0
     ep_len = torch.zeros(G, S, device="cuda")
-    max_steps = grp.members[0].cfg["max_depth"]
     target_eps = args.test_num
     pol_out = [dict() for _ in range(G)]
+    # Episode bookkeeping stays on the device: every member step appends one snapshot of what a motion primitive of the rollout file
+    # holds (crowd_env_crowd_eval.py:177-178 `self.outmps.append`), the termination flags are the ONE host read per member step, and
+    # the primitives of the episodes that just ended come over in one copy per field (before: five copies per member step and one
+    # per scene, whether or not anything ended).
+    hist = [[] for _ in range(G)]                 # hist[k][i] = (marker_b, pred_params, frame, pelvis) of member k's i-th kept step
+    t_start = np.zeros((G, S), np.int64)          # first kept step of the running episode of (member, scene)
+    import time
+    torch.cuda.synchronize()
+    t_loop = time.time()
     while done_cnt < target_eps:
         for k, m in enumerate(grp.members):
             out = policy(obs[k], out=pol_out[k])
-            wpath_before = m.wpath.cpu()
             o, rew, term = m.step(out["act"], auto_reset=False)
             ep_ret[k] += rew
             ep_len[k] += 1
-            mb, pp, fr = m.marker_b.cpu(), m.pred_params.cpu(), m.prev_frame.cpu()
-            pel = m.joints.reshape(S, 20, -1, 3)[:, :, 0].cpu()
+            hist[k].append((m.marker_b.clone(), m.pred_params.clone(), m.prev_frame.clone(),
+                            m.joints.reshape(S, 20, -1, 3)[:, :, 0].clone()))
             tm = term.cpu().numpy()
-            for s in range(S):
-                episodes[k][s].append([mb[s:s + 1], pp[s:s + 1], m.betas[s].cpu(), m.gender, fr[s, :9].reshape(3, 3),
-                                       fr[s, 9:].reshape(1, 3), pel[s:s + 1], "2-frame"])
-                if tm[s]:
-                    save_rollout_results({"wpath": wpath_before[s], "navmesh_path": None, "scene_path": "data/floor.ply"},
-                                         episodes[k][s], out_dir, man_id=f"crowd4_{k}" if S == 1 else f"crowd4_s{s}_{k}")
-                    episodes[k][s] = []
-                    done_ret.append(float(ep_ret[k, s]))
-                    done_len.append(float(ep_len[k, s]))
-                    done_cnt += 1
-                    ep_ret[k, s] = 0
-                    ep_len[k, s] = 0
+            if tm.any():
+                idx = np.nonzero(tm)[0]
+                it = torch.as_tensor(idx, device="cuda")
+                wp, bet = m.wpath[it].cpu(), m.betas[it].cpu()          # the reset below draws new targets: read them first
+                rets, lens = ep_ret[k, it].cpu().tolist(), ep_len[k, it].cpu().tolist()
+                for t0 in np.unique(t_start[k, idx]):
+                    sel = np.nonzero(t_start[k, idx] == t0)[0]         # positions in idx of the episodes that began at step t0
+                    its = it[torch.as_tensor(sel, device="cuda")]
+                    steps = hist[k][int(t0):]
+                    mb, pp, fr, pel = (torch.stack([h[f][its] for h in steps]).cpu() for f in range(4))    # [T, n, ...]
+                    for j, pos in enumerate(sel):
+                        sc = int(idx[pos])
+                        ep = [[mb[t, j:j + 1], pp[t, j:j + 1], bet[pos], m.gender, fr[t, j, :9].reshape(3, 3), fr[t, j, 9:].reshape(1, 3),
+                               pel[t, j:j + 1], "2-frame"] for t in range(len(steps))]
+                        save_rollout_results({"wpath": wp[pos], "navmesh_path": None, "scene_path": "data/floor.ply"}, ep, out_dir,
+                                             man_id=f"crowd4_{k}" if S == 1 else f"crowd4_s{sc}_{k}")
+                done_ret += rets
+                done_len += lens
+                done_cnt += len(idx)
+                ep_ret[k, it] = 0
+                ep_len[k, it] = 0
+                t_start[k, idx] = len(hist[k])
+                lo = int(t_start[k].min())
+                if lo > 0:                       # nothing before the oldest running episode is needed any more
+                    hist[k] = hist[k][lo:]
+                    t_start[k] -= lo
             m.sample_candidates()
             m._injected = True
             m._launch_reset(m.terminated)
             m._injected = False
             obs[k] = m.obs()
+    torch.cuda.synchronize()
+    t_loop = time.time() - t_loop
     print(f'Final reward: {np.mean(done_ret)}, length: {np.mean(done_len)}')
     stats_path = os.environ.get("EGX_CROWD_STATS")
     if stats_path:   # per-episode returns / lengths (statistical parity of the bf16 policy)
         import json
         with open(stats_path, "w") as f:
             json.dump({"reward": done_ret, "length": done_len, "scenes": S, "humans_per_scene": G}, f)
-    return {"rew": float(np.mean(done_ret)), "len": float(np.mean(done_len)), "episodes": done_cnt}
+    return {"rew": float(np.mean(done_ret)), "len": float(np.mean(done_len)), "episodes": done_cnt, "loop_s": t_loop}
 
 
 if __name__ == "__main__":
