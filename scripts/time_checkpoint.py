@@ -1,5 +1,8 @@
+"""Development aid (GPU box): what a checkpoint costs the training thread - state_dict + optim_state_dict, the device-to-host
+copy, torch.save (profiles/r05_driver_runs.md)."""
+import os
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from egogen_amd.trainer import CheckpointWriter
 from tests.test_trainer_gpu import _Args
 from egogen_amd import setup_world as sw
