@@ -1262,7 +1262,17 @@ def gen_learn():
     print("ppo_learn_ref", os.path.getsize(os.path.join(OUT, "ppo_learn_ref.npz")), "bytes")
 
 
+TARGETS = {"sdf": gen_sdf, "box": gen_box, "learn": gen_learn, "crowd": gen_crowd, "rollout": gen_rollout, "egobody": gen_egobody}
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sdf"]
-    for w in which:
-        {"sdf": gen_sdf, "box": gen_box, "learn": gen_learn, "crowd": gen_crowd, "rollout": gen_rollout, "egobody": gen_egobody}[w]()
+    if which == ["all"]:
+        which = list(TARGETS)
+    if len(which) == 1:
+        TARGETS[which[0]]()
+    else:
+        # every target installs its own substitutes over sys.modules (smplx.create, shapely, the tianshou stand-in ...) and takes
+        # the repository root off sys.path: one interpreter per target
+        import subprocess
+        for w in which:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), w])

@@ -33,7 +33,8 @@ import numpy as np
 import torch
 
 REF = "/root/reference/motion"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+# EGX_GOLDEN_OUT: write somewhere else (scripts/regen_and_diff_goldens.sh regenerates into a scratch directory and compares)
+OUT = os.environ.get("EGX_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
 def _stub(name, **attrs):
