@@ -311,6 +311,9 @@ def compact_line(full):
                                                       "launches", "bodies_per_launch", "flop_per_body", "products_per_fp32_product")}
     if cb is not None:
         line["cpu_baseline"] = {k: _r(cb.get(k), 3) for k in ("value", "unit", "cores", "kind")}
+        host = cb.get("host") or {}
+        if host.get("lscpu_physical_cores"):     # `cores` = the threads the headline leg used, not the size of the host
+            line["cpu_baseline"]["cores_note"] = f"{cb.get('cores')} threads of {host['lscpu_physical_cores']} physical cores (the fastest leg)"
         line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:200]
     for k in ("value_configs2", "value_fp32_equivalent", "value_reference_shape"):
         line[k] = _r(full.get(k), 1)
@@ -318,7 +321,8 @@ def compact_line(full):
         line["regions_ms_per_step"] = [_r(t, 4) for t in full["regions"]["ms_per_step"]]
     ar = full.get("allreduce")
     if ar:
-        line["allreduce"] = {k: _r(ar.get(k), 4) for k in ("bytes", "buckets", "calls_per_step", "in_loop_ms_per_step", "standalone_ms",
+        line["allreduce"] = {k: _r(ar.get(k), 4) for k in ("bytes", "backend", "world_size", "nccl_version", "buckets", "overlapped_with_backward",
+                                                           "calls_per_step", "in_loop_ms_per_step", "exposed_ms_per_step", "standalone_ms",
                                                            "standalone_busbw_GBps")}
     if full.get("weak"):
         w = full["weak"]
@@ -326,11 +330,26 @@ def compact_line(full):
                         "allreduce_in_loop_ms_per_step": _r((w.get("allreduce") or {}).get("in_loop_ms_per_step"), 4)}
     line["precision"] = {k: v for k, v in (full.get("precision") or {}).items() if k != "note"}
     line["detail"] = full.get("detail_file")
-    if len(json.dumps(line)) > LINE_BUDGET:      # never let an optional object cost the record
-        for k in ("precision", "weak", "regions_ms_per_step"):
-            line.pop(k, None)
-            if len(json.dumps(line)) <= LINE_BUDGET:
-                break
+    # never let an optional object or a long string cost the record: drop / shorten until the line fits, always return one
+    def fits():
+        return len(json.dumps(line)) <= LINE_BUDGET
+    for k in ("precision", "weak", "regions_ms_per_step", "allreduce"):
+        if fits():
+            break
+        line.pop(k, None)
+    for cut in (120, 60, 0):
+        if fits():
+            break
+        if "cpu_baseline" in line:
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:cut]
+        line["dtype"] = str(line.get("dtype"))[:max(cut, 16)]
+        line["config"]["workload"] = str(line["config"].get("workload"))[:max(2 * cut, 48)]
+        line["config"].pop("update_paths", None)
+    if not fits():
+        line["roofline"] = {k: line["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    if not fits():
+        line = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                         "vs_baseline", "data", "roofline", "detail")}
     return line
 
 
@@ -458,15 +477,29 @@ def _measure(args, world, rank, A, batch_local, scene, ops, steps, warmup, with_
         alone_ms = (time.perf_counter() - t1) / 10 * 1e3
         nbytes = flat.numel() * 4
         n_buckets = len(policy._grad_buckets())
+        overl = bool(policy.overlap_allreduce and n_buckets == 2 and args.update_graph)
+        # overlapped form: the calls alternate bucket 0 (beside the encoders' backward) / bucket 1 (nothing left to hide behind)
+        hidden = float(np.sum(in_loop[0::2])) / steps if (overl and in_loop) else 0.0
+        exposed = (float(np.sum(in_loop[1::2])) if overl else float(np.sum(in_loop))) / steps if in_loop else None
+        try:
+            nccl_v = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception:
+            nccl_v = None
+        devs = [None] * world
+        dist.all_gather_object(devs, f"rank {rank}: cuda:{torch.cuda.current_device()} {torch.cuda.get_device_name()}")
         ar = {"bytes": nbytes, "buckets": n_buckets, "bucket_bytes": [int(b.numel()) * 4 for b in policy._grad_buckets()],
-              "overlapped_with_backward": bool(policy.overlap_allreduce and n_buckets == 2 and args.update_graph),
-              "calls_per_step": n_mb * (n_buckets if (policy.overlap_allreduce and args.update_graph) else 1),
+              "backend": dist.get_backend(), "world_size": dist.get_world_size(), "nccl_version": nccl_v, "devices": devs,
+              "overlapped_with_backward": overl,
+              "calls_per_step": n_mb * (n_buckets if overl else 1),
               "in_loop_avg_ms": float(np.mean(in_loop)) if in_loop else None,
-              "in_loop_ms_per_step": float(np.sum(in_loop)) / steps if in_loop else None, "standalone_ms": alone_ms,
+              "in_loop_ms_per_step": float(np.sum(in_loop)) / steps if in_loop else None,
+              "exposed_ms_per_step": exposed, "beside_backward_ms_per_step": hidden, "standalone_ms": alone_ms,
               "standalone_algbw_GBps": nbytes / (alone_ms * 1e-3) / 1e9,
               "standalone_busbw_GBps": nbytes / (alone_ms * 1e-3) / 1e9 * 2 * (world - 1) / world,
-              "note": "in_loop = sum over the buckets, measured on the communication stream (bucket 0 overlaps the encoders' backward), includes "
-                      "the wait for the slowest rank; busbw = algbw * 2(N-1)/N (ring all-reduce)"}
+              "note": "in_loop = every all-reduce call of the timed region, events on the issuing stream, including the wait for the slowest "
+                      "rank.  Default: ONE call per optimiser step between the two graphs (all of it exposed).  EGX_DP_OVERLAP=1: two "
+                      "buckets, bucket 0 beside the encoders' backward (beside_backward: at most ~60 us of it can hide), bucket 1 exposed; "
+                      "busbw = algbw * 2(N-1)/N (ring all-reduce)"}
     graphs_ok = bool(args.update_graph) and not any(v.get("failed") for v in policy._graph_cache.values())
     forced = env.forced_accepts() if hasattr(env, "forced_accepts") else 0
     if world > 1:
@@ -541,6 +574,24 @@ def _lbs_penetrating_ms(env, lib, reps=8):
 
 
 def main():
+    """One JSON line on stdout whatever happens: the measurement, or - when any rank fails - a line with `value` null and
+    `error` naming the rank and the exception (the traceback still goes to stderr and the exit status stays non-zero)."""
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException as e:
+        import traceback
+        traceback.print_exc()
+        rank, world = os.environ.get("RANK", "0"), int(os.environ.get("WORLD_SIZE", "1"))
+        print(json.dumps({"metric": "PPO env-steps/sec (parallel SMPL-X agents)", "value": None, "unit": "env-steps/s", "n_gpus": world,
+                          "higher_is_better": True, "data": "synthetic",
+                          "error": f"rank {rank} of {world}: {type(e).__name__}: {str(e)[:600]}",
+                          "env": {k: os.environ.get(k) for k in ("EGX_DP_OVERLAP", "EGX_DIST_BACKEND", "EGX_LBS_BLEND", "LOCAL_RANK")}}), flush=True)
+        os._exit(1)   # do not wait in a collective's destructor for ranks that are already gone
+
+
+def _main():
     import faulthandler
     faulthandler.enable()
     faulthandler.dump_traceback_later(600, repeat=True, file=sys.stderr)
@@ -619,6 +670,12 @@ def main():
         # n-term bf16 split: BLEND_PRODUCTS bf16 MFMA products per fp32 product -> the matrix-pipe ceiling of the
         # ALGORITHMIC fp32 flops is the dense bf16 peak / that count
         npr = BLEND_PRODUCTS[blend]
+        if blend == 3 and m["env"].sdf is not None:
+            # the tiles that hold picked vertices run the two-plane product (3 per fp32 product), the count-only tiles 34/30
+            vp = bm_handle.lbs_vertices["picks"]
+            npr = (3.0 * vp + (34.0 / 30.0) * (verts_eval - vp)) / verts_eval
+        elif blend == 3:
+            npr = 3.0   # a call without counts evaluates the picked tiles only
         kernel_name, peak = "egx_lbs_fused3_kernel", PEAK_BF16_MFMA_TFLOPS / npr
         peak_note = (f"dense 16-bit MFMA peak 2500 TFLOP/s / {npr:.3g} products per fp32 product "
                      f"({BLEND_NAME[blend]}, fp32 accumulate)")
@@ -693,7 +750,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "avg_launch_ms": lbs_ms, "launches": len(ms_list), "bodies_per_launch": bodies,
-                     "flop_per_body": FLOP_PER_BODY, "products_per_fp32_product": BLEND_PRODUCTS.get(blend), "vertices_evaluated": verts_eval, "vertices_total": bm_handle.V,
+                     "flop_per_body": FLOP_PER_BODY, "products_per_fp32_product": npr if blend in (1, 2, 3) else None, "vertices_evaluated": verts_eval, "vertices_total": bm_handle.V,
                      "peak_note": peak_note, "executed_bf16_tflops": executed,
                      "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene, "in_scene_penetrating": penetrating,
                      "culling": {"model_allows": bool(bm_handle.culls), "reference_margin_m": bm_handle.cull_reference_margin,
@@ -769,9 +826,7 @@ def main():
             for k in ("roofline", "cpu_baseline", "other_configs"):
                 if result.get(k) is not None:
                     _log(f"detail {k}: " + json.dumps(result[k]))
-        line = json.dumps(compact_line(result))
-        assert len(line) <= LINE_BUDGET, len(line)
-        print(line, flush=True)
+        print(json.dumps(compact_line(result)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,6 +9,8 @@ interact, scenes do not, so there is no collective)."""
 import os
 import sys
 
+import time
+
 import numpy as np
 import torch
 
@@ -67,7 +69,18 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
     # per scene, whether or not anything ended).
     hist = [[] for _ in range(G)]                 # hist[k][i] = (marker_b, pred_params, frame, pelvis) of member k's i-th kept step
     t_start = np.zeros((G, S), np.int64)          # first kept step of the running episode of (member, scene)
-    import time
+    # Only the newest HIST_ON_DEVICE steps of a member stay in device memory (24 KB per scene and step: 12 MB per member step at 512
+    # scenes); older ones of still-running episodes move to page-locked host memory with asynchronous copies on this stream.
+    HIST_ON_DEVICE = 8
+
+    def offload(k):
+        n_old = len(hist[k]) - HIST_ON_DEVICE
+        for i in range(max(0, n_old)):
+            if hist[k][i][0].is_cuda:
+                hist[k][i] = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) for t in hist[k][i])
+
+    def rows(h, f, its, its_host):                # rows `its` of field f of one kept step, wherever it lives
+        return h[f][its] if h[f].is_cuda else h[f][its_host].to("cuda", non_blocking=True)
     torch.cuda.synchronize()
     t_loop = time.time()
     while done_cnt < target_eps:
@@ -87,8 +100,10 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
                 for t0 in np.unique(t_start[k, idx]):
                     sel = np.nonzero(t_start[k, idx] == t0)[0]         # positions in idx of the episodes that began at step t0
                     its = it[torch.as_tensor(sel, device="cuda")]
+                    its_host = torch.as_tensor(idx[sel])
                     steps = hist[k][int(t0):]
-                    mb, pp, fr, pel = (torch.stack([h[f][its] for h in steps]).cpu() for f in range(4))    # [T, n, ...]
+                    torch.cuda.current_stream().synchronize()           # offloaded steps: their asynchronous copies have landed
+                    mb, pp, fr, pel = (torch.stack([rows(h, f, its, its_host) for h in steps]).cpu() for f in range(4))    # [T, n, ...]
                     for j, pos in enumerate(sel):
                         sc = int(idx[pos])
                         ep = [[mb[t, j:j + 1], pp[t, j:j + 1], bet[pos], m.gender, fr[t, j, :9].reshape(3, 3), fr[t, j, 9:].reshape(1, 3),
@@ -105,6 +120,7 @@ def main(args, num_scenes=1, num_agents=4, out_dir="log/eval_results/crowd-4huma
                 if lo > 0:                       # nothing before the oldest running episode is needed any more
                     hist[k] = hist[k][lo:]
                     t_start[k] -= lo
+            offload(k)
             m.sample_candidates()
             m._injected = True
             m._launch_reset(m.terminated)

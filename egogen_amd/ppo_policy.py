@@ -114,12 +114,17 @@ class GAMMAPPOPolicy(nn.Module):
         self._seed = seed
         self._perm_gen = torch.Generator().manual_seed(seed)
         self._flat_grad: Optional[torch.Tensor] = None
+        self._after_minibatch = None   # optional callable(i), called after optimiser step i of learn() (tests)
         self._layout = None
         self._graph_cache: dict = {}
         self.use_update_graph = bool(_ignored.get("use_update_graph", False))
-        # data parallel + replayed graphs: all-reduce the actor + critic bucket beside the encoders' backward (EGX_DP_OVERLAP=0:
-        # one all-reduce of the whole flat gradient between the two graphs, the round-4 form - the parity tests compare the two)
-        self.overlap_allreduce = os.environ.get("EGX_DP_OVERLAP", "1") != "0"
+        # data parallel + replayed graphs: ONE all-reduce of the whole flat gradient between the two graphs (default).
+        # EGX_DP_OVERLAP=1 (opt-in): the chain in two halves, the actor + critic bucket all-reduced on a communication stream beside
+        # the encoders' backward.  Opt-in because its stream ordering has only ever run with both ranks on one device over gloo
+        # (the blocking collective serialises on the host there): no multi-GPU node has executed it, and a wrong bucket boundary
+        # or a missed wait would corrupt gradients silently.  tests/test_multirank_gpu.py holds the two forms to each other and
+        # checks that the heads half finalises exactly [0, n_clip) and the encoders half writes nothing below n_clip.
+        self.overlap_allreduce = os.environ.get("EGX_DP_OVERLAP", "0") == "1"
         self.use_fused_loss = bool(_ignored.get("use_fused_loss", True))
         self._scale_cache = {}
         # the minibatch as a fixed chain of hand-written launches (csrc/update3.hip); EGX_TRAIN_STEP=0: the autograd nodes
@@ -777,6 +782,8 @@ class GAMMAPPOPolicy(nn.Module):
                     last_log = log
                     self.update_paths[path] = self.update_paths.get(path, 0) + 1
                 logs.append(last_log[:5])
+                if self._after_minibatch is not None:   # parity tests: the flat gradient / clip coefficient of THIS optimiser step
+                    self._after_minibatch(len(logs) - 1)
                 # `loss/kld` of ppo_policy.py:232 reads minibatch.z_mu - the means the ROLLOUT stored - not the current network's:
                 # 0.5 mean(mu_rollout^2) over the minibatch's rows, evaluated for all minibatches at once after the loop
                 kld_rows.append(idx)

@@ -247,25 +247,40 @@ class CheckpointWriter:
     def _snapshot(self, state, slot: int):
         """Host copy of `state`: every device tensor becomes a view of the slot's page-locked buffer of its dtype (torch.save
         writes a storage once and refuses views of different types on one storage: one buffer per dtype)."""
-        need = {}
-        self._walk(state, lambda t: need.__setitem__(t.dtype, need.get(t.dtype, 0) + (t.numel() + 15) // 16 * 16) if t.is_cuda else None)
+        # entries that alias one tensor (the policy's state_dict lists the actor / critic parameters under `actor.*`, `critic.*`
+        # AND `_actor_critic.*`) are copied once and stay aliases in the file, as in a plain torch.save of the device state
+        key = lambda t: (t.data_ptr(), t.dtype, tuple(t.shape), tuple(t.stride()))
+        need, seen = {}, set()
+
+        def count(t):
+            if t.is_cuda and key(t) not in seen:
+                seen.add(key(t))
+                need[t.dtype] = need.get(t.dtype, 0) + (t.numel() + 15) // 16 * 16
+        self._walk(state, count)
         if not need:
             return self._to_host(state)
         bufs = self._stage[slot]
         if bufs is None:
             bufs = self._stage[slot] = {}
         for dt, n in need.items():
-            if dt not in bufs or bufs[dt].numel() < n:
+            # exactly the size this snapshot needs: torch.save writes a view's WHOLE storage, so a larger buffer kept from an
+            # earlier, bigger state would be written out in full (checkpoints of one run all have the same size: no churn)
+            if dt not in bufs or bufs[dt].numel() != n:
                 bufs[dt] = torch.empty(n, dtype=dt, pin_memory=True)
         off = {dt: 0 for dt in need}
+        done = {}
 
         def take(t):
             if not t.is_cuda:
                 return t.detach().to("cpu", copy=True)
+            k = key(t)
+            if k in done:
+                return done[k]
             n, o = t.numel(), off[t.dtype]
             view = bufs[t.dtype][o:o + n].reshape(t.shape)
             off[t.dtype] = o + (n + 15) // 16 * 16
             view.copy_(t.detach(), non_blocking=True)
+            done[k] = view
             return view
         out = self._walk(state, take)
         torch.cuda.current_stream().synchronize()
@@ -297,7 +312,9 @@ class CheckpointWriter:
 
     def save(self, state, path: str) -> str:
         if self.sync:
-            torch.save(state, path)
+            tmp = path + ".tmp"
+            torch.save(state, tmp)
+            os.replace(tmp, path)              # a reader never sees a half-written file, in either mode
             return path
         self._raise()
         slot = self._free.get()            # waits while every staging buffer still belongs to an unwritten snapshot

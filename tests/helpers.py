@@ -114,8 +114,15 @@ def build_world(V=1536, A=6, scene_kind="sdf", sdf_res=48, n_pairs=64, n_scenes=
 
 def level_set_band():
     """Distance from the SDF's zero level set (metres) inside which a penetration count of the HIP path may differ from a CPU
-    evaluation: 2e-5 (fp32 round-off of the vertex chain) in the blend modes that are fp32-equivalent on the offsets, 6e-5 in
-    mode 3 ("f16mix", the library default: the tiles that only feed the count run their pose-corrective columns as one fp16
-    product, ~4 um rms / ~22 um worst case; tests/test_lbs_gpu.py::test_lbs_blend_mode_accuracy_report)."""
-    from egogen_amd import _lib
-    return 6e-5 if int(_lib.load().egx_lbs_get_blend_mode()) == 3 else 2e-5
+    evaluation: 2e-5 (fp32 round-off of the vertex chain) in EVERY blend mode - mode 3 ("f16mix", the library default) classifies
+    with its fp16 product and re-evaluates in fp32 what that product cannot decide (csrc/body_model.hip: lbs_fix_process)."""
+    return 2e-5
+
+
+def free_port() -> int:
+    """A TCP port the kernel just handed out on 127.0.0.1 (rendezvous of the spawned multi-rank tests: a port derived from the pid
+    can collide with a listener of an earlier test still in TIME_WAIT, or with another run on the same box)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

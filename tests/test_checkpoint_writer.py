@@ -66,3 +66,29 @@ def test_device_tensors_are_staged_and_snapshots_stay_intact(tmp_path, monkeypat
         assert m["q"].shape == (53, 37) and float(m["q"].min()) == float(m["q"].max()) == 2 * (i + 1)
         assert m["k"].dtype == torch.float64 and float(m["k"]) == 3 * (i + 1) and m["idx"].tolist() == [0, 1, 2, 3, 4]
         assert st["optim"]["tag"] == i and float(st["optim"]["state"][0]["step"]) == i
+
+
+@pytest.mark.gpu
+def test_aliased_entries_are_written_once_and_stay_aliases(tmp_path, monkeypatch):
+    """The policy's state_dict names the actor / critic parameters twice (`actor.*` / `critic.*` and `_actor_critic.*`): the
+    worker-thread file holds each tensor once - same size as the synchronous torch.save, aliases still sharing storage after
+    torch.load - and not the rest of a staging buffer that an earlier, larger state left behind."""
+    p = torch.randn(1 << 18, device="cuda")
+    big = {"model": {"a": torch.randn(1 << 20, device="cuda")}}
+    state = {"model": {"actor.w": p, "_actor_critic.actor.w": p, "other": torch.randn(1 << 10, device="cuda")}}
+    monkeypatch.setenv("EGX_SYNC_CHECKPOINTS", "0")
+    w = CheckpointWriter(depth=1)
+    for i in range(3):                        # every staging slot has held the larger state once
+        w.save(big, str(tmp_path / f"big_{i}.pth"))
+    w.save(state, str(tmp_path / "async.pth"))
+    w.close()
+    monkeypatch.setenv("EGX_SYNC_CHECKPOINTS", "1")
+    w2 = CheckpointWriter()
+    w2.save(state, str(tmp_path / "sync.pth"))
+    w2.close()
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    a, b = os.path.getsize(tmp_path / "async.pth"), os.path.getsize(tmp_path / "sync.pth")
+    assert abs(a - b) <= 4096 and a < 4 * ((1 << 18) + (1 << 10)) + 65536, (a, b)
+    st = torch.load(tmp_path / "async.pth")["model"]
+    assert st["actor.w"].data_ptr() == st["_actor_critic.actor.w"].data_ptr()
+    assert torch.equal(st["actor.w"], p.cpu()) and torch.equal(st["other"], state["model"]["other"].cpu())

@@ -318,6 +318,23 @@ def test_auto_reset_reinitialises_finished_agents():
     assert env.steps.sum().item() == 0 and torch.all(obs["time"] == 1)
 
 
+def test_step_without_auto_reset_leaves_the_targets_alone():
+    """crowd_ppo/main_crowd_eval.py reads `wpath` / `betas` of the episodes that just ended AFTER `step(auto_reset=False)` and
+    before its own reset launch: the step must not touch them, terminated or not (the targets are drawn by reset only)."""
+    A = 8
+    w = build_world(A=A, scene_kind="sdf")
+    env = w["env"]
+    env.reset()
+    wp, bt = env.wpath.clone(), env.betas.clone()
+    env.steps.fill_(env.cfg["max_depth"] - 2)
+    z = torch.zeros(A, 128, device="cuda")
+    for expect_done in (False, True):
+        _, _, term = env.step(z, auto_reset=False)
+        assert bool(term.all()) == expect_done or not expect_done
+        assert torch.equal(env.wpath, wp) and torch.equal(env.betas, bt)
+    assert term.sum().item() == A
+
+
 def test_crowd_group_matches_oracle_with_sequential_hole_updates():
     """BASELINE config 5 plumbing (main_crowd_eval.py): 4 members per scene, each member's walkable polygon has the world
     marker boxes of the others as holes, and members step one after the other (dummy_vector_env.py:81-84)."""

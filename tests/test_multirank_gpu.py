@@ -15,6 +15,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from tests.helpers import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -55,7 +57,7 @@ def _probe_obs(n=32):
             "dist": torch.rand(n, generator=g).cuda(), "time": torch.rand(n, generator=g).cuda()}
 
 
-def _dp_worker(rank, world, port, n_local, n_steps, n_learn, out_path, overlap=True):
+def _dp_worker(rank, world, port, n_local, n_steps, n_learn, out_path, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       EGX_DP_OVERLAP="1" if overlap else "0")
     torch.cuda.set_device(0)
@@ -78,7 +80,8 @@ def _dp_worker(rank, world, port, n_local, n_steps, n_learn, out_path, overlap=T
     assert not any(v.get("failed") for v in pol._graph_cache.values()), "graph capture fell back to eager"
     assert all(v.get("g1") is not None and v.get("g2") is not None and v.get("path") == "chain" for v in pol._graph_cache.values()), \
         "world > 1 must replay two graphs per minibatch around the all-reduce"
-    # default: the chain in two halves, the actor + critic bucket all-reduced on the communication stream beside the second
+    # EGX_DP_OVERLAP=1: the chain in two halves, the actor + critic bucket all-reduced on the communication stream beside the
+    # second; default (0): one all-reduce of the whole flat gradient between the two graphs
     assert pol.overlap_allreduce == overlap and len(pol._grad_buckets()) == 2
     assert all((v.get("g1b") is not None) == overlap for v in pol._graph_cache.values())
     # the weight images the next rollout forward reads were re-made by the last replay of the second graph
@@ -130,20 +133,20 @@ def _single_process_reference(world, n_local, n_steps, n_learn):
 _DP_RUNS = {}   # (world, n_local, n_steps, n_learn, overlap) -> per-rank results: tests that use the same two-rank run share ONE spawn
 
 
-def _run_dp(tmp_path, world, n_local, n_steps, n_learn, overlap=True):
+def _run_dp(tmp_path, world, n_local, n_steps, n_learn, overlap=False):
     key = (world, n_local, n_steps, n_learn, bool(overlap))
     if key not in _DP_RUNS:
         out = str(tmp_path / f"dp{int(overlap)}.pt")
-        mp.spawn(_dp_worker, args=(world, 29500 + (os.getpid() + 311 * int(overlap)) % 2000, n_local, n_steps, n_learn, out, overlap),
+        mp.spawn(_dp_worker, args=(world, free_port(), n_local, n_steps, n_learn, out, overlap),
                  nprocs=world, join=True)
         _DP_RUNS[key] = [torch.load(out + f".{r}") for r in range(world)]
     return _DP_RUNS[key]
 
 
 def test_bucketed_overlapped_all_reduce_equals_single_all_reduce(tmp_path):
-    """Data-parallel update, default form - the chain in two halves, bucket 0 (actor + critic, the clipped prefix of the flat
-    gradient) all-reduced on a communication stream while the encoders' backward runs, bucket 1 after it, clip + AdamW after
-    both - against the round-4 form (ONE all-reduce of the whole flat gradient between the two graphs, EGX_DP_OVERLAP=0): the
+    """Data-parallel update, opt-in overlapped form (EGX_DP_OVERLAP=1) - the chain in two halves, bucket 0 (actor + critic, the
+    clipped prefix of the flat gradient) all-reduced on a communication stream while the encoders' backward runs, bucket 1 after
+    it, clip + AdamW after both - against the default (ONE all-reduce of the whole flat gradient between the two graphs): the
     same kernels on the same data and an element-wise sum either way.  The two runs agree to the run-to-run noise of the chain
     itself (the loss kernel sums its rows with floating-point atomics: the last bit of the logged loss and of the head gradients
     is not reproducible between two runs of the SAME configuration): losses to 1e-6 relative, the reduced + clipped gradients to
@@ -164,6 +167,53 @@ def test_bucketed_overlapped_all_reduce_equals_single_all_reduce(tmp_path):
         assert float(d.max()) <= 2 * 3e-4 * n_steps * n_learn, k
         moved += int((d > 2e-6).sum())
     assert moved <= 2000, moved
+
+
+def test_chain_halves_write_disjoint_gradient_buckets():
+    """What the overlapped all-reduce relies on, checked on the launches themselves: after the HEADS half of the update chain
+    (`egx_policy_train_step_heads`) every actor / critic gradient - the bucket [0, n_clip) that is handed to the collective while
+    the second half runs - holds its final value, and the ENCODERS half (`egx_policy_train_step_encoders`) writes nothing below
+    n_clip and every shared_net gradient above it.  The flat gradient is poisoned with NaN first: an entry a half does not
+    write stays NaN; an entry the second half touches in bucket 0 changes its bits."""
+    from egogen_amd.ppo_policy import RolloutBatch
+    pol = _make_policy(True)
+    n = 64
+    b = RolloutBatch(1, n, "cuda")
+    _fill(b, 5, pol)
+    pol.train()
+    pol._ensure_flat_grads()
+    assert pol._flat_optimizer_ready()
+    pol._refresh_images()
+    hs = pol._train_handle(n)
+    assert hs is not None
+    lay = pol._flat_layout()
+    n_clip = pol._n_clip
+    names = {id(p): k for k, p in pol.state_dict(keep_vars=True).items() if not k.startswith("_actor_critic.")}
+    idx = torch.arange(n, device="cuda")
+    log = torch.zeros(6, device="cuda")
+    pol._flat_grad.fill_(float("nan"))
+    pol._fwd_bwd_train_step(hs, b, idx, None, log, part="heads")
+    torch.cuda.synchronize()
+    after_heads = pol._flat_grad.clone()
+    for p_, off, cnt in lay:
+        written = bool(torch.isfinite(after_heads[off:off + cnt]).all())
+        assert written == (off < n_clip), (names.get(id(p_)), off, n_clip, written)
+        assert (off + cnt <= n_clip) or (off >= n_clip), "a tensor straddles the bucket boundary"
+    assert any(names[id(p_)].startswith("shared_net.") for p_, off, _ in lay if off >= n_clip)
+    assert all(not names[id(p_)].startswith("shared_net.") for p_, off, _ in lay if off < n_clip)
+    pol._fwd_bwd_train_step(hs, b, idx, None, log, part="encoders")
+    torch.cuda.synchronize()
+    after_both = pol._flat_grad.clone()
+    assert torch.equal(after_both[:n_clip].view(torch.int32), after_heads[:n_clip].view(torch.int32)), "the encoders half wrote into bucket 0"
+    for p_, off, cnt in lay:
+        assert bool(torch.isfinite(after_both[off:off + cnt]).all()), names.get(id(p_))
+    # and the two halves together are the undivided chain
+    pol._flat_grad.fill_(float("nan"))
+    pol._fwd_bwd_train_step(hs, b, idx, None, log, part="all")
+    torch.cuda.synchronize()
+    for p_, off, cnt in lay:
+        a, c = pol._flat_grad[off:off + cnt], after_both[off:off + cnt]
+        assert float((a - c).abs().max()) <= 1e-5 * max(float(c.abs().max()), 1e-12), names.get(id(p_))
 
 
 @pytest.mark.parametrize("n_local", [32, 64])   # 32 rows per rank = the 8-way split of the 256-row minibatch (BASELINE configs[3])
@@ -251,7 +301,7 @@ def test_rccl_all_reduce_between_graph_replays_single_rank(tmp_path):
     float64 moments instead of the fp32 kernel)."""
     n_local, n_steps = 64, 3
     out = str(tmp_path / "rccl.pt")
-    mp.spawn(_rccl_worker, args=(29500 + (os.getpid() + 77) % 2000, n_local, n_steps, out), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(free_port(), n_local, n_steps, out), nprocs=1, join=True)
     got = torch.load(out)
     from egogen_amd.ppo_policy import RolloutBatch
     pol = _make_policy(False)

@@ -8,6 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from tests.helpers import free_port
+
 from egogen_amd.models import ActorCritic, GAMMAActor, GAMMACritic, GAMMAPolicyBase, POLICY_CFG
 from egogen_amd.ppo_policy import GAMMAPPOPolicy, RolloutBatch
 from oracle import ppo as oppo
@@ -166,7 +168,7 @@ def _dp_worker(rank, world, port, n_local, out_path):
 def test_data_parallel_update_equals_single_process(tmp_path):
     world, n_local = 2, 6
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_dp_worker, args=(world, 29000 + os.getpid() % 2000, n_local, out), nprocs=world, join=True)
+    mp.spawn(_dp_worker, args=(world, free_port(), n_local, out), nprocs=world, join=True)
     dp = torch.load(out)
     # single process on the concatenated data
     pol = _policy(seed=0)

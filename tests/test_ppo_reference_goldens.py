@@ -103,13 +103,23 @@ def test_hip_ppo_learn_matches_reference_execution(case, mode):
     b.act[0].copy_(act); b.adv[0].copy_(adv); b.returns[0].copy_(ret); b.logp_old[0].copy_(lpo); b.mu[0].copy_(z_mu)
     b.values[0].copy_(v_s)
     pol._perm_queue = [g[pre + "perm"]]
+    # what each optimiser step consumed: the flat gradient as the backward left it and the clip coefficient egx_adamw_clip_step
+    # computed from its [0, n_clip) prefix and applied to that prefix only (csrc/ppo.hip: consts[0], 1024 floats into its
+    # workspace) - read after every minibatch, graph replay or not
+    seen = []
+
+    def spy(i):
+        torch.cuda.synchronize()
+        seen.append((pol._flat_grad.detach().cpu().clone(), float(pol._adamw_ws[1024].item()) if pol._flat_opt_state == "ready" else None))
+    pol._after_minibatch = spy
     res = pol.learn(b, int(g[pre + "batch_size"]), 1)
+    pol._after_minibatch = None
     expect = {"default": {"chain+graph": 1, "chain": 1}, "options": None}[case]
     if expect is not None:   # 64 rows: replayed graph; the merged 96-row minibatch: the chain, eagerly (its own handle)
         assert pol.update_paths == expect, pol.update_paths
     else:
         assert all(k.startswith("autograd") for k in pol.update_paths), pol.update_paths
-    tol = 1e-4 if mode == "f32" else 2e-4
+    tol = 1e-4   # north_star's tolerance, in both arithmetic modes of the update
     for k, v in res.items():
         ref = g[pre + "res_" + k.replace("/", "_")]
         np.testing.assert_allclose(v, ref, rtol=tol, atol=1e-5, err_msg=f"{k} ({mode})")
@@ -119,3 +129,34 @@ def test_hip_ppo_learn_matches_reference_execution(case, mode):
         assert float(d.norm()) == pytest.approx(float(g[pre + "delta_norm"][j]), rel=3e-2, abs=1e-7), k
         dh = np.abs(np.resize(d.flatten()[:8].numpy(), 8) - g[pre + "delta_head"][j])
         assert dh.max() <= 4 * 3e-4 + 1e-7 and np.median(dh) <= 5e-6, (k, dh)
+    # the reference's own gradients at `optim.step` (ppo_policy.py:242-248: AFTER its clip, which covers actor + critic only)
+    lay = {id(p_): (off, n) for p_, off, n in pol._flat_layout()}
+    named = pol.state_dict(keep_vars=True)
+    n_clip = pol._n_clip if pol._flat_opt_state == "ready" else None
+    assert len(seen) == 2
+    gtol = 2e-3                                # per-tensor gradient norms and leading entries (the CPU oracle's tolerance)
+    for i, (flat, coef) in enumerate(seen):
+        if n_clip is None:                     # autograd nodes + torch's clip (options case): .grad was scaled in place
+            coef, used = 1.0, flat
+        else:
+            assert 0.0 < coef < 1.0, coef      # the raw actor + critic norm is far above max_grad_norm = 0.1
+            used = flat.clone()
+            used[:n_clip] *= coef
+            # the clipped prefix ends exactly where the first shared_net tensor starts: the encoders are NOT rescaled
+            first_shared = min(lay[id(named[k])][0] for k in names if k.startswith("shared_net."))
+            last_clipped = max(lay[id(named[k])][0] + lay[id(named[k])][1] for k in names if not k.startswith("shared_net."))
+            assert last_clipped <= n_clip <= first_shared, (last_clipped, n_clip, first_shared)
+        sl = lambda k: used[lay[id(named[k])][0]:lay[id(named[k])][0] + lay[id(named[k])][1]]
+        nrm = np.array([float(sl(k).norm()) for k in names])
+        refn = g[f"{pre}mb{i}_grad_norm"]
+        print(f"{case}/{mode} step {i}: clip coefficient {coef:.6f}, worst per-parameter |norm / reference - 1| = "
+              f"{float(np.max(np.abs(nrm - refn) / np.maximum(refn, 1e-12))):.2e}")
+        np.testing.assert_allclose(nrm, refn, rtol=gtol, atol=1e-7, err_msg=f"step {i} per-parameter gradient norms")
+        for j, k in enumerate(names):
+            scale = float(sl(k).abs().max()) + 1e-12
+            assert np.abs(np.resize(sl(k)[:8].numpy(), 8) - g[f"{pre}mb{i}_grad_head"][j]).max() <= gtol * scale, (i, k)
+        clipped = float(torch.sqrt(sum(sl(k).double().pow(2).sum() for k in names if not k.startswith("shared_net."))))
+        assert clipped == pytest.approx(float(g[f"{pre}mb{i}_clipped_set_norm"]), rel=1e-3) and clipped == pytest.approx(0.1, rel=1e-3)
+        raw_shared = float(torch.sqrt(sum(sl(k).double().pow(2).sum() for k in names if k.startswith("shared_net."))))
+        ref_shared = float(np.sqrt(sum(float(g[f"{pre}mb{i}_grad_norm"][j]) ** 2 for j, k in enumerate(names) if k.startswith("shared_net."))))
+        assert raw_shared > 1.0 and raw_shared == pytest.approx(ref_shared, rel=gtol)
