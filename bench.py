@@ -688,12 +688,16 @@ def _main():
         act, tot = bm_handle.cull_stats(bodies)
         return {"items_evaluated": act, "items_total": tot, "fraction_evaluated": act / max(1, tot)}
     cull_loop = _cull_stats()          # the last launch of the timed loop
+    # mixed blend: vertices the last launch re-evaluated in fp32 (the ones its fp16 product / two-plane skinning could not decide)
+    fix_loop = bm_handle.fix_stats(bodies) if (blend == 3 and m["env"].sdf is not None) else None
     in_scene = _lbs_in_scene_ms(m["env"], lib)
     if in_scene is not None:
         in_scene["culling"] = _cull_stats()
+        in_scene["fixups"] = bm_handle.fix_stats(bodies) if blend == 3 else None
     penetrating = _lbs_penetrating_ms(m["env"], lib) if args.scene == "single_box" else None
     if penetrating is not None:
         penetrating["culling"] = _cull_stats()
+        penetrating["fixups"] = bm_handle.fix_stats(bodies) if blend == 3 else None
     if penetrating is not None:
         penetrating["achieved"] = FLOP_PER_BODY * bodies / (penetrating["avg_launch_ms"] * 1e-3) / 1e12
         penetrating["frac"] = penetrating["achieved"] / peak
@@ -755,7 +759,7 @@ def _main():
                      "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "in_scene": in_scene, "in_scene_penetrating": penetrating,
                      "culling": {"model_allows": bool(bm_handle.culls), "reference_margin_m": bm_handle.cull_reference_margin,
                                  "enabled": bool(args.lbs_cull), "last_launch_of_loop": cull_loop},
-                     "other_blend_mode": other_mode,
+                     "fixups_last_launch_of_loop": fix_loop, "other_blend_mode": other_mode,
                      "sustained_matrix_rate_note": "72 back-to-back v_mfma_f32_32x32x16_bf16 take 46, not 32, cycles each on this part "
                                                    "(clock-limited: 1720 of 2500 TFLOP/s in a load-free micro-benchmark, profiles/r01_ubench.md "
                                                    "section 4, profiles/r02_lbs_experiments.md); `peak` is the data-sheet figure"},

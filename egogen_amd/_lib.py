@@ -170,6 +170,10 @@ SIGNATURES = {
     "egx_ppo_loss_packed": (C.c_int, [C.c_void_p] * 8 + [C.c_float] * 6 + [C.c_int] + [C.c_void_p] * 4),
     "egx_lbs_set_blend_mode": (C.c_int, [C.c_int]),
     "egx_lbs_get_blend_mode": (C.c_int, []),
+    "egx_lbs_set_wave_tile": (C.c_int, [C.c_int]),
+    "egx_lbs_get_wave_tile": (C.c_int, []),
+    "egx_lbs_set_fix_queue_capacity": (C.c_int, [C.c_int]),
+    "egx_lbs_fix_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "egx_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egx_adv_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "egx_track_episode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -128,6 +128,15 @@ class BodyModelHandle:
         _lib.check(lib.egx_lbs_cull_stats(self.handle, _lib.ptr(self.workspace(B)), int(B), C.byref(act), C.byref(tot)), "egx_lbs_cull_stats")
         return int(act.value), int(tot.value)
 
+    def fix_stats(self, B: int) -> int:
+        """Vertices the LAST SDF-counting forward of B bodies on the current stream's workspace re-evaluated in fp32 (blend mode
+        "f16mix": the ones its fp16 product could not decide; `egx_lbs_fix_stats`, synchronises with the host)."""
+        lib = _lib.load()
+        n = C.c_int32()
+        torch.cuda.current_stream().synchronize()
+        _lib.check(lib.egx_lbs_fix_stats(self.handle, _lib.ptr(self.workspace(B)), int(B), C.byref(n)), "egx_lbs_fix_stats")
+        return int(n.value)
+
     def forward(self, xb: torch.Tensor, betas: torch.Tensor, frames_per_agent: int, want_verts=False,
                 want_joints=True, want_markers=True, sdf: Optional[SdfScene] = None,
                 R0: Optional[torch.Tensor] = None, T0: Optional[torch.Tensor] = None, out: Optional[dict] = None):

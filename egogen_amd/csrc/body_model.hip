@@ -108,12 +108,53 @@ struct PoseConsts {
   float J_shapedirs[NJ * 3 * 10];
   float hand_comps[2 * 12 * 45];
   float hand_mean[2 * 45];
+  float fix_c[NJ];   // per joint: largest |pose-corrective base column| (3-vector norm) over its 9 columns and all vertices
+  float v_norm_max;  // largest |v_template| + 0.25 m for the blend offsets: bound of a vertex before skinning
 };
+
+// Fix-up of the mixed blend (mode 3).  The count-only tiles evaluate the pose-corrective columns as ONE fp16 product: a vertex moves by
+// up to ~2e-5 m against the fp32 chain, and one that lies that close to the scene surface may be counted differently from the
+// reference's fp32 evaluation (crowd_env_2f.py:169-177).  So the cheap evaluation only CLASSIFIES: a vertex whose interpolated SDF
+// value is further from zero than the value change its position error can cause keeps the cheap decision; the few inside that band
+// are re-evaluated by their wave in fp32 (three-plane operand images, fp32 skinning: lbs_fix_process) and counted from that.
+// Position error of a body: the rounding errors of the 448 x 3 products are independent, std ~0.2 x
+//   bound(body) = 2^-11 sqrt(sum_j ||R_j - I||_F^2 C_j^2),  C_j = PoseConsts::fix_c
+// (scripts/emulate_lbs_fixup.py: error / bound rms 0.20, max 0.66 over 5e5 vertex samples, ordinary and wild poses); the band is
+// LBS_FIX_KAPPA x bound = ten standard deviations, plus a constant for the fp32 round-off of the rest of the chain.
+constexpr float LBS_FIX_KAPPA = 2.0f;
+constexpr float LBS_FIX_SLACK_M = 3e-6f;
+// Matrix-pipe skinning of the count-only tiles (lbs_skin_cell): weights and transforms as two bf16 planes, products hi.hi + hi.mid +
+// mid.hi.  Each operand is off by <= 2^-18 relative and the dropped mid.mid term is <= 2^-18, so a coordinate moves by at most
+// 3 x 2^-18 (|v| + |t_j|) and the position by sqrt(3) times that = 2.0e-5 (|v| + max_j |t_j|) in the worst case of every rounding
+// pointing the same way.  The roundings are independent: over 3.4e5 vertex samples of ordinary and wild poses the worst error is
+// 0.27 of that bound (scripts/emulate_lbs_fixup.py skin); the band allows half of it, twice the worst case seen.
+constexpr float LBS_SKIN_ERR = 1.0e-5f;
+// The fix-up queue is LBS_FIX_NQ sub-queues, a workgroup appends to sub-queue blockIdx % NQ: one counter for the whole launch made
+// every append (and, in the first version, every processed vertex) an atomic on ONE address - ~12 ns each at the L2, 190 us for
+// 16 000 vertices.  Counters sit 128 bytes apart: fix_stats[LBS_FIX_CNT0 + 32 q]; fix_stats[0] counts the vertices re-evaluated
+// inside the fused kernel (a full sub-queue).
+constexpr int LBS_FIX_NQ = 64;
+constexpr int LBS_FIX_CNT0 = 32;
+constexpr int LBS_FIX_STATS_INTS = LBS_FIX_CNT0 + 32 * LBS_FIX_NQ;
 
 }  // namespace
 
+// Skinning of the count-only tiles of the mixed blend on the matrix pipe (see lbs_epilogue_cell): T = W x A', W = the tile's skinning
+// weights [32 vertices x the joints of the tile's list], A' = the bodies' joint transforms premultiplied by the agent's
+// canonical-frame -> SDF-cell map, both as two bf16 planes.  One v_mfma_f32_32x32x16_bf16 k-step covers EIGHT joints of the list
+// with both planes of A' folded into K: lane half 0 holds (W_hi | A'_hi), lane half 1 (W_hi | A'_mid), so one MFMA yields
+// W_hi A'_hi + W_hi A'_mid; a second one with (W_mid | 0) on the same A' registers adds W_mid A'_hi.
+//   skinB  [bt][joint][plane][n] 8 x bf16 = entries (a, c) of rows a = 0, 1, then [bt][joint][plane][n] 4 x bf16 = row a = 2
+//   skinW  [ks_off[vt] + ks][operand 0 | 1][64 lanes] 8 x bf16, lane (h, row): operand 0 = W_hi[row][list[8 ks + e]] in both halves,
+//          operand 1 = W_mid in half 0, zero in half 1
+constexpr int SKIN_BT_A = NJ * 2 * 32;            // 16-byte records of rows a = 0, 1 per 32-body tile
+constexpr int SKIN_BT_BYTES = NJ * 2 * 32 * 24;   // both parts
+
 struct egx_body_model {
   int V = 0, NVT = 0, NW = 0, M = 0, NP = 0;
+  float* dirs_rm = nullptr;    // [NVT*32 rows][3 coords][KDIM] fp32, vertex-major: what the fp32 re-evaluation of single vertices reads (lbs_fix_one)
+  bf16x8* skinW = nullptr;     // matrix-pipe skinning weights (see SKIN_BT_BYTES)
+  int* skin_ks_off = nullptr;  // [NVT+1] k-steps (8 joints of the tile's list each) before tile vt
   f32x4* dirs = nullptr;       // [NVT][59][3][64] float4 (fp32 blend)
   bf16x8* dirs3 = nullptr;     // [NVT][30 k-steps][3 planes][3 coords][64 lanes] 8 x bf16 (bf16x3 blend)
   bf16x8* dirs4 = nullptr;     // [NVT][96 pieces][64 lanes] 8 x 16 bit (mixed blend, mode 3: see M4_BASE_PIECES)
@@ -143,6 +184,34 @@ struct egx_body_model {
   float cull_ref_margin = 0.f;              // blend-shape margin of the median tile at the reference pose (metres)
 };
 
+// Rotation matrix of joint j of one body from its parameter row x[93] (transl 3 | global orient 3 | body pose 63 | hand PCA 12 + 12;
+// jaw and eyes - joints 22..24 - have no field: identity): axis-angle -> smplx batch_rodrigues (angle = ||a + 1e-8||).
+__device__ __forceinline__ void lbs_joint_rotation(const PoseConsts* __restrict__ pc, const float* __restrict__ x, int j, float (&R)[9]) {
+  float a[3] = {0.f, 0.f, 0.f};
+  if (j == 0) {
+    a[0] = x[3]; a[1] = x[4]; a[2] = x[5];
+  } else if (j <= 21) {
+    a[0] = x[6 + 3 * (j - 1)]; a[1] = x[7 + 3 * (j - 1)]; a[2] = x[8 + 3 * (j - 1)];
+  } else if (j >= 25) {
+    const int side = (j >= 40) ? 1 : 0;
+    const int o = 3 * (j - (side ? 40 : 25));
+    const float* comps = pc->hand_comps + side * 12 * 45;
+    const float* pca = x + 69 + side * 12;
+    for (int c = 0; c < 3; ++c) {
+      float s = 0.f;
+      for (int k = 0; k < 12; ++k) s += pca[k] * comps[k * 45 + o + c];
+      a[c] = s + pc->hand_mean[side * 45 + o + c];
+    }
+  }
+  const float ex = a[0] + 1e-8f, ey = a[1] + 1e-8f, ez = a[2] + 1e-8f;
+  const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+  const float rx = a[0] / angle, ry = a[1] / angle, rz = a[2] / angle;
+  const float sn = sinf(angle), cs = 1.f - cosf(angle);
+  R[0] = 1.f + cs * (-(ry * ry + rz * rz)); R[1] = -sn * rz + cs * (rx * ry);     R[2] = sn * ry + cs * (rx * rz);
+  R[3] = sn * rz + cs * (rx * ry);          R[4] = 1.f + cs * (-(rx * rx + rz * rz)); R[5] = -sn * rx + cs * (ry * rz);
+  R[6] = -sn * ry + cs * (rx * rz);         R[7] = sn * rx + cs * (ry * rz);      R[8] = 1.f + cs * (-(rx * rx + ry * ry));
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernel 1: per-body pose features, rigid chain, joint transforms
 // ------------------------------------------------------------------------------------------------
@@ -159,12 +228,18 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
                                                              const int* __restrict__ agent_of_slot /* culled launches: slot order */,
                                                              float* __restrict__ fvec /* [64][Bp] |beta|, ||R_j - I||_F or null */,
                                                              float* __restrict__ jpos /* [55][3][Bp] posed joints + transl or null */,
-                                                             int Bp) {
+                                                             int Bp,
+                                                             float* __restrict__ fix_e /* [Bp] per slot: position error bound of the mixed blend (metres) or null */,
+                                                             int* __restrict__ fix_stats /* [1] cleared here, or null */,
+                                                             unsigned short* __restrict__ skinB /* matrix-pipe skinning operands (see SKIN_BT_BYTES) or null */,
+                                                             f32x4* __restrict__ cinit /* [Bp] per slot: cell coordinates of the body's translation */,
+                                                             const float* __restrict__ R0, const float* __restrict__ T0, SdfDev sdf) {
   __shared__ float sR[4][NJ][9];
   __shared__ float sJ[4][NJ][3];
   __shared__ float sG[4][NJ][12];
   __shared__ __attribute__((aligned(16))) unsigned short sF3[4][3][KS3 * 16];  // bf16x3 planes of the 4 bodies of the block
   __shared__ __attribute__((aligned(16))) unsigned short sF4[4][KS3 * 16];     // fp16 values (mixed blend, k-steps 1..28)
+  __shared__ __attribute__((aligned(16))) unsigned short sA[4][NJ][2][16];   // [body][joint][plane][(a, c) | 4 pad]: the skinning operands A' (32-byte rows: the 16-byte LDS reads below need the alignment)
   const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
   // a block works on four SLOTS of the operand buffers; slot s holds body agent_of_slot[s / fpa] * fpa + s % fpa (identity
   // without the table): inputs and per-body outputs are addressed by body, the GEMM operands by slot
@@ -173,6 +248,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
   const int ss = live ? slot : B - 1;
   const int b = agent_of_slot ? agent_of_slot[ss / fpa] * fpa + ss % fpa : ss;
   if (zero_counts && live && j == 0) zero_counts[b] = 0;   // the SDF epilogue of the skinning kernel adds to these
+  if (fix_stats && blockIdx.x == 0 && threadIdx.x <= LBS_FIX_NQ) fix_stats[threadIdx.x == 0 ? 0 : LBS_FIX_CNT0 + 32 * (threadIdx.x - 1)] = 0;
   const int bb = b;
   const float* x = xb + (size_t)bb * EGX_XB_DIM;
   const float* be = betas + (size_t)(bb / fpa) * 10;
@@ -194,6 +270,9 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
   };
   float R[9], Jr[3];
   if (j < NJ) {
+    {
+    // (lbs_joint_rotation, spelled out: through the shared function the compiler contracts these products differently - last-bit
+    // changes of R that the egosensing rays, aimed by eye landmarks centimetres apart, amplify past the parity floor)
     float a[3] = {0.f, 0.f, 0.f};
     if (j == 0) {
       a[0] = x[3]; a[1] = x[4]; a[2] = x[5];
@@ -210,7 +289,6 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
         a[c] = s + pc->hand_mean[side * 45 + o + c];
       }
     }
-    // smplx batch_rodrigues: angle = ||a + 1e-8||
     const float ex = a[0] + 1e-8f, ey = a[1] + 1e-8f, ez = a[2] + 1e-8f;
     const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
     const float rx = a[0] / angle, ry = a[1] / angle, rz = a[2] / angle;
@@ -218,6 +296,7 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
     R[0] = 1.f + cs * (-(ry * ry + rz * rz)); R[1] = -sn * rz + cs * (rx * ry);     R[2] = sn * ry + cs * (rx * rz);
     R[3] = sn * rz + cs * (rx * ry);          R[4] = 1.f + cs * (-(rx * rx + rz * rz)); R[5] = -sn * rx + cs * (ry * rz);
     R[6] = -sn * ry + cs * (rx * rz);         R[7] = sn * rx + cs * (ry * rz);      R[8] = 1.f + cs * (-(rx * rx + ry * ry));
+    }
     for (int c = 0; c < 3; ++c) {
       float s = pc->J_template[j * 3 + c];
       for (int k = 0; k < 10; ++k) s += be[k] * pc->J_shapedirs[(j * 3 + c) * 10 + k];
@@ -225,6 +304,20 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       sJ[w][j][c] = s;
     }
     for (int e = 0; e < 9; ++e) sR[w][j][e] = R[e];
+  }
+  if (fix_e) {   // wave-uniform: every lane of the body's wave takes part in the reduction
+    float q = 0.f;
+    if (j >= 1 && j < NJ) {
+      for (int e = 0; e < 9; ++e) {
+        const float dlt = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        q += dlt * dlt;
+      }
+      q *= pc->fix_c[j] * pc->fix_c[j];
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (live && j == 0) fix_e[slot] = LBS_FIX_KAPPA * 0.00048828125f * sqrtf(q) + LBS_FIX_SLACK_M;
+  }
+  if (j < NJ) {
     if (live && fvec) {
       if (j < 10) fvec[(size_t)j * Bp + slot] = fabsf(be[j]);
       if (j >= 1 && (j < 22 || j > 24)) {
@@ -310,6 +403,61 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  if (skinB) {   // block-uniform
+    // A'_j = Mc A_j: the joint transform followed by the agent's canonical frame -> SDF-cell map (the folded affine map of the
+    // fused kernel's epilogue scaled by 1/4, egx_sdf_coarse_at_cell); the constant part Mc transl + tc stays in fp32 (cinit)
+    const int ag = bb / fpa;
+    float Mc[9], tcv[3];
+    {
+      const float kk[3] = {sdf.scale * (float)sdf.d0 * 0.5f, sdf.scale * (float)sdf.d1 * 0.5f, sdf.scale * (float)sdf.d2 * 0.5f};
+      const float cc[3] = {sdf.cx, sdf.cy, sdf.cz};
+      const float dd[3] = {(float)sdf.d0, (float)sdf.d1, (float)sdf.d2};
+      for (int a = 0; a < 3; ++a) {
+        for (int e = 0; e < 3; ++e) Mc[a * 3 + e] = 0.25f * (kk[a] * (R0 ? R0[(size_t)ag * 9 + a * 3 + e] : ((a == e) ? 1.f : 0.f)));
+        const float tw = kk[a] * ((T0 ? T0[(size_t)ag * 3 + a] : 0.f) - cc[a]) + (dd[a] - 1.f) * 0.5f;
+        tcv[a] = fmaf(0.25f, tw, 1.f);
+      }
+    }
+    float tn = 0.f;
+    if (j < NJ) {
+      float Arow[3][4];
+      for (int r = 0; r < 3; ++r) {
+        Arow[r][0] = G[r * 4 + 0]; Arow[r][1] = G[r * 4 + 1]; Arow[r][2] = G[r * 4 + 2];
+        Arow[r][3] = G[r * 4 + 3] - (G[r * 4 + 0] * Jr[0] + G[r * 4 + 1] * Jr[1] + G[r * 4 + 2] * Jr[2]);
+      }
+      tn = sqrtf(Arow[0][3] * Arow[0][3] + Arow[1][3] * Arow[1][3] + Arow[2][3] * Arow[2][3]);
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 4; ++c) {
+          const float v = Mc[a * 3 + 0] * Arow[0][c] + Mc[a * 3 + 1] * Arow[1][c] + Mc[a * 3 + 2] * Arow[2][c];
+          unsigned short h[3];
+          egx_bf16_split3(v, h);
+          sA[w][j][0][a * 4 + c] = h[0];
+          sA[w][j][1][a * 4 + c] = h[1];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) tn = fmaxf(tn, __shfl_xor(tn, o));
+    if (live && j == 0) {
+      f32x4 ci;
+      for (int a = 0; a < 3; ++a) ci[a] = fmaf(Mc[a * 3 + 0], x[0], fmaf(Mc[a * 3 + 1], x[1], fmaf(Mc[a * 3 + 2], x[2], tcv[a])));
+      ci[3] = 0.f;
+      cinit[slot] = ci;
+      // the two-plane products of the skinning add to the body's position error bound (see LBS_SKIN_ERR)
+      if (fix_e) fix_e[slot] += LBS_SKIN_ERR * (pc->v_norm_max + tn);
+    }
+    __syncthreads();
+    // per 32-body tile: [joint][plane][n] 16 bytes (rows a = 0, 1) then [joint][plane][n] 8 bytes (row a = 2); the four bodies of the
+    // block are neighbours in n
+    for (int c = threadIdx.x; c < NJ * 2 * 4; c += 256) {
+      const int wb = c & 3, pl = (c >> 2) & 1, jt = c >> 3;
+      const int body = blockIdx.x * 4 + wb;   // slot
+      if (body < B) {
+        unsigned short* base = skinB + (size_t)(body >> 5) * (SKIN_BT_BYTES / 2);
+        const size_t rec = ((size_t)jt * 2 + pl) * 32 + (body & 31);
+        *reinterpret_cast<int4*>(base + rec * 8) = *reinterpret_cast<const int4*>(&sA[wb][jt][pl][0]);
+        *reinterpret_cast<int2*>(base + (size_t)SKIN_BT_A * 8 + rec * 4) = *reinterpret_cast<const int2*>(&sA[wb][jt][pl][8]);
+      }
+    }
+  }
   if (j < NJ && live) {
     // relative transform: translation column minus R_g * rest joint (smplx batch_rigid_transform)
     for (int r = 0; r < 3; ++r) {
@@ -365,6 +513,20 @@ struct LbsParams {
   const int* items;           // [8][items_stride] codes tile_index * nbg + body_group, or null (walk every item)
   const int* item_counts;     // [8]
   int items_stride;
+  // fix-up of the mixed blend (see LBS_FIX_KAPPA)
+  const float* fix_e;         // [Bp] per slot: position error bound (metres)
+  const float* sdf_aux;       // aux floats of the SDF's bracket table (egx_sdf_aux_offset): [0..2] largest sample step per axis
+  int* fix_stats;             // [0] vertices re-evaluated inside the fused kernel, [LBS_FIX_CNT0 + 32 q] fill of sub-queue q (cleared by the pose kernel)
+  const float* dirs_rm;       // vertex-major fp32 bases (fix-up)
+  const PoseConsts* pc;       // pose constants (fix-up: the body's rotation features are recomputed from xb)
+  const float* betas;         // [A][10]
+  int2* fixq;                 // fix-up queue: LBS_FIX_NQ sub-queues of fixq_cap entries (vertex tile * 32 + row, operand slot)
+  int fixq_cap;
+  // matrix-pipe skinning of the count-only tiles (lbs_epilogue_cell)
+  const bf16x8* skinW;        // [k-step][2][64] (see SKIN_BT_BYTES)
+  const int* skin_ks_off;     // [NVT+1]
+  const bf16x8* skinB;        // [bt] SKIN_BT_BYTES each
+  const f32x4* cinit;         // [Bp]
 };
 
 // one v_fma_f32, opaque to the SLP vectoriser (which would pair adjacent rows into v_pk_fma_f32 again)
@@ -394,6 +556,8 @@ struct LbsWave {
   int* s_slot;         // [row] pick slot or -1
   unsigned* s_masks;   // [0] rows with a pick slot, [1] rows in the SDF count
   int* s_cnt;          // [q*32 + n] penetration count of this item's 64 bodies
+  unsigned* s_fixmap;  // [q*32 + n] bit r = vertex row r of that body awaits the fp32 re-evaluation (mixed blend only)
+  float* s_thr;        // [q*32 + n] |SDF value| below which the cheap evaluation does not decide (mixed blend only)
   float* lds;          // vertex transpose buffer (vertex-writing variants)
   f32x4* s_queue;      // undecided SDF points (voxel x, y, z, counter slot)
   int qn;              // queued points (wave-uniform)
@@ -417,6 +581,7 @@ __device__ __forceinline__ LbsWave lbs_wave_init(char* my, int lane) {
   w.s_cnt = reinterpret_cast<int*>(w.s_masks + 4);
   w.lds = reinterpret_cast<float*>(my + LBS_META_BYTES);
   w.s_queue = reinterpret_cast<f32x4*>(my + LBS_META_BYTES);
+  w.s_fixmap = nullptr; w.s_thr = nullptr;
   w.qn = 0;
   w.s_cnt[lane] = 0;
   return w;
@@ -454,8 +619,179 @@ __device__ unsigned long long g_lbs_t[16];
 #endif
 
 // Epilogue of one work item: each lane owns 16 vertices (rows) x 2 bodies (column n of tiles bt0, bt0+1).
-template <bool WRITE_VERTS, bool DO_SDF, int RB, int QCAP, int NB = LBS_NB>
-__device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32x16 (&acc)[3][NB], int vt, int bt0, int JT) {
+__device__ __forceinline__ float lbs_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// v_posed of one vertex from the MFMA-ordered three-plane operand images (hi + mid + lo = the fp32 value exactly): 60 lanes take one
+// 8-column fragment each.  720 scattered cache lines per vertex - only the overflow path of lbs_fix_process (a full fix-up queue)
+// uses it, because it is compact code inside the fused kernel; egx_lbs_fix_kernel reads the vertex-major copy instead.
+__device__ __forceinline__ void lbs_fix_blend_planes(const LbsParams& p, int lane, int vt, int row, int bt, int n, float (&v)[3]) {
+  v[0] = v[1] = v[2] = 0.f;
+  if (lane < 2 * KS3) {
+    const int sidx = lane >> 1, hf = lane & 1;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.f;
+#pragma unroll
+    for (int pl = 2; pl >= 0; --pl) {   // lo + mid first: their sum is exact, then + hi = the fp32 value
+      const bf16x8 fr = p.feat3[(((size_t)bt * KS3 + sidx) * 3 + pl) * 64 + hf * 32 + n];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += egx_bf16_to_f32((unsigned short)fr[e]);
+    }
+    // column 470 (the template's third bf16 term, switched on for the two-plane product) is part of column 469 here
+    if (sidx == KS3 - 1 && hf == 0) f[6] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float b[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] = 0.f;
+#pragma unroll
+      for (int pl = 2; pl >= 0; --pl) {
+        const bf16x8 br = p.dirs3[((((size_t)vt * KS3 + sidx) * 3 + pl) * 3 + c) * 64 + hf * 32 + row];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] += egx_bf16_to_f32((unsigned short)br[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c] = fmaf(f[e], b[e], v[c]);
+    }
+  }
+}
+
+// fp32 re-evaluation of ONE vertex the cheap evaluation of the mixed blend could not decide (see LBS_FIX_KAPPA): row `row` of vertex
+// tile vt for the body in operand slot `slot`.  The whole wave works on it: lane j takes joint j's share of the blend product
+// (below), the sums are reduced across the wave, lane jj < JT applies joint jl[jj] of the tile's list (weight Wt[jj * 32 + row]),
+// and the trilinear sample decides.  ~70 cache lines per vertex (the first version read the MFMA-ordered operand images: 720
+// lines, and 22 000 vertices of a launch with every body inside the obstacle took 330 us).
+// Returns -trilinear (wave-uniform); negative = the vertex counts.
+template <bool VERTEX_MAJOR>
+__device__ __forceinline__ float lbs_fix_one(const LbsParams& p, int lane, int vt, int row, int slot, int JT, const int* jl, const float* Wt) {
+  const int bt = slot >> 5, n = slot & 31;
+  const int body = p.agent_of_slot ? p.agent_of_slot[slot / p.fpa] * p.fpa + slot % p.fpa : slot;
+  const int ag = body / p.fpa;
+  // v_posed = v_template + shape offsets + pose correctives, in fp32 from the vertex-major bases: lane j owns joint j - it
+  // recomputes the joint's rotation from the body's parameter row (the pose kernel's formulas) and multiplies its nine R - I
+  // entries with the vertex's nine columns of that joint (36 contiguous bytes per coordinate); lane 0 (the global orientation is
+  // not a blend feature) takes the ten shape columns and the template
+  float v[3] = {0.f, 0.f, 0.f};
+  if constexpr (!VERTEX_MAJOR) {
+    lbs_fix_blend_planes(p, lane, vt, row, bt, n, v);
+  } else {
+    const float* x = p.xb + (size_t)body * EGX_XB_DIM;
+    const float* base = p.dirs_rm + ((size_t)vt * 32 + row) * 3 * KDIM;
+    if (lane == 0) {
+      const float* be = p.betas + (size_t)ag * 10;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float acc = base[c * KDIM + KACT];
+        for (int k = 0; k < 10; ++k) acc = fmaf(be[k], base[c * KDIM + k], acc);
+        v[c] = acc;
+      }
+    } else if (lane < NJ && (lane < 22 || lane > 24)) {
+      float R[9];
+      lbs_joint_rotation(p.pc, x, lane, R);
+      const int k0 = 10 + egx_compact_joint(lane) * 9;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc = fmaf(R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f), base[c * KDIM + k0 + e], acc);
+        v[c] = acc;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] = lbs_wave_sum(v[c]);
+  // skinning: one joint of the tile's list per lane
+  float o[3] = {0.f, 0.f, 0.f};
+  if (lane < JT) {   // JT <= 55 < 64
+    const int j = jl[lane] & 0xff;
+    const float wv = Wt[lane * 32 + row];
+    const f32x4* Aq = p.A4 + ((size_t)bt * NJ + j) * 3 * 32 + n;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const f32x4 ar = Aq[a * 32];
+      o[a] = wv * fmaf(ar[0], v[0], fmaf(ar[1], v[1], fmaf(ar[2], v[2], ar[3])));
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) o[a] = lbs_wave_sum(o[a]) + p.xb[(size_t)body * EGX_XB_DIM + a];
+  // canonical frame -> world -> voxel coordinates: the folded affine map of the epilogue
+  const float kk[3] = {p.sdf.scale * (float)p.sdf.d0 * 0.5f, p.sdf.scale * (float)p.sdf.d1 * 0.5f, p.sdf.scale * (float)p.sdf.d2 * 0.5f};
+  const float cc[3] = {p.sdf.cx, p.sdf.cy, p.sdf.cz};
+  const float dd[3] = {(float)p.sdf.d0, (float)p.sdf.d1, (float)p.sdf.d2};
+  float vox[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float Mw[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) Mw[e] = kk[a] * (p.R0 ? p.R0[(size_t)ag * 9 + a * 3 + e] : ((a == e) ? 1.f : 0.f));
+    const float tw = kk[a] * ((p.T0 ? p.T0[(size_t)ag * 3 + a] : 0.f) - cc[a]) + (dd[a] - 1.f) * 0.5f;
+    vox[a] = fmaf(Mw[0], o[0], fmaf(Mw[1], o[1], fmaf(Mw[2], o[2], tw)));
+  }
+  return egx_sdf_neg_trilinear_at(p.sdf, __builtin_amdgcn_fmed3f(vox[0], 0.f, (float)(p.sdf.d0 - 1)), __builtin_amdgcn_fmed3f(vox[1], 0.f, (float)(p.sdf.d1 - 1)),
+                                  __builtin_amdgcn_fmed3f(vox[2], 0.f, (float)(p.sdf.d2 - 1)));
+}
+
+// What a wave does with the vertices of its item that fell into the band (bit r of s_fixmap[q*32 + n] = row r of the item's
+// vertex tile for body (q, n)): they go to the launch's fix-up queue - (vertex tile, row, operand slot) - which
+// egx_lbs_fix_kernel works through after the fused kernel, one wave per vertex, thousands of them side by side.  Doing it here
+// instead (a whole wave busy for several dependent round trips per vertex while the three other waves of its workgroup wait at
+// the next item's barrier) cost 55 us of a 700 us launch for 3 300 vertices; the queue costs one atomic per wave and item
+// that has any.  Only when the queue is full are they re-evaluated on the spot.
+template <int NB>
+__device__ __forceinline__ void lbs_fix_process(const LbsParams& p, const LbsWave& w, int vt, int bt0, int JT) {
+  const int lane = w.lane;
+  unsigned mybits = lane < 32 * NB ? w.s_fixmap[lane] : 0u;
+  if (mybits != 0u) w.s_fixmap[lane] = 0u;
+  unsigned long long pend = __ballot(mybits != 0u);
+  // exclusive prefix of the per-lane counts over the (few) lanes that hold any
+  const int mine = __popc(mybits);
+  int total = 0, my_off = 0;
+  for (unsigned long long m = pend; m != 0ull; m &= m - 1) {
+    const int sl = __builtin_ctzll(m);
+    if (lane == sl) my_off = total;
+    total += __builtin_amdgcn_readlane(mine, sl);
+  }
+  int base = 0;
+#ifndef EGX_LBS_FIX_IN_KERNEL   // development builds (A/B timing): never queue
+  const int sq = blockIdx.x % LBS_FIX_NQ;
+  int2* q = p.fixq + (size_t)sq * p.fixq_cap;
+  if (lane == 0) base = atomicAdd(p.fix_stats + LBS_FIX_CNT0 + 32 * sq, total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (base + total <= p.fixq_cap) {
+    const int slot = min((bt0 + (lane >> 5)) * 32 + (lane & 31), p.B - 1);
+    for (int k = 0; mybits != 0u; ++k) {
+      const int row = __builtin_ctz(mybits);
+      mybits &= mybits - 1;
+      q[base + my_off + k] = make_int2(vt * 32 + row, slot);
+    }
+    return;
+  }
+  // full: what this wave reserved below the capacity is marked void (egx_lbs_fix_kernel skips it), its vertices are done here
+  for (int i = base + lane; i < min(base + total, p.fixq_cap); i += 64) q[i] = make_int2(-1, 0);
+#endif
+  while (pend != 0ull) {
+    const int sl = __builtin_ctzll(pend);
+    pend &= pend - 1;
+    unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)mybits, sl);
+    const int slot = min((bt0 + (sl >> 5)) * 32 + (sl & 31), p.B - 1);
+    while (bits != 0u) {
+      const int row = __builtin_ctz(bits);
+      bits &= bits - 1;
+      const float sv = lbs_fix_one<false>(p, lane, vt, row, slot, JT, w.s_jl, w.s_W);
+      if (lane == 0) {
+        if (sv < 0.f) atomicAdd(&w.s_cnt[sl], 1);
+        atomicAdd(p.fix_stats, 1);
+      }
+    }
+  }
+}
+
+template <bool WRITE_VERTS, bool DO_SDF, int RB, int QCAP, int NB = LBS_NB, bool FIX = false>
+__device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32x16 (&acc)[3][NB], int vt, int bt0, int JT, bool fix_on = false) {
   const int lane = w.lane, n = w.n, half = w.half;
   float* s_W = w.s_W; int* s_jl = w.s_jl; int* s_slot = w.s_slot; unsigned* s_masks = w.s_masks; int* s_cnt = w.s_cnt;
   float* lds = w.lds; f32x4* s_queue = w.s_queue;
@@ -475,6 +811,21 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
     tr[q][1] = p.xb[(size_t)bb * EGX_XB_DIM + 1];
     tr[q][2] = p.xb[(size_t)bb * EGX_XB_DIM + 2];
   }
+  // mixed blend, count-only tiles: |SDF value| below which the cheap evaluation of a body's vertices does not decide = the
+  // body's position error bound (pose kernel) x the most the interpolated value can change per metre (aux[3] of the table)
+  [[maybe_unused]] float thr[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) thr[q] = 0.f;
+  if constexpr (FIX && DO_SDF) {
+    if (fix_on) {
+      const float lip = p.sdf_aux[3];   // steepest slope of the interpolated field, value per metre
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        thr[q] = p.fix_e[min((bt0 + q) * 32 + n, p.B - 1)] * lip;
+        w.s_thr[q * 32 + n] = thr[q];   // both lane halves write the same value
+      }
+    }
+  }
   // Skinning walks the tile's joint list: one transform fetch per (joint, body) - prefetched one joint ahead - applied
   // to the lane's 16 vertices with their weights from LDS (o = sum_j w_j (A_j v + t_j); rows whose weights are all zero
   // are skipped in groups of four).  The accumulators already hold v_template + offsets (template column of the GEMM).
@@ -484,7 +835,18 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
       const int idx = base + lane;
       if (idx < count) {
         const f32x4 e = s_queue[idx];
-        if (egx_sdf_neg_trilinear_at(p.sdf, e[0], e[1], e[2]) < 0.f) atomicAdd(&s_cnt[__float_as_int(e[3])], 1);
+        const int code = __float_as_int(e[3]);   // counter slot | vertex row << 8
+        const float sv = egx_sdf_neg_trilinear_at(p.sdf, e[0], e[1], e[2]);
+        if constexpr (FIX) {
+          const float t = fix_on ? w.s_thr[code & 63] : 0.f;
+          if (sv < -t) atomicAdd(&s_cnt[code & 63], 1);
+          else if (fix_on && sv <= t) {
+            const int rr = (code >> 8) & 15;   // accumulator row -> row of the vertex tile
+            atomicOr(&w.s_fixmap[code & 63], 1u << ((rr & 3) + 8 * (rr >> 2) + 4 * (code >> 12)));
+          }
+        } else {
+          if (sv < 0.f) atomicAdd(&s_cnt[code & 63], 1);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -615,15 +977,21 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
 #pragma unroll
         for (int r = r0; r < r0 + RB; ++r) {
           const bool on = (mine >> ((r & 3) + 8 * (r >> 2))) & 1u;
-          const bool inside = mm[r - rb0].x > 0.f;
+          const bool inside = mm[r - rb0].x > thr[q];
           cnt += (on && inside) ? 1 : 0;
-          const bool und = on && !inside && !(mm[r - rb0].y < 0.f);
+          const bool und = on && !inside && !(mm[r - rb0].y < -thr[q]);
           const unsigned long long bm = __ballot(und);
           if (bm != 0) {
             const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
-            if (und)
+            if (und) {
+              // counter slot | accumulator row r << 8 | lane half << 12, formed here (as loop invariants the sixteen per-lane
+              // codes of a body tile would be kept alive across the whole item)
+              int ln = lane;
+              asm volatile("" : "+v"(ln));
               s_queue[pos] = f32x4{__builtin_amdgcn_fmed3f(world(r, 0), 0.f, hx), __builtin_amdgcn_fmed3f(world(r, 1), 0.f, hy),
-                                   __builtin_amdgcn_fmed3f(world(r, 2), 0.f, hz), __int_as_float(q * 32 + n)};
+                                   __builtin_amdgcn_fmed3f(world(r, 2), 0.f, hz),
+                                   __int_as_float((q * 32 + (ln & 31)) | (r << 8) | ((ln >> 5) << 12))};
+            }
             qn += __popcll(bm);
           }
         }
@@ -689,8 +1057,15 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
   if (DO_SDF) {
     if (!WRITE_VERTS) { sdf_flush(qn); qn = 0; }
     __builtin_amdgcn_wave_barrier();
-    const int c = s_cnt[lane];            // lane = q*32 + n: one global atomic per body and item
-    s_cnt[lane] = 0;
+    if constexpr (FIX) {
+      if (fix_on) {   // wave-uniform
+        const unsigned fb = lane < 32 * NB ? w.s_fixmap[lane] : 0u;
+        if (__ballot(fb != 0u) != 0ull) lbs_fix_process<NB>(p, w, vt, bt0, JT);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    const int c = lane < 32 * NB ? s_cnt[lane] : 0;   // lane = q*32 + n: one global atomic per body and item
+    if (lane < 32 * NB) s_cnt[lane] = 0;
     const int sd = (bt0 + (lane >> 5)) * 32 + (lane & 31);
     if (c != 0 && sd < p.B && lane < 32 * NB) {
       const int bd = p.agent_of_slot ? p.agent_of_slot[sd / p.fpa] * p.fpa + sd % p.fpa : sd;
@@ -703,6 +1078,202 @@ __device__ __forceinline__ void lbs_epilogue(const LbsParams& p, LbsWave& w, f32
   et[2] += LBS_NOW() - f0;
   et[3] += 1;
 #endif
+  w.qn = qn;
+}
+
+#define LBS_MFMA_RESULT_WAIT()                   \
+  do {                                           \
+    __builtin_amdgcn_sched_barrier(0);           \
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);           \
+  } while (0)
+
+// Epilogue of a COUNT-ONLY tile of the mixed blend (mode 3; a tile after the ones that hold picked vertices, joint list of at most
+// eight): skinning on the matrix pipe, straight into SDF-cell coordinates.
+//   o_cell[v, body] = cinit[body] + sum_j W[v, j] (A'_j [v_posed; 1]),   A'_j = Mc A_j   (pose kernel: skinB, cinit)
+// is evaluated as T = W x A' - twelve 32 x 32 outputs per 32-body tile, one per entry (a, c) of the 3 x 4 transform, K = the eight
+// joints of the tile's list x the two planes of A' (see SKIN_BT_BYTES), two MFMAs each - followed by
+// o[a] = T[a][0] x + T[a][1] y + T[a][2] z + T[a][3] on the accumulators of the blend GEMM, which already hold (x, y, z) in the
+// same lane layout: 9 FMAs per (vertex, body) instead of 12 per (vertex, body, joint), and no canonical -> cell map (9 more)
+// afterwards.  The operands of a body tile arrive in ONE burst (24 bytes per joint and lane, joint-major) and are turned into
+// MFMA operands (entry-major, eight joints each) by 48 v_perm_b32: one L2 round trip per body tile instead of one per joint.
+// What it costs: 24 MFMAs per body tile on a matrix pipe that was 23 % busy, and a position error of up to LBS_SKIN_ERR (|v| + |t|),
+// which the fix-up band absorbs - the result only classifies, lbs_fix_process decides the close calls.
+template <int RB, int QCAP, int NB>
+__device__ __forceinline__ void lbs_epilogue_cell(const LbsParams& p, LbsWave& w, f32x16 (&acc)[3][NB], int vt, int bt0, int JT) {
+  int lane = w.lane;
+  asm volatile("" : "+v"(lane));   // per-lane operand addresses are formed per item (not kept alive as invariants of the persistent loop)
+  const int n = lane & 31, half = lane >> 5;
+  int* s_cnt = w.s_cnt;
+  f32x4* s_queue = w.s_queue;
+  const int num_bt = (p.B + 31) >> 5;
+  int qn = w.qn;
+  const unsigned sdf_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)w.s_masks[1]);
+  const int ks0 = __builtin_amdgcn_readfirstlane(p.skin_ks_off[vt]);   // JT <= 8 here: one k-step (the caller sends longer lists to the VALU epilogue)
+  const float lip = p.sdf_aux[3];   // steepest slope of the interpolated field, value per metre
+  const float hx = (float)(p.sdf.d0 - 1), hy = (float)(p.sdf.d1 - 1), hz = (float)(p.sdf.d2 - 1);
+  auto sdf_flush = [&](int count) {
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < count; base += 64) {
+      const int idx = base + lane;
+      if (idx < count) {
+        const f32x4 e = s_queue[idx];
+        const int code = __float_as_int(e[3]);   // counter slot | accumulator row << 8 | lane half << 12
+        const float sv = egx_sdf_neg_trilinear_at(p.sdf, e[0], e[1], e[2]);
+        const float t = w.s_thr[code & 63];
+        if (sv < -t) atomicAdd(&s_cnt[code & 63], 1);
+        else if (sv <= t) {
+          const int rr = (code >> 8) & 15;
+          atomicOr(&w.s_fixmap[code & 63], 1u << ((rr & 3) + 8 * (rr >> 2) + 4 * (code >> 12)));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // two 16-bit entries of neighbouring joints -> one operand register: v_perm_b32 picks the low (even entry) or high halves
+  auto pack2 = [](unsigned hi_joint, unsigned lo_joint, int odd) {
+    return odd ? __builtin_amdgcn_perm(hi_joint, lo_joint, 0x07060302u) : __builtin_amdgcn_perm(hi_joint, lo_joint, 0x05040100u);
+  };
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  // the tile's joint list (LDS, published by the blend's barriers) -> one register, read out lane by lane below: a load per
+  // entry in front of its records would make every body tile a chain of JT round trips again
+  const int jl_v = w.s_jl[min(lane, JT - 1)] & 0xff;
+  // the tile's weight operands: once per item
+  const bf16x8 W0 = p.skinW[((size_t)ks0 * 2 + 0) * 64 + lane], W1 = p.skinW[((size_t)ks0 * 2 + 1) * 64 + lane];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int slot = (bt0 + q) * 32 + n;
+    const bool bvalid = slot < p.B;
+    const f32x4 ci = p.cinit[bvalid ? slot : p.B - 1];
+    const float fe = p.fix_e[bvalid ? slot : p.B - 1];   // requested here, used after the skinning
+    // this lane's records: plane = lane half, body column n; record of joint j at index j * 64
+    const char* tile_base = reinterpret_cast<const char*>(p.skinB) + (size_t)min(bt0 + q, num_bt - 1) * SKIN_BT_BYTES;
+    const u32x4* recA = reinterpret_cast<const u32x4*>(tile_base) + half * 32 + n;
+    const u32x2* recB = reinterpret_cast<const u32x2*>(tile_base + (size_t)SKIN_BT_A * 16) + half * 32 + n;
+    float o[16][3];
+    {
+      // all twelve entries of the (up to) eight joints in ONE burst: 16 + 8 bytes per joint and lane
+      u32x4 RA[8];
+      u32x2 RC[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (e < JT) {   // scalar branch
+          const int j = __builtin_amdgcn_readlane(jl_v, e);
+          RA[e] = recA[j * 64];
+          RC[e] = recB[j * 64];
+        } else {        // the weights of the unused slots are zero: any finite operand does
+          RA[e] = u32x4{0u, 0u, 0u, 0u};
+          RC[e] = u32x2{0u, 0u};
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // records (joint-major) -> operands (entry-major, eight joints per operand): all twelve now, so that the 48 record registers
+      // are free before the first accumulators are
+      bf16x8 Bop[12];
+#pragma unroll
+      for (int cc = 0; cc < 12; ++cc) {
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          v[i] = cc < 8 ? pack2(RA[2 * i + 1][cc >> 1], RA[2 * i][cc >> 1], cc & 1) : pack2(RC[2 * i + 1][(cc - 8) >> 1], RC[2 * i][(cc - 8) >> 1], cc & 1);
+        Bop[cc] = __builtin_bit_cast(bf16x8, v);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        // two entries of the row at a time (32 accumulator registers live instead of 64): (translation, x) then (y, z);
+        // W_mid A'_hi first (the small term), then W_hi (A'_hi + A'_mid)
+        f32x16 Ta, Tb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Ta[r] = ci[a]; Tb[r] = 0.f; }
+        Ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1, Bop[a * 4 + 3], Ta, 0, 0, 0);
+        Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1, Bop[a * 4 + 0], Tb, 0, 0, 0);
+        Ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, Bop[a * 4 + 3], Ta, 0, 0, 0);
+        Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, Bop[a * 4 + 0], Tb, 0, 0, 0);
+        float oa[16];
+#pragma unroll
+        // The FMAs below are inline asm (lbs_fma: see there), which the compiler's hazard recogniser does not look into: the wait
+        // states between an MFMA and a VALU read of its result (software-managed on CDNA: up to 19 for a 16-pass MFMA) are put
+        // here by hand.  Without them the FMAs read accumulators the matrix pipe is still writing.
+        LBS_MFMA_RESULT_WAIT();
+        for (int r = 0; r < 16; ++r) oa[r] = lbs_fma(Tb[r], acc[0][q][r], Ta[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Ta[r] = 0.f; Tb[r] = 0.f; }
+        Ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1, Bop[a * 4 + 1], Ta, 0, 0, 0);
+        Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1, Bop[a * 4 + 2], Tb, 0, 0, 0);
+        Ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, Bop[a * 4 + 1], Ta, 0, 0, 0);
+        Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, Bop[a * 4 + 2], Tb, 0, 0, 0);
+#pragma unroll
+        LBS_MFMA_RESULT_WAIT();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r][a] = lbs_fma(Ta[r], acc[1][q][r], lbs_fma(Tb[r], acc[2][q][r], oa[r]));
+      }
+    }
+    // SDF: bracket lookups of all sixteen rows in one burst (cell coordinates are what the skinning produced), decisions with the
+    // body's band, undecided points to the wave's queue as clamped voxel coordinates 4 (cell - 1)
+    const unsigned mine = bvalid ? (sdf_mask >> (4 * half)) : 0u;
+    int cnt = 0;
+    float2 mm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mm[r] = egx_sdf_coarse_at_cell(p.sdf, o[r][0], o[r][1], o[r][2]);
+#ifdef EGX_LBS_THR0   // development builds (A/B timing): no band - the cheap evaluation decides everything
+    const float thr = 0.f * fe;
+#else
+    const float thr = fe * lip;
+#endif
+    w.s_thr[q * 32 + n] = thr;   // both lane halves write the same value
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += RB) {
+      if (qn + RB * 64 > QCAP) { sdf_flush(qn); qn = 0; }
+#pragma unroll
+      for (int r = r0; r < r0 + RB; ++r) {
+        const bool on = (mine >> ((r & 3) + 8 * (r >> 2))) & 1u;
+        const bool inside = mm[r].x > thr;
+        cnt += (on && inside) ? 1 : 0;
+        const bool und = on && !inside && !(mm[r].y < -thr);
+        const unsigned long long bm = __ballot(und);
+        if (bm != 0) {
+          const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+          if (und) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            s_queue[pos] = f32x4{__builtin_amdgcn_fmed3f(fmaf(4.f, o[r][0], -4.f), 0.f, hx), __builtin_amdgcn_fmed3f(fmaf(4.f, o[r][1], -4.f), 0.f, hy),
+                                 __builtin_amdgcn_fmed3f(fmaf(4.f, o[r][2], -4.f), 0.f, hz),
+                                 __int_as_float((q * 32 + (ln & 31)) | (r << 8) | ((ln >> 5) << 12))};
+          }
+          qn += __popcll(bm);
+        }
+      }
+    }
+    if (cnt != 0) {
+      int nn = n;
+      asm volatile("" : "+v"(nn));
+      atomicAdd(&s_cnt[q * 32 + nn], cnt);
+    }
+  }
+  sdf_flush(qn);
+  qn = 0;
+  __builtin_amdgcn_wave_barrier();
+  {
+    const unsigned fb = lane < 32 * NB ? w.s_fixmap[lane] : 0u;
+#ifdef EGX_LBS_NOFIXPROC   // development builds (A/B timing): the band is kept, what falls into it is dropped
+    if (fb != 0u) w.s_fixmap[lane] = 0u;
+#else
+    if (__ballot(fb != 0u) != 0ull) lbs_fix_process<NB>(p, w, vt, bt0, JT);
+#endif
+    __builtin_amdgcn_wave_barrier();
+  }
+  const int c = lane < 32 * NB ? s_cnt[lane] : 0;   // lane = q*32 + n: one global atomic per body and item
+  if (lane < 32 * NB) s_cnt[lane] = 0;
+  const int sd = (bt0 + (lane >> 5)) * 32 + (lane & 31);
+  if (c != 0 && sd < p.B && lane < 32 * NB) {
+    const int bd = p.agent_of_slot ? p.agent_of_slot[sd / p.fpa] * p.fpa + sd % p.fpa : sd;
+    atomicAdd(p.pene + bd, c);
+  }
+  __builtin_amdgcn_wave_barrier();
   w.qn = qn;
 }
 
@@ -840,7 +1411,8 @@ constexpr int LBS3_SHARED_BYTES = 2 * 18 * 1024 + 7424;                // stage 
 static_assert(Wg4Cfg<3>::STAGE_PIECES <= 18 && Wg4Cfg<2>::STAGE_PIECES <= 18, "stage ring");
 constexpr int LBS3_RB = 4;                                             // SDF rows per bracket batch
 constexpr int LBS3_QCAP = LBS3_RB * 64 + 64;
-constexpr int LBS3_WAVE_BYTES = 256 + LBS3_QCAP * 16;                  // s_cnt + queue
+// per-wave LDS of the fused3 kernels: penetration counters, fix-up bitmap, fix-up thresholds (32 x NB entries each), queue
+template <int NBW> constexpr int lbs3_wave_bytes() { return 3 * 128 * NBW + LBS3_QCAP * 16; }
 
 template <int NPL>
 __device__ __forceinline__ void lbs_blend_split(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave,
@@ -1084,7 +1656,8 @@ __device__ __forceinline__ void lbs_blend_split2_small(const LbsParams& p, f32x1
 // 168 registers, and the third wave per SIMD is what the latency chain of this kernel was missing - one workgroup per CU runs
 // the launch in 1.07 ms, two in 0.70 (profiles/r05_lbs_mixed.md section 5).
 template <int NBW> constexpr int lbs3_ring_bytes() { return NBW == 1 ? 2 * M4_RING_PIECES * 1024 : 2 * 18 * 1024; }
-template <int NBW> constexpr size_t lbs3_lds_bytes() { return (size_t)lbs3_ring_bytes<NBW>() + 7424 + 4 * LBS3_WAVE_BYTES; }
+template <int NBW> constexpr size_t lbs3_lds_bytes() { return (size_t)lbs3_ring_bytes<NBW>() + 7424 + 4 * lbs3_wave_bytes<NBW>(); }
+static_assert(3 * ((lbs3_lds_bytes<1>() + 511) / 512 * 512) <= 160 * 1024, "three workgroups of the small wave tile share a CU's LDS");
 
 template <int NPL, bool DO_SDF, int NBW = LBS_NB>
 __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void egx_lbs_fused3_kernel(LbsParams p) {
@@ -1094,7 +1667,7 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void egx_lbs_fused3_kernel(L
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id: an SGPR
   bf16x8* sA = reinterpret_cast<bf16x8*>(smem_raw);
   char* meta = smem_raw + lbs3_ring_bytes<NBW>();
-  char* my = meta + 7424 + wave * LBS3_WAVE_BYTES;
+  char* my = meta + 7424 + wave * lbs3_wave_bytes<NBW>();
   LbsWave w;
   w.lane = lane; w.n = lane & 31; w.half = lane >> 5;
   w.s_W = reinterpret_cast<float*>(meta);                    // tile metadata is shared by the four waves here
@@ -1102,10 +1675,12 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void egx_lbs_fused3_kernel(L
   w.s_slot = w.s_jl + 56;
   w.s_masks = reinterpret_cast<unsigned*>(w.s_slot + 32);
   w.s_cnt = reinterpret_cast<int*>(my);
-  w.s_queue = reinterpret_cast<f32x4*>(my + 256);
+  w.s_fixmap = reinterpret_cast<unsigned*>(my + 128 * NBW);
+  w.s_thr = reinterpret_cast<float*>(my + 256 * NBW);
+  w.s_queue = reinterpret_cast<f32x4*>(my + 384 * NBW);
   w.lds = nullptr;
   w.qn = 0;
-  w.s_cnt[lane] = 0;
+  if (lane < 32 * NBW) { w.s_cnt[lane] = 0; w.s_fixmap[lane] = 0u; }
   // Work partition over the XCDs (blocks are dealt to them round-robin).  Either every XCD owns a chunk of BODY GROUPS and
   // all vertex tiles (its bodies' features / transforms stay in its L2 and the bases stream through once per block of groups)
   // or a chunk of VERTEX TILES and all groups (it streams an eighth of the bases once per block; every XCD reads all
@@ -1188,7 +1763,23 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void egx_lbs_fused3_kernel(L
       if (sum == 123.456f) p.pene[0] = 1;
       return;
     }
-    lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP, NB>(p, w, acc, vt, bt0, JT);
+    // mixed blend: the tiles that only feed the count (everything after the picked tiles) classify with the cheap product and
+    // re-evaluate what it cannot decide
+#ifdef EGX_LBS_NOFIX   // development builds: the cheap product decides alone (the round-5 kernel), for A/B timing
+    constexpr bool FIX = false;
+#else
+    constexpr bool FIX = NPL == 4 && DO_SDF;
+#endif
+#ifdef EGX_LBS_VALU_SKIN   // development builds: the count-only tiles skinned on the VALU as well (fix-up only), for A/B timing
+    lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP, NB, FIX>(p, w, acc, vt, bt0, JT, FIX && vti >= p.n_precise);
+#else
+    // count-only tiles whose joint list fits one k-step (eight joints: 309 of the 328 tiles of the synthetic body) are skinned on
+    // the matrix pipe; the tiles with picked vertices (exact positions) and the long lists take the VALU epilogue - the latter with
+    // the fix-up band as well, since their blend product is the cheap one too.  The small wave tile (three workgroups per CU, 168
+    // registers) has no room for the twelve operands: VALU epilogue throughout.
+    if (FIX && NB == LBS_NB && vti >= p.n_precise && JT <= 8) lbs_epilogue_cell<LBS3_RB, LBS3_QCAP, NB>(p, w, acc, vt, bt0, JT);
+    else lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP, NB, FIX>(p, w, acc, vt, bt0, JT, FIX && vti >= p.n_precise);
+#endif
 #ifdef EGX_LBS_TIMING
     w.et[4] += LBS_NOW() - item_t0; w.et[5] += 1;
 #endif
@@ -1221,6 +1812,28 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void egx_lbs_fused3_kernel(L
     atomicAdd(&g_lbs_t[13], w.et[4]); atomicAdd(&g_lbs_t[14], w.et[5]);
   }
 #endif
+}
+
+// The fix-up queue of a mixed-blend launch (lbs_fix_process): one wave per queued vertex, re-evaluated in fp32 and counted.
+constexpr int LBS_FIXQ_CAP = 1 << 12;   // entries per sub-queue: 64 x 4096 x 8 bytes = 2 MB of workspace, 25 vertices per body at 10 240 bodies
+constexpr int LBS_FIX_BLOCKS = 1024;
+static_assert((LBS_FIX_BLOCKS * 4) % LBS_FIX_NQ == 0, "waves of the fix-up kernel per sub-queue");
+__global__ __launch_bounds__(256) void egx_lbs_fix_kernel(LbsParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  const int sq = wave % LBS_FIX_NQ;   // n_waves is a multiple of LBS_FIX_NQ: a wave stays with one sub-queue
+  const int count = min(p.fix_stats[LBS_FIX_CNT0 + 32 * sq], p.fixq_cap);
+  for (int i = wave / LBS_FIX_NQ; i < count; i += n_waves / LBS_FIX_NQ) {
+    const int2 e = p.fixq[(size_t)sq * p.fixq_cap + i];
+    if (e.x < 0) continue;   // wave-uniform
+    const int vt = e.x >> 5, row = e.x & 31, slot = e.y;
+    const int j_lo = p.tj_off[vt], JT = p.tj_off[vt + 1] - j_lo;
+    const float sv = lbs_fix_one<true>(p, lane, vt, row, slot, JT, p.tj_idx + j_lo, p.tj_w + (size_t)j_lo * 32);
+    if (lane == 0 && sv < 0.f) {
+      const int body = p.agent_of_slot ? p.agent_of_slot[slot / p.fpa] * p.fpa + slot % p.fpa : slot;
+      atomicAdd(p.pene + body, 1);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1523,6 +2136,24 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
           dirs[(((size_t)vt * KGROUPS + g) * 3 + c) * 64 + l] = val;
         }
 
+  // the same bases vertex-major (one vertex's 3 x 472 columns contiguous): the single-vertex fp32 re-evaluation of the mixed blend
+  // reads 5.7 KB per vertex from here instead of 720 scattered cache lines of the MFMA-ordered images
+  std::vector<float> dirs_rm((size_t)VP * 3 * KDIM, 0.f);
+  for (int vn = 0; vn < VP; ++vn) {
+    const int v = perm[vn];
+    if (v < 0) continue;
+    for (int c = 0; c < 3; ++c) {
+      float* dst = &dirs_rm[((size_t)vn * 3 + c) * KDIM];
+      for (int k = 0; k < 10; ++k) dst[k] = d->shapedirs_host[((size_t)v * 3 + c) * 10 + k];
+      for (int k = 10; k < KACT; ++k) {
+        const int jc = (k - 10) / 9, e9 = (k - 10) % 9;
+        const int j = jc + 1 + (jc >= 21 ? 3 : 0);
+        dst[k] = d->posedirs_host[(size_t)((j - 1) * 9 + e9) * 3 * V + (size_t)v * 3 + c];
+      }
+      dst[KACT] = d->v_template_host[(size_t)v * 3 + c];
+    }
+  }
+
   // the same bases as three bf16 planes in the A-operand order of v_mfma_f32_32x32x16_bf16:
   // [vt][s][plane][c][lane] 8 x bf16, element e <-> k = 16 s + 8 (lane>>5) + e, row = lane & 31
   std::vector<unsigned short> dirs3((size_t)NVT * KS3 * 9 * 64 * 8, 0);
@@ -1611,6 +2242,25 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
     tj_off[vt + 1] = (int)tj_idx.size();
   }
 
+  // matrix-pipe skinning weights of every tile (lbs_epilogue_cell): k-step ks covers joints list[8 ks .. 8 ks + 7] of the tile
+  std::vector<int> skin_ks_off(NVT + 1, 0);
+  for (int vt = 0; vt < NVT; ++vt) skin_ks_off[vt + 1] = skin_ks_off[vt] + (tj_off[vt + 1] - tj_off[vt] + 7) / 8;
+  std::vector<unsigned short> skinW((size_t)skin_ks_off[NVT] * 2 * 64 * 8, 0);
+  for (int vt = 0; vt < NVT; ++vt) {
+    const int JT = tj_off[vt + 1] - tj_off[vt];
+    for (int ks = 0; ks < (JT + 7) / 8; ++ks)
+      for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 8; ++e) {
+          const int jj = 8 * ks + e;
+          if (jj >= JT) continue;
+          unsigned short hh[3];
+          egx_bf16_split3(tj_w[(size_t)(tj_off[vt] + jj) * 32 + (l & 31)], hh);
+          const size_t base = ((size_t)(skin_ks_off[vt] + ks) * 2) * 64 * 8;
+          skinW[base + (size_t)l * 8 + e] = hh[0];                                   // operand 0: W_hi in both lane halves
+          if (l < 32) skinW[base + (size_t)(64 + l) * 8 + e] = hh[1];                // operand 1: W_mid in lane half 0, zero in half 1
+        }
+  }
+
   // picked vertices (markers, vertex joints, landmark corners)
   std::vector<int> pick_slot(VP, -1), marker_slot(d->num_markers), extra_slot(NEXTRA), lmk_slot(NLMK * 3);
   int NP = 0;
@@ -1680,6 +2330,28 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
       pc.J_template[j * 3 + c] = (float)s;
       for (int k = 0; k < 10; ++k) pc.J_shapedirs[(j * 3 + c) * 10 + k] = (float)sd[k];
     }
+  for (int j = 1; j < NJ; ++j) {   // fix-up threshold of the mixed blend: largest pose-corrective column (3-vector norm) per joint
+    double mx = 0.0;
+    for (int e9 = 0; e9 < 9; ++e9)
+      for (int v = 0; v < V; ++v) {
+        double q = 0.0;
+        for (int c = 0; c < 3; ++c) {
+          const double e = d->posedirs_host[(size_t)((j - 1) * 9 + e9) * 3 * V + (size_t)v * 3 + c];
+          q += e * e;
+        }
+        mx = std::max(mx, q);
+      }
+    pc.fix_c[j] = (float)(std::sqrt(mx) * (1.0 + 1e-6));
+  }
+  {
+    double mx = 0.0;
+    for (int v = 0; v < V; ++v) {
+      double q = 0.0;
+      for (int c = 0; c < 3; ++c) q += (double)d->v_template_host[(size_t)v * 3 + c] * d->v_template_host[(size_t)v * 3 + c];
+      mx = std::max(mx, q);
+    }
+    pc.v_norm_max = (float)std::sqrt(mx) + 0.25f;
+  }
   std::memcpy(pc.hand_comps, d->hand_comps_l_host, 12 * 45 * sizeof(float));
   std::memcpy(pc.hand_comps + 12 * 45, d->hand_comps_r_host, 12 * 45 * sizeof(float));
   std::memcpy(pc.hand_mean, d->hand_mean_l_host, 45 * sizeof(float));
@@ -1776,6 +2448,11 @@ extern "C" int egx_body_model_create(const egx_body_model_host* d, egx_body_mode
     if ((rc = upload(&d4, dirs4))) { egx_body_model_destroy(m); return rc; }
     m->dirs4 = reinterpret_cast<bf16x8*>(d4);
   }
+  {
+    unsigned short* sw = nullptr;
+    if ((rc = upload(&sw, skinW)) || (rc = upload(&m->skin_ks_off, skin_ks_off)) || (rc = upload(&m->dirs_rm, dirs_rm))) { egx_body_model_destroy(m); return rc; }
+    m->skinW = reinterpret_cast<bf16x8*>(sw);
+  }
   if ((rc = upload(&m->vorig, perm)) || (rc = upload(&m->pick_tiles, pick_tiles)) ||
       (rc = upload(&m->sdf_tiles, sdf_tiles))) { egx_body_model_destroy(m); return rc; }
   if ((rc = upload(&m->dirs, dirs)) || (rc = upload(&m->tj_off, tj_off)) || (rc = upload(&m->tj_idx, tj_idx)) ||
@@ -1795,6 +2472,7 @@ extern "C" void egx_body_model_destroy(egx_body_model* m) {
   (void)hipFree(m->pick_slot); (void)hipFree(m->pick_tiles); (void)hipFree(m->sdf_tiles); (void)hipFree(m->vflags); (void)hipFree(m->vorig); (void)hipFree(m->pc); (void)hipFree(m->marker_slot);
   (void)hipFree(m->extra_slot); (void)hipFree(m->lmk_slot); (void)hipFree(m->lmk_bary);
   (void)hipFree(m->cull_E); (void)hipFree(m->cull_D0);
+  (void)hipFree(m->skinW); (void)hipFree(m->skin_ks_off); (void)hipFree(m->dirs_rm);
   delete m;
 }
 
@@ -1819,8 +2497,10 @@ int blend_mode() {
   if (m < 0) {
     const char* e = getenv("EGX_LBS_BLEND");
     const std::string v = e ? e : "";
-    m = (v == "f32" || v == "0") ? 0 : ((v == "bf16x3" || v == "1") ? 1 : ((v == "bf16x2" || v == "2") ? 2 : 3));   // default: f16mix
-    g_blend_mode.store(m);
+    // unset = f16mix (mode 3: counts re-evaluated in fp32 where the cheap product cannot decide); an unknown string is an
+    // error of the call that reads it (-2), not a silent default
+    m = (v == "f32" || v == "0") ? 0 : ((v == "bf16x3" || v == "1") ? 1 : ((v == "bf16x2" || v == "2") ? 2 : ((v.empty() || v == "f16mix" || v == "3") ? 3 : -2)));
+    if (m >= 0) g_blend_mode.store(m);
   }
   return m;
 }
@@ -1828,6 +2508,9 @@ struct WsLayout {
   size_t feat, feat4, A4, picked, total;
   // culled SDF launches
   size_t fvec, jpos, order, flags, items, counts;
+  size_t fix_e, fix_stats;   // fix-up of the mixed blend: per-slot error bound, counter of re-evaluated vertices
+  size_t skinB, cinit;       // matrix-pipe skinning operands of the mixed blend
+  size_t fixq;               // fix-up queue
   size_t Bp;
   int items_stride;
 };
@@ -1847,7 +2530,12 @@ WsLayout ws_layout(const egx_body_model* m, int B) {
   w.items_stride = (int)n_items;
   w.items = egx_align_up(w.flags + n_items * sizeof(int), 256);
   w.counts = egx_align_up(w.items + 8 * n_items * sizeof(int), 256);
-  w.total = egx_align_up(w.counts + 16 * sizeof(int), 256);
+  w.fix_e = egx_align_up(w.counts + 16 * sizeof(int), 256);
+  w.fix_stats = egx_align_up(w.fix_e + Bp * sizeof(float), 256);
+  w.skinB = egx_align_up(w.fix_stats + LBS_FIX_STATS_INTS * sizeof(int), 256);
+  w.cinit = egx_align_up(w.skinB + (Bp / 32) * (size_t)SKIN_BT_BYTES, 256);
+  w.fixq = egx_align_up(w.cinit + Bp * sizeof(f32x4), 256);
+  w.total = egx_align_up(w.fixq + (size_t)LBS_FIX_NQ * LBS_FIXQ_CAP * sizeof(int2), 256);
   return w;
 }
 // free-space culling of SDF work items: OPT-IN (EGX_LBS_CULL=1 / egx_lbs_set_culling(1)).  Measured on MI355X, 10 240 bodies,
@@ -1866,6 +2554,36 @@ int culling_on() {
   return c;
 }
 }  // namespace
+
+namespace {
+// wave tile of the mixed-blend kernel: 0 = by launch size (see egx_lbs_forward), 1 = 32 x 32 (three workgroups per CU), 2 = 32 x 64
+std::atomic<int> g_wave_tile{-1};
+int wave_tile() {
+  int t = g_wave_tile.load();
+  if (t < 0) {
+    const char* e = getenv("EGX_LBS_WAVE_TILE");
+    t = e ? atoi(e) : 0;
+    g_wave_tile.store(t);
+  }
+  return t;
+}
+}  // namespace
+
+namespace {
+std::atomic<int> g_fixq_cap{0};   // 0 = LBS_FIXQ_CAP
+}
+extern "C" int egx_lbs_set_fix_queue_capacity(int entries) {
+  EGX_REQUIRE(entries >= 0 && entries <= LBS_FIXQ_CAP, "capacity must be 0 (default) .. the workspace's queue size");
+  g_fixq_cap.store(entries);
+  return EGX_OK;
+}
+
+extern "C" int egx_lbs_set_wave_tile(int tile) {
+  EGX_REQUIRE(tile >= 0 && tile <= 2, "wave tile must be 0 (by launch size), 1 (32 x 32) or 2 (32 x 64)");
+  g_wave_tile.store(tile);
+  return EGX_OK;
+}
+extern "C" int egx_lbs_get_wave_tile(void) { return wave_tile(); }
 
 extern "C" int egx_lbs_set_culling(int on) {
   g_cull.store(on ? 1 : 0);
@@ -1894,6 +2612,19 @@ extern "C" int egx_lbs_cull_stats(const egx_body_model* m, const void* workspace
   return EGX_OK;
 }
 
+extern "C" int egx_lbs_fix_stats(const egx_body_model* m, const void* workspace, int num_bodies, int32_t* out_reevaluated) {
+  EGX_REQUIRE(m && workspace && num_bodies > 0 && out_reevaluated, "bad arguments");
+  const WsLayout wl = ws_layout(m, num_bodies);
+  std::vector<int32_t> st(LBS_FIX_STATS_INTS);
+  EGX_HIP_CHECK(hipMemcpy(st.data(), static_cast<const char*>(workspace) + wl.fix_stats, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  const int cap = g_fixq_cap.load() > 0 ? g_fixq_cap.load() : LBS_FIXQ_CAP;   // the capacity in force now (= at the launch, unless changed since)
+  int64_t n = st[0];                                                            // re-evaluated inside the fused kernel (full sub-queue)
+  for (int q = 0; q < LBS_FIX_NQ; ++q) n += std::min(st[LBS_FIX_CNT0 + 32 * q], cap);
+  // (entries a wave reserved and then marked void are counted twice: only when a sub-queue overflowed)
+  *out_reevaluated = (int32_t)std::min<int64_t>(n, INT32_MAX);
+  return EGX_OK;
+}
+
 #ifdef EGX_LBS_TIMING
 extern "C" int egx_lbs_timing_read(unsigned long long* out16, int reset) {
   EGX_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lbs_t), 16 * sizeof(unsigned long long)));
@@ -1910,7 +2641,7 @@ extern "C" int egx_lbs_set_blend_mode(int mode) {
   g_blend_mode.store(mode);
   return EGX_OK;
 }
-extern "C" int egx_lbs_get_blend_mode(void) { return blend_mode(); }
+extern "C" int egx_lbs_get_blend_mode(void) { return blend_mode(); }   // < 0: EGX_LBS_BLEND holds an unknown string
 
 extern "C" size_t egx_lbs_workspace_bytes(const egx_body_model* m, int num_bodies) {
   if (!m || num_bodies <= 0) return 0;
@@ -1930,7 +2661,9 @@ extern "C" int egx_lbs_joints(const egx_body_model* m, const float* xb, const fl
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream_), m->pc, xb,
                      betas, B, fpa, static_cast<float*>(nullptr), static_cast<unsigned short*>(nullptr),
                      reinterpret_cast<f32x4*>(ws + wl.A4), out_joints55, NJ, 0.f, static_cast<unsigned short*>(nullptr), static_cast<int*>(nullptr),
-                     static_cast<const int*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0);
+                     static_cast<const int*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0, static_cast<float*>(nullptr),
+                     static_cast<int*>(nullptr), static_cast<unsigned short*>(nullptr), static_cast<f32x4*>(nullptr),
+                     static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), SdfDev{});
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
@@ -1958,6 +2691,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   float* picked = need_picks ? reinterpret_cast<float*>(ws + wl.picked) : nullptr;
 
   const int mode = blend_mode();   // read ONCE per call: the feature flag of column 470 and the kernel choice must agree
+  EGX_REQUIRE(mode >= 0, "EGX_LBS_BLEND must be one of f32 | bf16x3 | bf16x2 | f16mix");
   const bool split3 = mode >= 1 && !out_verts;
   const int nbg_all = egx_ceil_div(B, BODY_PAD);
   // free-space culling: SDF counts on the split kernels, a convex-weight model, whole agents, enough items to deal to 8 XCDs
@@ -1973,6 +2707,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     sd.c0 = egx_ceil_div(sdf->d0, 4); sd.c1 = egx_ceil_div(sdf->d1, 4); sd.c2 = egx_ceil_div(sdf->d2, 4);
     mips = reinterpret_cast<const float*>(static_cast<const char*>(sdf->coarse_minmax) + egx_sdf_table_bytes(sd.c0, sd.c1, sd.c2));
   }
+  const bool fix = split3 && mode == 3 && sdf;   // mixed blend with counts: the pose kernel also writes the per-body error bound
   int* order = cull ? reinterpret_cast<int*>(ws + wl.order) : nullptr;
   int* flags = reinterpret_cast<int*>(ws + wl.flags);
   int* items = reinterpret_cast<int*>(ws + wl.items);
@@ -1989,7 +2724,9 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
   hipLaunchKernelGGL(egx_pose_chain_kernel, dim3(egx_ceil_div(B, 4)), dim3(256), 0, stream, m->pc, xb, betas, B, fpa,
                      split3 ? nullptr : feat, split3 ? reinterpret_cast<unsigned short*>(feat) : nullptr, A4, out_joints,
                      EGX_NUM_JOINTS_OUT, (split3 && mode >= 2) ? 1.f : 0.f, (split3 && mode == 3) ? feat4 : nullptr, sdf ? out_pene_count : nullptr,
-                     static_cast<const int*>(order), fvec, jpos, (int)wl.Bp);
+                     static_cast<const int*>(order), fvec, jpos, (int)wl.Bp, fix ? reinterpret_cast<float*>(ws + wl.fix_e) : nullptr,
+                     reinterpret_cast<int*>(ws + wl.fix_stats), fix ? reinterpret_cast<unsigned short*>(ws + wl.skinB) : nullptr,
+                     reinterpret_cast<f32x4*>(ws + wl.cinit), R0, T0, sd);
   if (cull) {
     const int n_np = m->n_sdf_tiles - m->n_pick_tiles;
     hipLaunchKernelGGL(egx_lbs_cull_kernel, dim3(nbg_all, egx_ceil_div(n_np, CULL_TILES_PER_BLOCK)), dim3(256), 0, stream, m->sdf_tiles,
@@ -2027,6 +2764,13 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     if (const char* e = getenv("EGX_LBS_PRECISE")) p.n_precise = atoi(e);
 #endif
     p.sdf = sd;   // out_pene_count was cleared by the pose kernel above
+    p.fix_e = reinterpret_cast<const float*>(ws + wl.fix_e);
+    p.fix_stats = reinterpret_cast<int*>(ws + wl.fix_stats);
+    p.skinW = m->skinW; p.skin_ks_off = m->skin_ks_off;
+    p.fixq = reinterpret_cast<int2*>(ws + wl.fixq); p.fixq_cap = g_fixq_cap.load() > 0 ? g_fixq_cap.load() : LBS_FIXQ_CAP;
+    p.dirs_rm = m->dirs_rm; p.pc = m->pc; p.betas = betas;
+    p.skinB = reinterpret_cast<const bf16x8*>(ws + wl.skinB); p.cinit = reinterpret_cast<const f32x4*>(ws + wl.cinit);
+    p.sdf_aux = sdf ? reinterpret_cast<const float*>(static_cast<const char*>(sdf->coarse_minmax) + egx_sdf_aux_offset(sd.c0, sd.c1, sd.c2)) : nullptr;
     // one persistent workgroup per CU; per-device launch facts (CU count, raised dynamic-LDS caps) are set up once per device
     constexpr size_t lds_meta = (size_t)8 * LBS_META_BYTES, lds_verts = (size_t)8 * (LBS_META_BYTES + LBS_VERT_BYTES),
                      lds_sdf = (size_t)8 * (LBS_META_BYTES + LBS_QCAP * 16);
@@ -2044,7 +2788,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<true, false>), lds_verts));
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<false, true>), lds_sdf));
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused_kernel<false, false>), lds_meta));
-        constexpr size_t lds3a = (size_t)LBS3_SHARED_BYTES + 4 * LBS3_WAVE_BYTES;
+        constexpr size_t lds3a = (size_t)LBS3_SHARED_BYTES + 4 * lbs3_wave_bytes<LBS_NB>();
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<3, true>), lds3a));
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<3, false>), lds3a));
         EGX_HIP_CHECK(raise(reinterpret_cast<const void*>(&egx_lbs_fused3_kernel<2, true>), lds3a));
@@ -2072,7 +2816,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
     if (ev0) EGX_HIP_CHECK(hipEventRecord(ev0, stream));
     if (split3) {
       // two persistent 4-wave workgroups per CU: one's VALU epilogue runs under the other's MFMA stages
-      constexpr size_t lds3 = (size_t)LBS3_SHARED_BYTES + 4 * LBS3_WAVE_BYTES;
+      constexpr size_t lds3 = (size_t)LBS3_SHARED_BYTES + 4 * lbs3_wave_bytes<LBS_NB>();
       int wg_per_cu = 2;
 #ifdef EGX_LBS_DEVELOPMENT
       if (const char* e = getenv("EGX_LBS_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));   // occupancy sensitivity (1 = one wave per SIMD)
@@ -2084,7 +2828,7 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
       // XCDs better and a third wave per SIMD helps where the launch is short: 640 bodies 0.086 -> 0.073 ms, 1 280 0.150 -> 0.116,
       // 2 560 0.250 -> 0.209, 5 120 0.461 -> 0.355; at 10 240 bodies the larger tile wins (0.686 against 0.734: the halved
       // item repeats the bases traffic and the barriers), profiles/r05_lbs_mixed.md section 5.  EGX_LBS_WAVE_TILE=1 | 2 forces one.
-      static const int forced_tile = []() { const char* e = getenv("EGX_LBS_WAVE_TILE"); return e ? atoi(e) : 0; }();
+      const int forced_tile = wave_tile();
       const bool small_tile = forced_tile == 1 || (forced_tile != 2 && p.nbg <= 20);
       if (mode == 3 && small_tile && !p.items) {
         LbsParams q = p;
@@ -2113,6 +2857,9 @@ extern "C" int egx_lbs_forward(const egx_body_model* m, const float* xb, const f
       hipLaunchKernelGGL((egx_lbs_fused_kernel<false, true>), dim3(grid), dim3(LBS_THREADS), lds, stream, p);
     else
       hipLaunchKernelGGL((egx_lbs_fused_kernel<false, false>), dim3(grid), dim3(LBS_THREADS), lds, stream, p);
+    // mixed blend with counts: the vertices the fused kernel queued for the fp32 re-evaluation (inside the profiled interval: it is
+    // part of what the mode costs)
+    if (fix) hipLaunchKernelGGL(egx_lbs_fix_kernel, dim3(LBS_FIX_BLOCKS), dim3(256), 0, stream, p);
     if (ev1) EGX_HIP_CHECK(hipEventRecord(ev1, stream));
   }
   if (need_picks)

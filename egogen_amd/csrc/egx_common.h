@@ -71,18 +71,44 @@ __host__ __device__ inline size_t egx_sdf_table_bytes(int c0, int c1, int c2) { 
   return ((size_t)(c0 + 2) * (c1 + 2) * (c2 + 2) * 8 + 255) / 256 * 256;
 }
 
+// After the pyramid (256-byte aligned): EGX_SDF_AUX_FLOATS floats written by egx_sdf_build_coarse -
+//   [0..2] the largest |difference| of two neighbouring samples along x, y, z
+//   [3]    the steepest slope of the interpolated field, value per metre of world space (sdf.hip: egx_sdf_axis_steps_kernel):
+//          a position error bound times this is a bound on the change of the sampled value (fix-up of the mixed blend).
+constexpr int EGX_SDF_AUX_FLOATS = 64;
+__host__ __device__ inline size_t egx_sdf_aux_offset(int c0, int c1, int c2) {       // in bytes, from the start of the table
+  return (egx_sdf_table_bytes(c0, c1, c2) + egx_sdf_mip_offset(c0, c1, c2, EGX_SDF_MIP_LEVELS + 1) * sizeof(float) + 255) / 256 * 256;
+}
+
 inline bool egx_sdf_dims_ok(int d0, int d1, int d2) {
   return d2 >= 2 && (unsigned long long)d0 * (unsigned long long)d1 * (unsigned long long)d2 < (1ull << 32);
 }
 
+// One rounding per operation, whatever the surrounding code: hip-clang's __fmul_rn / __fadd_rn are plain `*` / `+` compiled with
+// the default -ffp-contract=fast, i.e. the compiler fuses them into FMAs differently from kernel to kernel (a last-bit
+// difference between two kernels that inline the same function).  These are compiled with contraction off.
+__device__ __forceinline__ float egx_mul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float egx_add(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float egx_sub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 // Continuous voxel coordinates of a world point, clamped to the grid (align_corners=False, padding "border").
-// explicit _rn intrinsics: immune to fma contraction, so the coordinates round exactly like the CPU path
+// every operation rounds on its own (contraction off below), so the coordinates round exactly like the CPU path
 __device__ __forceinline__ void egx_sdf_voxel_coords(const SdfDev& s, float x, float y, float z, float& px, float& py, float& pz) {
-  const float nx = __fmul_rn(__fsub_rn(x, s.cx), s.scale), ny = __fmul_rn(__fsub_rn(y, s.cy), s.scale),
-              nz = __fmul_rn(__fsub_rn(z, s.cz), s.scale);
-  px = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.f), (float)s.d0), 1.f), 0.5f);
-  py = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.f), (float)s.d1), 1.f), 0.5f);
-  pz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(nz, 1.f), (float)s.d2), 1.f), 0.5f);
+#pragma clang fp contract(off)   // __fmul_rn / __fadd_rn are plain * and + under hip-clang: without this the compiler fuses them
+  const float nx = egx_mul(egx_sub(x, s.cx), s.scale), ny = egx_mul(egx_sub(y, s.cy), s.scale),
+              nz = egx_mul(egx_sub(z, s.cz), s.scale);
+  px = egx_mul(egx_sub(egx_mul(egx_add(nx, 1.f), (float)s.d0), 1.f), 0.5f);
+  py = egx_mul(egx_sub(egx_mul(egx_add(ny, 1.f), (float)s.d1), 1.f), 0.5f);
+  pz = egx_mul(egx_sub(egx_mul(egx_add(nz, 1.f), (float)s.d2), 1.f), 0.5f);
   px = fminf(fmaxf(px, 0.f), (float)(s.d0 - 1));
   py = fminf(fmaxf(py, 0.f), (float)(s.d1 - 1));
   pz = fminf(fmaxf(pz, 0.f), (float)(s.d2 - 1));
@@ -121,9 +147,10 @@ struct __attribute__((packed, aligned(4))) EgxF2 { float x, y; };  // two z-neig
 // of each (x,y) corner column are one 8-byte load; corners that fall off the grid have weight exactly 0 (aten drops
 // them) and a clamped index.  Requires d2 >= 2 and d0*d1*d2 < 2^32.
 __device__ __forceinline__ float egx_sdf_neg_trilinear_at(const SdfDev& s, float px, float py, float pz) {
+#pragma clang fp contract(off)   // products and sums round one by one as in aten's kernel, in every kernel this is inlined into
   const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
-  const float wx1 = __fsub_rn(px, x0), wy1 = __fsub_rn(py, y0), wz1 = __fsub_rn(pz, z0);
-  const float wx0 = __fsub_rn(__fadd_rn(x0, 1.f), px), wy0 = __fsub_rn(__fadd_rn(y0, 1.f), py), wz0 = __fsub_rn(__fadd_rn(z0, 1.f), pz);
+  const float wx1 = egx_sub(px, x0), wy1 = egx_sub(py, y0), wz1 = egx_sub(pz, z0);
+  const float wx0 = egx_sub(egx_add(x0, 1.f), px), wy0 = egx_sub(egx_add(y0, 1.f), py), wz0 = egx_sub(egx_add(z0, 1.f), pz);
   const unsigned ix0 = (unsigned)x0, iy0 = (unsigned)y0, iz0 = (unsigned)z0;
   const bool x1_in = ix0 + 1 < (unsigned)s.d0, y1_in = iy0 + 1 < (unsigned)s.d1, z1_in = iz0 + 1 < (unsigned)s.d2;
   const unsigned zb = z1_in ? iz0 : iz0 - 1;                      // pair (zb, zb+1) always inside the row
@@ -135,16 +162,16 @@ __device__ __forceinline__ float egx_sdf_neg_trilinear_at(const SdfDev& s, float
   (void)g;
   const float wx1e = x1_in ? wx1 : 0.f, wy1e = y1_in ? wy1 : 0.f, wz1e = z1_in ? wz1 : 0.f;
   const float v000 = z1_in ? c00.x : c00.y, v010 = z1_in ? c01.x : c01.y, v100 = z1_in ? c10.x : c10.y, v110 = z1_in ? c11.x : c11.y;
-  const float a00 = __fmul_rn(wx0, wy0), a01 = __fmul_rn(wx0, wy1e), a10 = __fmul_rn(wx1e, wy0), a11 = __fmul_rn(wx1e, wy1e);
+  const float a00 = egx_mul(wx0, wy0), a01 = egx_mul(wx0, wy1e), a10 = egx_mul(wx1e, wy0), a11 = egx_mul(wx1e, wy1e);
   float acc;
-  acc = __fmul_rn(v000, __fmul_rn(a00, wz0));
-  acc = __fadd_rn(acc, __fmul_rn(c00.y, __fmul_rn(a00, wz1e)));
-  acc = __fadd_rn(acc, __fmul_rn(v010, __fmul_rn(a01, wz0)));
-  acc = __fadd_rn(acc, __fmul_rn(c01.y, __fmul_rn(a01, wz1e)));
-  acc = __fadd_rn(acc, __fmul_rn(v100, __fmul_rn(a10, wz0)));
-  acc = __fadd_rn(acc, __fmul_rn(c10.y, __fmul_rn(a10, wz1e)));
-  acc = __fadd_rn(acc, __fmul_rn(v110, __fmul_rn(a11, wz0)));
-  acc = __fadd_rn(acc, __fmul_rn(c11.y, __fmul_rn(a11, wz1e)));
+  acc = egx_mul(v000, egx_mul(a00, wz0));
+  acc = egx_add(acc, egx_mul(c00.y, egx_mul(a00, wz1e)));
+  acc = egx_add(acc, egx_mul(v010, egx_mul(a01, wz0)));
+  acc = egx_add(acc, egx_mul(c01.y, egx_mul(a01, wz1e)));
+  acc = egx_add(acc, egx_mul(v100, egx_mul(a10, wz0)));
+  acc = egx_add(acc, egx_mul(c10.y, egx_mul(a10, wz1e)));
+  acc = egx_add(acc, egx_mul(v110, egx_mul(a11, wz0)));
+  acc = egx_add(acc, egx_mul(c11.y, egx_mul(a11, wz1e)));
   return -acc;
 }
 

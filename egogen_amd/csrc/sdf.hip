@@ -1,11 +1,25 @@
-// calc_sdf (crowd_ppo/utils.py:54-84) as a standalone gather kernel: one point per lane, grid-stride.
+// calc_sdf (crowd_ppo/utils.py:54-84) as a standalone gather kernel: four points per lane and trip, grid-stride.  What bounds it is
+// the L2 -> L1 line traffic of the corner gathers (a 128-byte line per 8-byte corner pair), not the 16 bytes per point of
+// coordinates and output: profiles/r06_sdf_sample.md (incl. the LDS-staged per-body variant that was built, measured slower and
+// removed).
 #include "egx_common.h"
 
+#ifndef EGX_SDF_PPT
+#define EGX_SDF_PPT 4   // points per lane and trip: their 4 x PPT corner-pair gathers are in flight together
+#endif
 __global__ __launch_bounds__(256) void egx_sdf_sample_kernel(SdfDev s, const float* __restrict__ pts, int64_t n,
                                                             float* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-    out[i] = egx_sdf_neg_trilinear(s, x, y, z);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += EGX_SDF_PPT * stride) {
+    float r[EGX_SDF_PPT];
+#pragma unroll
+    for (int u = 0; u < EGX_SDF_PPT; ++u) {
+      const int64_t i = min(i0 + u * stride, n - 1);
+      r[u] = egx_sdf_neg_trilinear(s, pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]);
+    }
+#pragma unroll
+    for (int u = 0; u < EGX_SDF_PPT; ++u)
+      if (i0 + u * stride < n) out[i0 + u * stride] = r[u];
   }
 }
 
@@ -53,10 +67,40 @@ __global__ void egx_sdf_build_mip_kernel(const float2* __restrict__ table, int c
   out[idx] = mx;
 }
 
+// aux[0..2] (egx_common.h): largest |difference| of neighbouring samples along each axis; aux[3]: the steepest slope of the
+// interpolated field in value per METRE.  Inside a cell every component of the trilinear gradient is a convex combination of the
+// cell's four edge differences along that axis, so |gradient| <= sqrt(sum_a (k_a max edge_a)^2) per cell, k_a = samples per
+// metre; outside the cube the border clamp only removes components.  Non-negative floats order like their bit patterns, so the
+// reductions are integer atomicMax.
+__global__ __launch_bounds__(256) void egx_sdf_axis_steps_kernel(const float* __restrict__ grid, int d0, int d1, int d2, float k0, float k1,
+                                                                float k2, unsigned* __restrict__ aux) {
+  const size_t n = (size_t)d0 * d1 * d2;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int z = (int)(i % d2), y = (int)((i / d2) % d1), x = (int)(i / ((size_t)d1 * d2));
+    const int x1 = min(x + 1, d0 - 1), y1 = min(y + 1, d1 - 1), z1 = min(z + 1, d2 - 1);
+    auto at = [&](int xx, int yy, int zz) { return grid[((size_t)xx * d1 + yy) * d2 + zz]; };
+    // the cell with origin (x, y, z) (degenerate along an axis at the last plane: those edges are zero)
+    const float v000 = at(x, y, z), v001 = at(x, y, z1), v010 = at(x, y1, z), v011 = at(x, y1, z1);
+    const float v100 = at(x1, y, z), v101 = at(x1, y, z1), v110 = at(x1, y1, z), v111 = at(x1, y1, z1);
+    const float ex = fmaxf(fmaxf(fabsf(v100 - v000), fabsf(v101 - v001)), fmaxf(fabsf(v110 - v010), fabsf(v111 - v011)));
+    const float ey = fmaxf(fmaxf(fabsf(v010 - v000), fabsf(v011 - v001)), fmaxf(fabsf(v110 - v100), fabsf(v111 - v101)));
+    const float ez = fmaxf(fmaxf(fabsf(v001 - v000), fabsf(v011 - v010)), fmaxf(fabsf(v101 - v100), fabsf(v111 - v110)));
+    g[0] = fmaxf(g[0], ex); g[1] = fmaxf(g[1], ey); g[2] = fmaxf(g[2], ez);
+    g[3] = fmaxf(g[3], sqrtf(k0 * ex * k0 * ex + k1 * ey * k1 * ey + k2 * ez * k2 * ez));
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float m = g[a];
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && !(m != m)) atomicMax(&aux[a], __float_as_uint(m * (a == 3 ? 1.0001f : 1.f)));
+  }
+}
+
 extern "C" size_t egx_sdf_coarse_bytes(int d0, int d1, int d2) {
   if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
   const int c0 = egx_ceil_div(d0, 4), c1 = egx_ceil_div(d1, 4), c2 = egx_ceil_div(d2, 4);
-  return egx_sdf_table_bytes(c0, c1, c2) + egx_sdf_mip_offset(c0, c1, c2, EGX_SDF_MIP_LEVELS + 1) * sizeof(float);
+  return egx_sdf_aux_offset(c0, c1, c2) + EGX_SDF_AUX_FLOATS * sizeof(float);
 }
 
 extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream_) {
@@ -71,6 +115,10 @@ extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, v
     hipLaunchKernelGGL(egx_sdf_build_mip_kernel, dim3(egx_ceil_div(ne, 128)), dim3(128), 0, static_cast<hipStream_t>(stream_),
                        static_cast<const float2*>(coarse_out), c0, c1, c2, l, mips + egx_sdf_mip_offset(c0, c1, c2, l));
   }
+  unsigned* aux = reinterpret_cast<unsigned*>(static_cast<char*>(coarse_out) + egx_sdf_aux_offset(c0, c1, c2));
+  EGX_HIP_CHECK(hipMemsetAsync(aux, 0, EGX_SDF_AUX_FLOATS * sizeof(float), static_cast<hipStream_t>(stream_)));
+  hipLaunchKernelGGL(egx_sdf_axis_steps_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream_), sdf->grid, sdf->d0, sdf->d1,
+                     sdf->d2, sdf->scale * (float)sdf->d0 * 0.5f, sdf->scale * (float)sdf->d1 * 0.5f, sdf->scale * (float)sdf->d2 * 0.5f, aux);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }
@@ -81,8 +129,8 @@ extern "C" int egx_sdf_sample(const egx_sdf_grid* sdf, const float* pts, int64_t
   if (n == 0) return EGX_OK;  // empty input is legal
   EGX_REQUIRE(pts && out && n > 0, "null points / output");
   SdfDev s{sdf->grid, sdf->d0, sdf->d1, sdf->d2, sdf->center[0], sdf->center[1], sdf->center[2], sdf->scale, nullptr, 0, 0, 0};
-  const int64_t blocks = (n + 255) / 256;
-  const int grid = (int)(blocks < 4096 ? blocks : 4096);
+  const int64_t blocks = (n + 256 * EGX_SDF_PPT - 1) / (256 * EGX_SDF_PPT);
+  const int grid = (int)(blocks < 8192 ? blocks : 8192);
   hipLaunchKernelGGL(egx_sdf_sample_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), s, pts, n, out);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;

@@ -124,13 +124,29 @@ int egx_lbs_cull_stats(const egx_body_model* m, const void* workspace, int num_b
  *   3  "f16mix" (DEFAULT): the vertex tiles that hold PICKED vertices (markers, vertex joints, landmark corners - everything the
  *      caller reads as a position) run exactly as in mode 2; the other tiles, which only feed the penetration COUNT, keep the
  *      shape / template k-steps as in mode 2 and run the 28 k-steps that hold only pose-corrective columns (centimetre-scale
- *      offsets) as ONE v_mfma_f32_32x32x16_f16 product on operands rounded to fp16 (2^-12 per operand): 204 instead of 540
+ *      offsets) as ONE v_mfma_f32_32x32x16_f16 product on operands rounded to fp16 (2^-11 per operand): 204 instead of 540
  *      MFMAs per wave and work item, a third of the operand bytes.  Those vertices move by ~4e-6 m rms / ~2.2e-5 m worst case
- *      against float64 on the synthetic body (2e-5 of a metre-scale coordinate, inside north_star's 1e-4), i.e. a count may
- *      differ by the vertices within that distance of the level set (parity tests: 6e-5 m band); positions are unaffected.
+ *      against float64 on the synthetic body, so the cheap product only CLASSIFIES: a vertex whose interpolated SDF value is
+ *      closer to zero than its position error can account for (ten standard deviations of the product's rounding error for
+ *      that body's pose, times the steepest slope of the grid) is re-evaluated inside the kernel in fp32 (three-plane operand
+ *      images, fp32 skinning) and counted from that - a few per thousand counted vertices.  The counts are those of an fp32
+ *      evaluation (crowd_env_2f.py:169-177): the parity tests hold every mode to the same 2e-5 m level-set band, and
+ *      egx_lbs_fix_stats reads how many vertices the last call re-evaluated.  Positions are unaffected.
+ * An unrecognised EGX_LBS_BLEND string is an error of the first egx_lbs_forward call (no silent default).
  * (No reference counterpart: smplx evaluates the blend shapes as fp32 einsum/matmul, lbs.py [upstream smplx 0.1.28].) */
 int egx_lbs_set_blend_mode(int mode);
 int egx_lbs_get_blend_mode(void);
+/* Mode 3 only: wave tile of the fused kernel - 0 (default) = chosen by launch size: 32 vertices x 32 bodies per wave, three
+ * workgroups per CU, VALU skinning, for launches of at most 20 groups of 256 bodies; 32 x 64, two workgroups per CU, count-only
+ * tiles skinned on the matrix pipe, above that.  1 / 2 force one (EGX_LBS_WAVE_TILE in the environment does the same): the
+ * parity tests run both on the same inputs. */
+int egx_lbs_set_wave_tile(int tile);
+int egx_lbs_get_wave_tile(void);
+/* Mode 3 only: entries of each of the 64 sub-queues of the launch's fix-up queue that are used (0 = all 4 096).  Vertices that find the queue full are
+ * re-evaluated inside the fused kernel instead - slower, same result; the parity tests shrink the queue to exercise that path. */
+int egx_lbs_set_fix_queue_capacity(int entries);
+/* Mode 3 only: vertices the last SDF-counting egx_lbs_forward call on this workspace re-evaluated in fp32 (host synchronisation). */
+int egx_lbs_fix_stats(const egx_body_model* m, const void* workspace, int num_bodies, int32_t* out_reevaluated);
 
 size_t egx_lbs_workspace_bytes(const egx_body_model* m, int num_bodies);
 

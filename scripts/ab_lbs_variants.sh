@@ -5,7 +5,7 @@ cp egogen_amd/libegogen_hip.so /tmp/lib_product.so
 ROUNDS=${2:-3}
 for r in $(seq 1 $ROUNDS); do for v in $1; do
   cp ab_libs/lib_$v.so egogen_amd/libegogen_hip.so
-  echo "round $r $v: $(EGX_BENCH_MODES=3 EGX_BENCH_AGENTS=${AGENTS:-512} timeout 300 python scripts/bench_lbs.py 2>&1 | grep -E 'picks\+sdf' | grep -v verts | sed 's/blend.*//' | tr '\n' ';')"
+  echo "round $r $v: $(EGX_BENCH_MODES=3 EGX_BENCH_AGENTS=${AGENTS:-512} timeout 300 python scripts/bench_lbs.py 2>&1 | grep -E 'picks\+sdf' | grep -v verts | sed "s/blend.*fixups/fixups/" | tr '\n' ';')"
 done; done
 if [ -n "${3:-}" ]; then
   cp ab_libs/lib_$3.so egogen_amd/libegogen_hip.so

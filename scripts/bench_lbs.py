@@ -18,7 +18,7 @@ for mode, A in [(m, a) for m in modes for a in agents]:
     T = 20
     B = A * T
     g = torch.Generator().manual_seed(0)
-    xb = (torch.randn(B, 93, generator=g) * 0.2).cuda(); xb[:, 2] += 1
+    xb = (torch.randn(B, 93, generator=g) * 0.2).cuda(); xb[:, 2] += float(os.environ.get("EGX_BENCH_Z", "1"))   # 0.3: legs inside the floor
     betas = torch.randn(A, 10, generator=g).cuda()
     R0 = torch.eye(3).repeat(A, 1, 1).cuda(); T0 = (torch.rand(A, 3, generator=g) * 2 - 1).cuda(); T0[:, 2] = 0
     for name, kw in (("picks", {}), ("picks+sdf", dict(sdf=scene, R0=R0, T0=T0)),
@@ -46,6 +46,7 @@ for mode, A in [(m, a) for m in modes for a in agents]:
             v = C.c_float(); lib.egx_event_elapsed_ms(k0, k1, C.byref(v)); kms.append(v.value)
             lib.egx_event_destroy(k0); lib.egx_event_destroy(k1)
         kms = min(kms)
+        nfix = h.fix_stats(B) if (mode == 3 and "sdf" in name and "verts" not in name) else -1
         flops = B * 31425 * 469 * 2
         print(f"mode={mode} A={A} B={B} {name:10s} {ms:8.3f} ms (fused kernel {kms:6.3f} ms = {flops/kms/1e9:6.1f} TF)  blend {flops/ms/1e9:7.1f} TFLOP/s  "
-              f"{'verts %.1f GB/s' % (B*10475*12/ms/1e6) if 'verts' in name else ''}", flush=True)
+              f"{'verts %.1f GB/s' % (B*10475*12/ms/1e6) if 'verts' in name else ''} fixups {nfix} counted {int(out['pene_count'].sum()) if 'pene_count' in out else -1}", flush=True)

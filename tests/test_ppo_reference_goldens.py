@@ -152,9 +152,15 @@ def test_hip_ppo_learn_matches_reference_execution(case, mode):
         print(f"{case}/{mode} step {i}: clip coefficient {coef:.6f}, worst per-parameter |norm / reference - 1| = "
               f"{float(np.max(np.abs(nrm - refn) / np.maximum(refn, 1e-12))):.2e}")
         np.testing.assert_allclose(nrm, refn, rtol=gtol, atol=1e-7, err_msg=f"step {i} per-parameter gradient norms")
+        # leading entries of every tensor, relative to the tensor's largest entry: fp32 chain 2e-3 (the CPU oracle's tolerance);
+        # the two-term bf16 split (2^-16 per operand) is held to 1e-2 on single entries - its per-tensor norms above are at 2e-4
+        htol = gtol if mode == "f32" else 1e-2
+        worst_h = 0.0
         for j, k in enumerate(names):
             scale = float(sl(k).abs().max()) + 1e-12
-            assert np.abs(np.resize(sl(k)[:8].numpy(), 8) - g[f"{pre}mb{i}_grad_head"][j]).max() <= gtol * scale, (i, k)
+            worst_h = max(worst_h, float(np.abs(np.resize(sl(k)[:8].numpy(), 8) - g[f"{pre}mb{i}_grad_head"][j]).max()) / scale)
+        print(f"{case}/{mode} step {i}: worst leading-entry error / largest entry of its tensor = {worst_h:.2e} (bound {htol:g})")
+        assert worst_h <= htol
         clipped = float(torch.sqrt(sum(sl(k).double().pow(2).sum() for k in names if not k.startswith("shared_net."))))
         assert clipped == pytest.approx(float(g[f"{pre}mb{i}_clipped_set_norm"]), rel=1e-3) and clipped == pytest.approx(0.1, rel=1e-3)
         raw_shared = float(torch.sqrt(sum(sl(k).double().pow(2).sum() for k in names if k.startswith("shared_net."))))
