@@ -649,7 +649,7 @@ def _main():
     # applies only to the configuration that pass was taken on
     traffic = None
     try:
-        for name in (f"r05_lbs_pmc_mode{blend}.json", f"r04_lbs_pmc_mode{blend}.json", f"r03_lbs_pmc_mode{blend}.json",
+        for name in (f"r06_lbs_pmc_mode{blend}.json", f"r05_lbs_pmc_mode{blend}.json", f"r04_lbs_pmc_mode{blend}.json", f"r03_lbs_pmc_mode{blend}.json",
                      f"r02_lbs_pmc_mode{blend}.json"):   # newest round first
             f = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(f):

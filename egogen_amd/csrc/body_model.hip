@@ -239,7 +239,6 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
   __shared__ float sG[4][NJ][12];
   __shared__ __attribute__((aligned(16))) unsigned short sF3[4][3][KS3 * 16];  // bf16x3 planes of the 4 bodies of the block
   __shared__ __attribute__((aligned(16))) unsigned short sF4[4][KS3 * 16];     // fp16 values (mixed blend, k-steps 1..28)
-  __shared__ __attribute__((aligned(16))) unsigned short sA[4][NJ][2][16];   // [body][joint][plane][(a, c) | 4 pad]: the skinning operands A' (32-byte rows: the 16-byte LDS reads below need the alignment)
   const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
   // a block works on four SLOTS of the operand buffers; slot s holds body agent_of_slot[s / fpa] * fpa + s % fpa (identity
   // without the table): inputs and per-body outputs are addressed by body, the GEMM operands by slot
@@ -426,14 +425,29 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
         Arow[r][3] = G[r * 4 + 3] - (G[r * 4 + 0] * Jr[0] + G[r * 4 + 1] * Jr[1] + G[r * 4 + 2] * Jr[2]);
       }
       tn = sqrtf(Arow[0][3] * Arow[0][3] + Arow[1][3] * Arow[1][3] + Arow[2][3] * Arow[2][3]);
-      for (int a = 0; a < 3; ++a)
-        for (int c = 0; c < 4; ++c) {
-          const float v = Mc[a * 3 + 0] * Arow[0][c] + Mc[a * 3 + 1] * Arow[1][c] + Mc[a * 3 + 2] * Arow[2][c];
-          unsigned short h[3];
-          egx_bf16_split3(v, h);
-          sA[w][j][0][a * 4 + c] = h[0];
-          sA[w][j][1][a * 4 + c] = h[1];
+      // the joint's two records (hi and mid plane: 12 entries each), packed in registers and stored straight to the image:
+      // 16 + 8 bytes per plane at [joint][plane][n] (the four bodies of the block are neighbours in n: 64-byte runs)
+      unsigned pk[2][6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        unsigned short hh[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int a = (2 * i + u) >> 2, c = (2 * i + u) & 3;
+          egx_bf16_split3(Mc[a * 3 + 0] * Arow[0][c] + Mc[a * 3 + 1] * Arow[1][c] + Mc[a * 3 + 2] * Arow[2][c], hh[u]);
         }
+        pk[0][i] = (unsigned)hh[0][0] | ((unsigned)hh[1][0] << 16);
+        pk[1][i] = (unsigned)hh[0][1] | ((unsigned)hh[1][1] << 16);
+      }
+      if (live) {
+        unsigned short* base = skinB + (size_t)bt * (SKIN_BT_BYTES / 2);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const size_t rec = ((size_t)j * 2 + pl) * 32 + n;
+          *reinterpret_cast<uint4*>(base + rec * 8) = make_uint4(pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]);
+          *reinterpret_cast<uint2*>(base + (size_t)SKIN_BT_A * 8 + rec * 4) = make_uint2(pk[pl][4], pk[pl][5]);
+        }
+      }
     }
     for (int o = 32; o > 0; o >>= 1) tn = fmaxf(tn, __shfl_xor(tn, o));
     if (live && j == 0) {
@@ -443,19 +457,6 @@ __global__ __launch_bounds__(256) void egx_pose_chain_kernel(const PoseConsts* _
       cinit[slot] = ci;
       // the two-plane products of the skinning add to the body's position error bound (see LBS_SKIN_ERR)
       if (fix_e) fix_e[slot] += LBS_SKIN_ERR * (pc->v_norm_max + tn);
-    }
-    __syncthreads();
-    // per 32-body tile: [joint][plane][n] 16 bytes (rows a = 0, 1) then [joint][plane][n] 8 bytes (row a = 2); the four bodies of the
-    // block are neighbours in n
-    for (int c = threadIdx.x; c < NJ * 2 * 4; c += 256) {
-      const int wb = c & 3, pl = (c >> 2) & 1, jt = c >> 3;
-      const int body = blockIdx.x * 4 + wb;   // slot
-      if (body < B) {
-        unsigned short* base = skinB + (size_t)(body >> 5) * (SKIN_BT_BYTES / 2);
-        const size_t rec = ((size_t)jt * 2 + pl) * 32 + (body & 31);
-        *reinterpret_cast<int4*>(base + rec * 8) = *reinterpret_cast<const int4*>(&sA[wb][jt][pl][0]);
-        *reinterpret_cast<int2*>(base + (size_t)SKIN_BT_A * 8 + rec * 4) = *reinterpret_cast<const int2*>(&sA[wb][jt][pl][8]);
-      }
     }
   }
   if (j < NJ && live) {
