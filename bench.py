@@ -309,6 +309,13 @@ def compact_line(full):
                                               "minibatch_global", "parallelism", "hip_graph_update", "update_paths") if k in cfg}
     line["roofline"] = {k: _r(rf.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
                                                       "launches", "bodies_per_launch", "flop_per_body", "products_per_fp32_product")}
+    # the same launch with every body INSIDE the scene (freshly reset agents): the random-init prior of the timed loop throws most
+    # bodies out of the SDF cube, which flatters the in-loop launch for a trained policy
+    if (rf.get("in_scene") or {}).get("avg_launch_ms") is not None:
+        line["roofline"]["in_scene_avg_launch_ms"] = _r(rf["in_scene"]["avg_launch_ms"], 5)
+        line["roofline"]["in_scene_frac"] = _r(rf["in_scene"].get("frac"), 5)
+    if rf.get("fixups_last_launch_of_loop") is not None:
+        line["roofline"]["fp32_reevaluated_vertices"] = rf["fixups_last_launch_of_loop"]
     if cb is not None:
         line["cpu_baseline"] = {k: _r(cb.get(k), 3) for k in ("value", "unit", "cores", "kind")}
         host = cb.get("host") or {}

@@ -1412,8 +1412,11 @@ constexpr int LBS3_SHARED_BYTES = 2 * 18 * 1024 + 7424;                // stage 
 static_assert(Wg4Cfg<3>::STAGE_PIECES <= 18 && Wg4Cfg<2>::STAGE_PIECES <= 18, "stage ring");
 constexpr int LBS3_RB = 4;                                             // SDF rows per bracket batch
 constexpr int LBS3_QCAP = LBS3_RB * 64 + 64;
+// the small wave tile runs THREE workgroups per CU and must stay below round 5's 53.5 KB of LDS per workgroup to do so (with the
+// fix-up bitmap and thresholds added, 54.0 KB, the launch lost the third workgroup: +45 % at every size): its queue gives up 32 entries
+template <int NBW> constexpr int lbs3_qcap() { return NBW == 1 ? LBS3_RB * 64 + 32 : LBS3_QCAP; }
 // per-wave LDS of the fused3 kernels: penetration counters, fix-up bitmap, fix-up thresholds (32 x NB entries each), queue
-template <int NBW> constexpr int lbs3_wave_bytes() { return 3 * 128 * NBW + LBS3_QCAP * 16; }
+template <int NBW> constexpr int lbs3_wave_bytes() { return 3 * 128 * NBW + lbs3_qcap<NBW>() * 16; }
 
 template <int NPL>
 __device__ __forceinline__ void lbs_blend_split(const LbsParams& p, f32x16 (&acc)[3][LBS_NB], int vt, int bt0, int lane, int wave,
@@ -1658,7 +1661,7 @@ __device__ __forceinline__ void lbs_blend_split2_small(const LbsParams& p, f32x1
 // the launch in 1.07 ms, two in 0.70 (profiles/r05_lbs_mixed.md section 5).
 template <int NBW> constexpr int lbs3_ring_bytes() { return NBW == 1 ? 2 * M4_RING_PIECES * 1024 : 2 * 18 * 1024; }
 template <int NBW> constexpr size_t lbs3_lds_bytes() { return (size_t)lbs3_ring_bytes<NBW>() + 7424 + 4 * lbs3_wave_bytes<NBW>(); }
-static_assert(3 * ((lbs3_lds_bytes<1>() + 511) / 512 * 512) <= 160 * 1024, "three workgroups of the small wave tile share a CU's LDS");
+static_assert(lbs3_lds_bytes<1>() <= 53504, "three workgroups of the small wave tile share a CU's LDS: not above round 5's size");
 
 template <int NPL, bool DO_SDF, int NBW = LBS_NB>
 __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void egx_lbs_fused3_kernel(LbsParams p) {
@@ -1772,14 +1775,14 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void egx_lbs_fused3_kernel(L
     constexpr bool FIX = NPL == 4 && DO_SDF;
 #endif
 #ifdef EGX_LBS_VALU_SKIN   // development builds: the count-only tiles skinned on the VALU as well (fix-up only), for A/B timing
-    lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP, NB, FIX>(p, w, acc, vt, bt0, JT, FIX && vti >= p.n_precise);
+    lbs_epilogue<false, DO_SDF, LBS3_RB, lbs3_qcap<NB>(), NB, FIX>(p, w, acc, vt, bt0, JT, FIX && vti >= p.n_precise);
 #else
     // count-only tiles whose joint list fits one k-step (eight joints: 309 of the 328 tiles of the synthetic body) are skinned on
     // the matrix pipe; the tiles with picked vertices (exact positions) and the long lists take the VALU epilogue - the latter with
     // the fix-up band as well, since their blend product is the cheap one too.  The small wave tile (three workgroups per CU, 168
     // registers) has no room for the twelve operands: VALU epilogue throughout.
-    if (FIX && NB == LBS_NB && vti >= p.n_precise && JT <= 8) lbs_epilogue_cell<LBS3_RB, LBS3_QCAP, NB>(p, w, acc, vt, bt0, JT);
-    else lbs_epilogue<false, DO_SDF, LBS3_RB, LBS3_QCAP, NB, FIX>(p, w, acc, vt, bt0, JT, FIX && vti >= p.n_precise);
+    if (FIX && NB == LBS_NB && vti >= p.n_precise && JT <= 8) lbs_epilogue_cell<LBS3_RB, lbs3_qcap<NB>(), NB>(p, w, acc, vt, bt0, JT);
+    else lbs_epilogue<false, DO_SDF, LBS3_RB, lbs3_qcap<NB>(), NB, FIX>(p, w, acc, vt, bt0, JT, FIX && vti >= p.n_precise);
 #endif
 #ifdef EGX_LBS_TIMING
     w.et[4] += LBS_NOW() - item_t0; w.et[5] += 1;

@@ -285,8 +285,10 @@ __global__ __launch_bounds__(256) void egx_rollout_store_kernel(const float* __r
 // pass 1: per-block partial sums of squares of g[0..n_clip) (double accumulation, fixed order -> deterministic); block 0
 // also advances the step counter, so that pass 2 (a later kernel on the same stream) reads the new value everywhere.
 __global__ __launch_bounds__(256) void egx_sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partials,
-                                                                float* __restrict__ step) {
+                                                                float* __restrict__ step, unsigned* __restrict__ ticket, int do_clip,
+                                                                float max_norm, double lr, double b1, double b2, float* __restrict__ consts) {
   __shared__ double red[256];
+  __shared__ bool s_last;
   double a = 0.0;
   const size_t stride = (size_t)gridDim.x * 256 * 4;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += stride) {
@@ -303,30 +305,34 @@ __global__ __launch_bounds__(256) void egx_sumsq_partial_kernel(const float* __r
     if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partials[blockIdx.x] = (float)red[0];
-}
-
-// pass 1b (one workgroup): total norm -> clip coefficient; bias corrections of the new step count
-__global__ __launch_bounds__(256) void egx_adamw_consts_kernel(const float* __restrict__ partials, int n_partials, int do_clip,
-                                                               float max_norm, double lr, double b1, double b2,
-                                                               const float* __restrict__ step, float* __restrict__ consts) {
-  __shared__ double red[256];
-  double a = 0.0;
-  for (int i = threadIdx.x; i < n_partials; i += 256) a += partials[i];
-  red[threadIdx.x] = a;
+  // pass 1b, by the LAST block to get here (until round 6 a launch of its own - 5 us of every optimiser step): total norm -> clip
+  // coefficient; bias corrections of the new step count.  Every block publishes its partial sum (block 0 also the new step count)
+  // before it takes a ticket; the block that draws the last ticket sees them all, and leaves the ticket counter at zero.
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = (float)red[0];
+    __threadfence();
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  double t = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += (double)*reinterpret_cast<volatile float*>(partials + i);
+  red[threadIdx.x] = t;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
     if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double t = (double)*step;
-    const float bc1 = (float)(1.0 - pow(b1, t)), bc2 = (float)(1.0 - pow(b2, t));
+    const double tt = (double)*reinterpret_cast<volatile float*>(step);
+    const float bc1 = (float)(1.0 - pow(b1, tt)), bc2 = (float)(1.0 - pow(b2, tt));
     float coef = 1.f;
     if (do_clip) coef = fminf(max_norm / ((float)sqrt(red[0]) + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
     consts[0] = coef;
     consts[1] = (float)(lr / bc1);
     consts[2] = sqrtf(bc2);
+    *ticket = 0u;
   }
 }
 
@@ -491,7 +497,7 @@ extern "C" int egx_rollout_store(const float* state, const float* egosensing, co
   return EGX_OK;
 }
 
-extern "C" size_t egx_adamw_workspace_floats(void) { return 1024 + 8; }
+extern "C" size_t egx_adamw_workspace_floats(void) { return 1024 + 8 + 8; }   // partials | constants | ticket (zeroed once by the caller)
 
 extern "C" int egx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_clip,
                                    float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
@@ -500,9 +506,9 @@ extern "C" int egx_adamw_clip_step(float* param, const float* grad, float* exp_a
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int nb = 1024;
   const bool do_clip = max_norm > 0.f && n_clip > 0;
-  hipLaunchKernelGGL(egx_sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, grad, do_clip ? n_clip : (size_t)0, workspace, step);
-  hipLaunchKernelGGL(egx_adamw_consts_kernel, dim3(1), dim3(256), 0, st, workspace, nb, do_clip ? 1 : 0, max_norm, lr, beta1, beta2,
-                     step, workspace + nb);
+  // norm of the clipped prefix + (last block) clip coefficient and bias corrections: workspace = partials[nb] | consts[8] | ticket
+  hipLaunchKernelGGL(egx_sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, grad, do_clip ? n_clip : (size_t)0, workspace, step,
+                     reinterpret_cast<unsigned*>(workspace + nb + 8), do_clip ? 1 : 0, max_norm, lr, beta1, beta2, workspace + nb);
   const size_t blocks = (n + 1023) / 1024;
   hipLaunchKernelGGL(egx_adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, n_clip,
                      workspace + nb, lr, beta1, beta2, eps, weight_decay);

@@ -655,7 +655,9 @@ int egx_rollout_store(const float* state, const float* egosensing, const float* 
  * n_clip elements is clipped to max_norm (skipped when max_norm <= 0), then AdamW with decoupled weight decay and bias
  * correction (torch.optim.AdamW arithmetic [upstream torch]) updates param / exp_avg / exp_avg_sq in place.  `step` is a
  * device scalar holding the number of steps taken so far; it is incremented by the call.  workspace: device floats,
- * egx_adamw_workspace_floats() of them.  grad is left unscaled.  Hyper-parameters are doubles, as torch passes them. */
+ * egx_adamw_workspace_floats() of them, ZEROED once by the caller (a block counter lives there; every call leaves it zero again);
+ * workspace[1024] holds the clip coefficient of the last call.  grad is left unscaled.  Hyper-parameters are doubles, as torch
+ * passes them.  Two launches: squared norm + (its last block) clip coefficient and bias corrections; the element-wise update. */
 size_t egx_adamw_workspace_floats(void);
 int egx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_clip,
                         float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay, float* step,
