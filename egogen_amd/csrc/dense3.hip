@@ -503,7 +503,10 @@ __global__ __launch_bounds__(512) void egx_gru3_kernel(D3Gru2 two) {
 // input: fp32 into `out` (row stride ld, the residual of the first MLP unit) and packed into k-steps s0 .. s0 + 3 of `out3`.
 __global__ __launch_bounds__(256) void egx_posenc3_kernel(const float* __restrict__ dist, const float* __restrict__ time, int n,
                                                           float* __restrict__ out, int ld, bf16x8* __restrict__ out3, int S3, int s0,
-                                                          bf16x8* __restrict__ out3T, int S3T, int col0T) {
+                                                          bf16x8* __restrict__ out3T, int S3T, int col0T, float* __restrict__ zero6) {
+  // (the update chain's loss kernel accumulates six sums with atomics: cleared here, several launches ahead of it, instead of
+  // by a launch of their own)
+  if (zero6 && blockIdx.x == 0 && threadIdx.x < 6) zero6[threadIdx.x] = 0.f;
   int frag = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int RT = 2 * ((n + 31) >> 5);
@@ -553,10 +556,10 @@ __global__ __launch_bounds__(256) void egx_posenc3_kernel(const float* __restric
   for (int p = 0; p < 3; ++p) o[p * 64] = pl[p];
 }
 void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, int n, float* out, int ld, void* out3, int S3, int s0,
-                        void* out3T, int S3T, int col0T) {
+                        void* out3T, int S3T, int col0T, float* zero6) {
   const int frags = 2 * egx_ceil_div(n, 32) * 4 + (out3T ? 8 * egx_ceil_div(n, 32) : 0);
   hipLaunchKernelGGL(egx_posenc3_kernel, dim3(egx_ceil_div(frags, 4)), dim3(256), 0, st, dist, time, n, out, ld,
-                     static_cast<bf16x8*>(out3), S3, s0, static_cast<bf16x8*>(out3T), S3T, col0T);
+                     static_cast<bf16x8*>(out3), S3, s0, static_cast<bf16x8*>(out3T), S3T, col0T, zero6);
 }
 
 // ---------------------------------------------------------------------------------------------------------

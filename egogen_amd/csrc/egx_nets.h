@@ -68,8 +68,13 @@ void egx_launch_dense3_n(hipStream_t st, const D3Plain* ps, int n);   // up to f
 void egx_launch_dense3(hipStream_t st, const D3Plain& p);
 void egx_launch_dense3_pair(hipStream_t st, const D3Plain& p, const D3Plain& q);  // two independent layers, one launch
 void egx_launch_dense3_triple(hipStream_t st, const D3Plain& p, const D3Plain& q, const D3Plain& r);
+// egx_ppo_loss_packed without its clearing launch (ppo.hip): the caller has cleared out_terms earlier on the same stream
+int egx_ppo_loss_packed_precleared(const float* zp, const float* value, const float* act, const float* adv, const float* ret,
+                                   const float* logp_old, const float* adv_stats, const float* scale, float adv_eps, float min_logvar,
+                                   float max_logvar, float eps_clip, float vf_coef, float ent_coef, int num_rows, float* g_zp,
+                                   float* g_value, float* out_terms, void* stream_);
 void egx_launch_posenc3(hipStream_t st, const float* dist, const float* time, int n, float* out, int ld, void* out3, int S3, int s0,
-                        void* out3T = nullptr, int S3T = 0, int col0T = 0);
+                        void* out3T = nullptr, int S3T = 0, int col0T = 0, float* zero6 = nullptr /* six floats cleared by the launch */);
 
 // One GRU cell step (gate order r, z, n; weights [3H, K] packed): see egx_gru3_kernel.
 struct D3Gru {

@@ -166,6 +166,10 @@ struct GatherArgs {  // scalar fields only (a runtime-indexed array inside kerne
   int w0, w1, w2, w3, w4, w5, w6, w7;
   const long long* idx;
   int n;
+  // optional (egx_gather_rows_adv_stats): {mean, unbiased std} of one gathered one-column tensor, by the last block to finish
+  const float* stats_src;   // that tensor's DESTINATION [n]
+  float* stats_out;         // [2]
+  unsigned* ticket;         // block counter, zero between launches
 };
 __device__ __forceinline__ void gather_seg(const float* __restrict__ s, float* __restrict__ d, int w, long long src_row, int dst_row) {
   if (!s || w <= 0) return;
@@ -180,6 +184,46 @@ __global__ __launch_bounds__(256) void egx_gather_rows_kernel(GatherArgs a) {
   gather_seg(a.s2, a.d2, a.w2, src, r); gather_seg(a.s3, a.d3, a.w3, src, r);
   gather_seg(a.s4, a.d4, a.w4, src, r); gather_seg(a.s5, a.d5, a.w5, src, r);
   gather_seg(a.s6, a.d6, a.w6, src, r); gather_seg(a.s7, a.d7, a.w7, src, r);
+  if (!a.stats_out) return;
+  // advantage statistics of the minibatch (egx_adv_stats_kernel's two-pass arithmetic) without a launch of their own: every block
+  // publishes its row before it takes a ticket, the block that draws the last one sees all n advantages
+  __shared__ bool s_last;
+  __shared__ double red[256];
+  __shared__ double s_mean;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const volatile float* adv = a.stats_src;
+  const int n = a.n;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) t += adv[i];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_mean = red[0] / n;
+  __syncthreads();
+  const double mean = s_mean;
+  double b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { const double d = adv[i] - mean; b += d * d; }
+  red[threadIdx.x] = b;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    a.stats_out[0] = (float)mean;
+    a.stats_out[1] = (n > 1) ? (float)sqrt(red[0] / (n - 1)) : nanf("");
+    *a.ticket = 0u;
+  }
 }
 
 // mean and UNBIASED standard deviation of the minibatch advantages (ppo_policy.py:195-197: adv.mean(), adv.std())
@@ -400,6 +444,20 @@ extern "C" int egx_ppo_loss(const float* mu, const float* logvar, const float* v
   return EGX_OK;
 }
 
+// the update chain's form (csrc/update3.hip): out_terms was cleared by an earlier launch of the chain (egx_launch_posenc3)
+int egx_ppo_loss_packed_precleared(const float* zp, const float* value, const float* act, const float* adv, const float* ret,
+                                   const float* logp_old, const float* adv_stats, const float* scale, float adv_eps, float min_logvar,
+                                   float max_logvar, float eps_clip, float vf_coef, float ent_coef, int num_rows, float* g_zp,
+                                   float* g_value, float* out_terms, void* stream_) {
+  EGX_REQUIRE(zp && value && act && adv && ret && logp_old && scale && g_zp && g_value && out_terms && num_rows > 0, "bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(egx_ppo_loss_kernel, dim3(ppo_loss_blocks(num_rows)), dim3(256), 0, st, zp, zp + 128, value, act, adv, ret, logp_old, adv_stats,
+                     scale, adv_eps, min_logvar, max_logvar, eps_clip, vf_coef, ent_coef, num_rows, 256, g_zp, g_zp + 128, g_value,
+                     out_terms);
+  EGX_HIP_CHECK(hipGetLastError());
+  return EGX_OK;
+}
+
 extern "C" int egx_ppo_loss_packed(const float* zp, const float* value, const float* act, const float* adv, const float* ret,
                                    const float* logp_old, const float* adv_stats, const float* scale, float adv_eps, float min_logvar,
                                    float max_logvar, float eps_clip, float vf_coef, float ent_coef, int num_rows, float* g_zp,
@@ -449,8 +507,23 @@ extern "C" int egx_act_bwd_colsum(const float* dy, const float* a, float* g, flo
   return EGX_OK;
 }
 
+static int gather_rows_impl(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
+                            float* const* dst, int stats_tensor, float* out_mean_std, uint32_t* ticket, void* stream_);
+
 extern "C" int egx_gather_rows(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
                                float* const* dst, void* stream_) {
+  return gather_rows_impl(idx, num_rows, num_tensors, src, width, dst, -1, nullptr, nullptr, stream_);
+}
+
+extern "C" int egx_gather_rows_adv_stats(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
+                                         float* const* dst, int stats_tensor, float* out_mean_std, uint32_t* ticket, void* stream_) {
+  EGX_REQUIRE(stats_tensor >= 0 && stats_tensor < num_tensors && out_mean_std && ticket, "statistics need a tensor index, an output and a ticket counter");
+  EGX_REQUIRE(width && width[stats_tensor] == 1, "the statistics tensor must have one column");
+  return gather_rows_impl(idx, num_rows, num_tensors, src, width, dst, stats_tensor, out_mean_std, ticket, stream_);
+}
+
+static int gather_rows_impl(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
+                            float* const* dst, int stats_tensor, float* out_mean_std, uint32_t* ticket, void* stream_) {
   EGX_REQUIRE(idx && src && width && dst && num_rows > 0 && num_tensors > 0 && num_tensors <= 8, "bad arguments");
   GatherArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -463,6 +536,7 @@ extern "C" int egx_gather_rows(const int64_t* idx, int num_rows, int num_tensors
   }
   a.idx = reinterpret_cast<const long long*>(idx);
   a.n = num_rows;
+  if (stats_tensor >= 0) { a.stats_src = dst[stats_tensor]; a.stats_out = out_mean_std; a.ticket = ticket; }
   hipLaunchKernelGGL(egx_gather_rows_kernel, dim3(num_rows), dim3(256), 0, static_cast<hipStream_t>(stream_), a);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;

@@ -544,7 +544,7 @@ static int train_step_parts(egx_policy_train* h, const float* dist, const float*
   if (parts & 1) {
   // ================= forward =================
   run_table(st, h->tab_inputs, h->n_inputs, h->frags_inputs, planes_of(h->prec));
-  egx_launch_posenc3(st, dist, time, n, h->catf + 2 * HD, CAT, h->cat_r, S_CAT, 2 * S_HD, h->catT, Sn, 2 * HD);
+  egx_launch_posenc3(st, dist, time, n, h->catf + 2 * HD, CAT, h->cat_r, S_CAT, 2 * S_HD, h->catT, Sn, 2 * HD, out_terms);   // also clears the loss sums
   {
     D3Gru g[2];
     for (int e = 0; e < 2; ++e) {   // step 1: zero previous state
@@ -603,7 +603,7 @@ static int train_step_parts(egx_policy_train* h, const float* dist, const float*
     launch_n(st, L, 2);
   }
   // ================= loss and its gradient w.r.t. the two heads (ppo_policy.py:189-241) =================
-  rc = egx_ppo_loss_packed(h->br[0].head, h->br[1].head, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_logvar, max_logvar,
+  rc = egx_ppo_loss_packed_precleared(h->br[0].head, h->br[1].head, act, adv, ret, logp_old, adv_stats, scale, adv_eps, min_logvar, max_logvar,
                                eps_clip, vf_coef, ent_coef, n, h->br[0].ghead, h->br[1].ghead, out_terms, st);
   if (rc) return rc;
   run_table(st, h->tab_loss, h->n_loss, h->frags_loss, planes_of(h->prec));

@@ -128,9 +128,11 @@ int egx_lbs_cull_stats(const egx_body_model* m, const void* workspace, int num_b
  *      MFMAs per wave and work item, a third of the operand bytes.  Those vertices move by ~4e-6 m rms / ~2.2e-5 m worst case
  *      against float64 on the synthetic body, so the cheap product only CLASSIFIES: a vertex whose interpolated SDF value is
  *      closer to zero than its position error can account for (ten standard deviations of the product's rounding error for
- *      that body's pose, times the steepest slope of the grid) is re-evaluated inside the kernel in fp32 (three-plane operand
- *      images, fp32 skinning) and counted from that - a few per thousand counted vertices.  The counts are those of an fp32
- *      evaluation (crowd_env_2f.py:169-177): the parity tests hold every mode to the same 2e-5 m level-set band, and
+ *      that body's pose - plus, in launches of more than 5 120 bodies, whose count-only tiles are also SKINNED on the matrix
+ *      pipe in two bf16 planes, an allowance for that - times the steepest slope of the grid) is queued and re-evaluated in
+ *      fp32 by a small kernel launched behind the fused one (vertex-major fp32 bases, the body's rotations recomputed from its
+ *      parameter row, fp32 skinning) and counted from that - a few per thousand counted vertices.  The counts are those of an
+ *      fp32 evaluation (crowd_env_2f.py:169-177): the parity tests hold every mode to the same 2e-5 m level-set band, and
  *      egx_lbs_fix_stats reads how many vertices the last call re-evaluated.  Positions are unaffected.
  * An unrecognised EGX_LBS_BLEND string is an error of the first egx_lbs_forward call (no silent default).
  * (No reference counterpart: smplx evaluates the blend shapes as fp32 einsum/matmul, lbs.py [upstream smplx 0.1.28].) */
@@ -142,8 +144,9 @@ int egx_lbs_get_blend_mode(void);
  * parity tests run both on the same inputs. */
 int egx_lbs_set_wave_tile(int tile);
 int egx_lbs_get_wave_tile(void);
-/* Mode 3 only: entries of each of the 64 sub-queues of the launch's fix-up queue that are used (0 = all 4 096).  Vertices that find the queue full are
- * re-evaluated inside the fused kernel instead - slower, same result; the parity tests shrink the queue to exercise that path. */
+/* Mode 3 only: entries of each of the 64 sub-queues of the launch's fix-up queue that are used (0 = all 4 096).  Vertices that
+ * find their sub-queue full are re-evaluated inside the fused kernel instead - slower, same result; the parity tests shrink the
+ * queue to exercise that path. */
 int egx_lbs_set_fix_queue_capacity(int entries);
 /* Mode 3 only: vertices the last SDF-counting egx_lbs_forward call on this workspace re-evaluated in fp32 (host synchronisation). */
 int egx_lbs_fix_stats(const egx_body_model* m, const void* workspace, int num_bodies, int32_t* out_reevaluated);
@@ -634,6 +637,11 @@ int egx_act_bwd_colsum(const float* dy, const float* a, float* g, float* db_accu
  * src / width / dst are HOST arrays of device pointers / row widths. */
 int egx_gather_rows(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
                     float* const* dst, void* stream);
+/* The same launch + egx_adv_stats of the gathered one-column tensor `stats_tensor` (the minibatch's advantages,
+ * ppo_policy.py:195-197) computed by its last block: out_mean_std = {mean, unbiased std}.  `ticket`: one device uint32, zeroed
+ * once by the caller (every call leaves it zero again). */
+int egx_gather_rows_adv_stats(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
+                              float* const* dst, int stats_tensor, float* out_mean_std, uint32_t* ticket, void* stream);
 
 /* Advantage normalisation statistics of one minibatch (ppo_policy.py:195-197): out = {mean, unbiased std}. */
 int egx_adv_stats(const float* adv, int n, float* out_mean_std, void* stream);
