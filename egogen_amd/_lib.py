@@ -175,8 +175,6 @@ SIGNATURES = {
     "egx_lbs_set_fix_queue_capacity": (C.c_int, [C.c_int]),
     "egx_lbs_fix_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "egx_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "egx_gather_rows_adv_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                            C.c_void_p]),
     "egx_adv_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "egx_track_episode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egx_rollout_store": (C.c_int, [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 10),

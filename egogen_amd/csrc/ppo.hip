@@ -166,10 +166,6 @@ struct GatherArgs {  // scalar fields only (a runtime-indexed array inside kerne
   int w0, w1, w2, w3, w4, w5, w6, w7;
   const long long* idx;
   int n;
-  // optional (egx_gather_rows_adv_stats): {mean, unbiased std} of one gathered one-column tensor, by the last block to finish
-  const float* stats_src;   // that tensor's DESTINATION [n]
-  float* stats_out;         // [2]
-  unsigned* ticket;         // block counter, zero between launches
 };
 __device__ __forceinline__ void gather_seg(const float* __restrict__ s, float* __restrict__ d, int w, long long src_row, int dst_row) {
   if (!s || w <= 0) return;
@@ -184,46 +180,6 @@ __global__ __launch_bounds__(256) void egx_gather_rows_kernel(GatherArgs a) {
   gather_seg(a.s2, a.d2, a.w2, src, r); gather_seg(a.s3, a.d3, a.w3, src, r);
   gather_seg(a.s4, a.d4, a.w4, src, r); gather_seg(a.s5, a.d5, a.w5, src, r);
   gather_seg(a.s6, a.d6, a.w6, src, r); gather_seg(a.s7, a.d7, a.w7, src, r);
-  if (!a.stats_out) return;
-  // advantage statistics of the minibatch (egx_adv_stats_kernel's two-pass arithmetic) without a launch of their own: every block
-  // publishes its row before it takes a ticket, the block that draws the last one sees all n advantages
-  __shared__ bool s_last;
-  __shared__ double red[256];
-  __shared__ double s_mean;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  const volatile float* adv = a.stats_src;
-  const int n = a.n;
-  double t = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) t += adv[i];
-  red[threadIdx.x] = t;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) s_mean = red[0] / n;
-  __syncthreads();
-  const double mean = s_mean;
-  double b = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) { const double d = adv[i] - mean; b += d * d; }
-  red[threadIdx.x] = b;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    a.stats_out[0] = (float)mean;
-    a.stats_out[1] = (n > 1) ? (float)sqrt(red[0] / (n - 1)) : nanf("");
-    *a.ticket = 0u;
-  }
 }
 
 // mean and UNBIASED standard deviation of the minibatch advantages (ppo_policy.py:195-197: adv.mean(), adv.std())
@@ -329,10 +285,8 @@ __global__ __launch_bounds__(256) void egx_rollout_store_kernel(const float* __r
 // pass 1: per-block partial sums of squares of g[0..n_clip) (double accumulation, fixed order -> deterministic); block 0
 // also advances the step counter, so that pass 2 (a later kernel on the same stream) reads the new value everywhere.
 __global__ __launch_bounds__(256) void egx_sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partials,
-                                                                float* __restrict__ step, unsigned* __restrict__ ticket, int do_clip,
-                                                                float max_norm, double lr, double b1, double b2, float* __restrict__ consts) {
+                                                                float* __restrict__ step) {
   __shared__ double red[256];
-  __shared__ bool s_last;
   double a = 0.0;
   const size_t stride = (size_t)gridDim.x * 256 * 4;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += stride) {
@@ -349,34 +303,30 @@ __global__ __launch_bounds__(256) void egx_sumsq_partial_kernel(const float* __r
     if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
-  // pass 1b, by the LAST block to get here (until round 6 a launch of its own - 5 us of every optimiser step): total norm -> clip
-  // coefficient; bias corrections of the new step count.  Every block publishes its partial sum (block 0 also the new step count)
-  // before it takes a ticket; the block that draws the last ticket sees them all, and leaves the ticket counter at zero.
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = (float)red[0];
-    __threadfence();
-    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  double t = 0.0;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += (double)*reinterpret_cast<volatile float*>(partials + i);
-  red[threadIdx.x] = t;
+  if (threadIdx.x == 0) partials[blockIdx.x] = (float)red[0];
+}
+
+// pass 1b (one workgroup): total norm -> clip coefficient; bias corrections of the new step count
+__global__ __launch_bounds__(256) void egx_adamw_consts_kernel(const float* __restrict__ partials, int n_partials, int do_clip,
+                                                               float max_norm, double lr, double b1, double b2,
+                                                               const float* __restrict__ step, float* __restrict__ consts) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += 256) a += partials[i];
+  red[threadIdx.x] = a;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
     if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double tt = (double)*reinterpret_cast<volatile float*>(step);
-    const float bc1 = (float)(1.0 - pow(b1, tt)), bc2 = (float)(1.0 - pow(b2, tt));
+    const double t = (double)*step;
+    const float bc1 = (float)(1.0 - pow(b1, t)), bc2 = (float)(1.0 - pow(b2, t));
     float coef = 1.f;
     if (do_clip) coef = fminf(max_norm / ((float)sqrt(red[0]) + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
     consts[0] = coef;
     consts[1] = (float)(lr / bc1);
     consts[2] = sqrtf(bc2);
-    *ticket = 0u;
   }
 }
 
@@ -507,23 +457,8 @@ extern "C" int egx_act_bwd_colsum(const float* dy, const float* a, float* g, flo
   return EGX_OK;
 }
 
-static int gather_rows_impl(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
-                            float* const* dst, int stats_tensor, float* out_mean_std, uint32_t* ticket, void* stream_);
-
 extern "C" int egx_gather_rows(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
                                float* const* dst, void* stream_) {
-  return gather_rows_impl(idx, num_rows, num_tensors, src, width, dst, -1, nullptr, nullptr, stream_);
-}
-
-extern "C" int egx_gather_rows_adv_stats(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
-                                         float* const* dst, int stats_tensor, float* out_mean_std, uint32_t* ticket, void* stream_) {
-  EGX_REQUIRE(stats_tensor >= 0 && stats_tensor < num_tensors && out_mean_std && ticket, "statistics need a tensor index, an output and a ticket counter");
-  EGX_REQUIRE(width && width[stats_tensor] == 1, "the statistics tensor must have one column");
-  return gather_rows_impl(idx, num_rows, num_tensors, src, width, dst, stats_tensor, out_mean_std, ticket, stream_);
-}
-
-static int gather_rows_impl(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
-                            float* const* dst, int stats_tensor, float* out_mean_std, uint32_t* ticket, void* stream_) {
   EGX_REQUIRE(idx && src && width && dst && num_rows > 0 && num_tensors > 0 && num_tensors <= 8, "bad arguments");
   GatherArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -536,7 +471,6 @@ static int gather_rows_impl(const int64_t* idx, int num_rows, int num_tensors, c
   }
   a.idx = reinterpret_cast<const long long*>(idx);
   a.n = num_rows;
-  if (stats_tensor >= 0) { a.stats_src = dst[stats_tensor]; a.stats_out = out_mean_std; a.ticket = ticket; }
   hipLaunchKernelGGL(egx_gather_rows_kernel, dim3(num_rows), dim3(256), 0, static_cast<hipStream_t>(stream_), a);
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
@@ -571,7 +505,7 @@ extern "C" int egx_rollout_store(const float* state, const float* egosensing, co
   return EGX_OK;
 }
 
-extern "C" size_t egx_adamw_workspace_floats(void) { return 1024 + 8 + 8; }   // partials | constants | ticket (zeroed once by the caller)
+extern "C" size_t egx_adamw_workspace_floats(void) { return 1024 + 8; }
 
 extern "C" int egx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_clip,
                                    float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
@@ -580,9 +514,9 @@ extern "C" int egx_adamw_clip_step(float* param, const float* grad, float* exp_a
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int nb = 1024;
   const bool do_clip = max_norm > 0.f && n_clip > 0;
-  // norm of the clipped prefix + (last block) clip coefficient and bias corrections: workspace = partials[nb] | consts[8] | ticket
-  hipLaunchKernelGGL(egx_sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, grad, do_clip ? n_clip : (size_t)0, workspace, step,
-                     reinterpret_cast<unsigned*>(workspace + nb + 8), do_clip ? 1 : 0, max_norm, lr, beta1, beta2, workspace + nb);
+  hipLaunchKernelGGL(egx_sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, grad, do_clip ? n_clip : (size_t)0, workspace, step);
+  hipLaunchKernelGGL(egx_adamw_consts_kernel, dim3(1), dim3(256), 0, st, workspace, nb, do_clip ? 1 : 0, max_norm, lr, beta1, beta2,
+                     step, workspace + nb);
   const size_t blocks = (n + 1023) / 1024;
   hipLaunchKernelGGL(egx_adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, n_clip,
                      workspace + nb, lr, beta1, beta2, eps, weight_decay);

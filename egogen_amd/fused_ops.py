@@ -243,10 +243,8 @@ def linear_act(x, lin: torch.nn.Linear, act="none", slope=0.01, res=None):
     return LinearFn.apply(x, lin.weight, lin.bias, lin.weight.grad, lin.bias.grad, ACT_CODE[act], slope, res)
 
 
-def gather_rows(idx: torch.Tensor, srcs, out=None, stats=None):
-    """dst[t][r] = src[t][idx[r]] for up to 8 dense fp32 tensors (leading dimension = rows) in ONE launch.
-    `stats` = (tensor index, out[2], ticket[1] int32 zeros): the same launch also leaves {mean, unbiased std} of that gathered
-    one-column tensor in out (`egx_gather_rows_adv_stats`: the minibatch's advantage statistics without a launch of their own)."""
+def gather_rows(idx: torch.Tensor, srcs, out=None):
+    """dst[t][r] = src[t][idx[r]] for up to 8 dense fp32 tensors (leading dimension = rows) in ONE launch."""
     import ctypes as C
     lib = _lib.load()
     n = int(idx.shape[0])
@@ -258,12 +256,7 @@ def gather_rows(idx: torch.Tensor, srcs, out=None, stats=None):
     sp = (C.c_void_p * k)(*[s.data_ptr() for s in srcs])
     dp = (C.c_void_p * k)(*[o.data_ptr() for o in out])
     wp = (C.c_int * k)(*widths)
-    if stats is not None:
-        t, st_out, ticket = stats
-        _lib.check(lib.egx_gather_rows_adv_stats(_lib.ptr(idx), n, k, sp, wp, dp, int(t), _lib.ptr(st_out), _lib.ptr(ticket),
-                                                 _lib.current_stream_ptr()), "egx_gather_rows_adv_stats")
-    else:
-        _lib.check(lib.egx_gather_rows(_lib.ptr(idx), n, k, sp, wp, dp, _lib.current_stream_ptr()), "egx_gather_rows")
+    _lib.check(lib.egx_gather_rows(_lib.ptr(idx), n, k, sp, wp, dp, _lib.current_stream_ptr()), "egx_gather_rows")
     return out
 
 

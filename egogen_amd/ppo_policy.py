@@ -356,7 +356,7 @@ class GAMMAPPOPolicy(nn.Module):
         _lib.check(lib.egx_policy_train_bind(h, _lib.ptr(bufs[0]), _lib.ptr(bufs[1])), "egx_policy_train_bind")
         packed = _lib.PolicyPacked3()
         _lib.check(lib.egx_policy_train_packed(h, C.byref(packed)), "egx_policy_train_packed")
-        hs = {"h": h, "bufs": bufs, "stats": torch.zeros(2, **f), "ticket": torch.zeros(1, dtype=torch.int32, device=f["device"]), "key": (w.x_enc_w_ih, g.x_enc_w_ih), "packed": packed}
+        hs = {"h": h, "bufs": bufs, "stats": torch.zeros(2, **f), "key": (w.x_enc_w_ih, g.x_enc_w_ih), "packed": packed}
         self._train_handles[n] = hs
         if len(self._train_handles) == 1:   # the rollout forward reads the images this handle keeps current
             self._runner.adopt_packed(packed, refresh=self._refresh_images)
@@ -413,13 +413,13 @@ class GAMMAPPOPolicy(nn.Module):
         N = batch.n * batch.A
         obs_all = batch.obs_flat()
         b = hs["bufs"]
-        # one launch: the minibatch's rows and - single process - its advantage statistics (tensor 5), by the launch's last block
         gather_rows(idx, [obs_all["state"].reshape(N, 804), obs_all["egosensing"].reshape(N, 64), obs_all["dist"].reshape(N, 1),
                           obs_all["time"].reshape(N, 1), batch.act.reshape(N, 128), batch.adv.reshape(N, 1), batch.returns.reshape(N, 1),
-                          batch.logp_old.reshape(N, 1)], out=b, stats=(5, hs["stats"], hs["ticket"]) if gstats is None else None)
+                          batch.logp_old.reshape(N, 1)], out=b)
         n = int(idx.shape[0])
         dev = b[0].device
         if gstats is None:
+            _lib.check(lib.egx_adv_stats(_lib.ptr(b[5]), n, _lib.ptr(hs["stats"]), st), "egx_adv_stats")
             scale = self._scale_cache.get((n, dev))
             if scale is None:
                 scale = torch.full((1,), 1.0 / n, dtype=torch.float32, device=dev)

@@ -637,11 +637,6 @@ int egx_act_bwd_colsum(const float* dy, const float* a, float* g, float* db_accu
  * src / width / dst are HOST arrays of device pointers / row widths. */
 int egx_gather_rows(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
                     float* const* dst, void* stream);
-/* The same launch + egx_adv_stats of the gathered one-column tensor `stats_tensor` (the minibatch's advantages,
- * ppo_policy.py:195-197) computed by its last block: out_mean_std = {mean, unbiased std}.  `ticket`: one device uint32, zeroed
- * once by the caller (every call leaves it zero again). */
-int egx_gather_rows_adv_stats(const int64_t* idx, int num_rows, int num_tensors, const float* const* src, const int* width,
-                              float* const* dst, int stats_tensor, float* out_mean_std, uint32_t* ticket, void* stream);
 
 /* Advantage normalisation statistics of one minibatch (ppo_policy.py:195-197): out = {mean, unbiased std}. */
 int egx_adv_stats(const float* adv, int n, float* out_mean_std, void* stream);
@@ -663,9 +658,8 @@ int egx_rollout_store(const float* state, const float* egosensing, const float* 
  * n_clip elements is clipped to max_norm (skipped when max_norm <= 0), then AdamW with decoupled weight decay and bias
  * correction (torch.optim.AdamW arithmetic [upstream torch]) updates param / exp_avg / exp_avg_sq in place.  `step` is a
  * device scalar holding the number of steps taken so far; it is incremented by the call.  workspace: device floats,
- * egx_adamw_workspace_floats() of them, ZEROED once by the caller (a block counter lives there; every call leaves it zero again);
- * workspace[1024] holds the clip coefficient of the last call.  grad is left unscaled.  Hyper-parameters are doubles, as torch
- * passes them.  Two launches: squared norm + (its last block) clip coefficient and bias corrections; the element-wise update. */
+ * egx_adamw_workspace_floats() of them; workspace[1024] holds the clip coefficient of the last call.  grad is left unscaled.
+ * Hyper-parameters are doubles, as torch passes them. */
 size_t egx_adamw_workspace_floats(void);
 int egx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_clip,
                         float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay, float* step,
