@@ -23,6 +23,69 @@ __global__ __launch_bounds__(256) void egx_sdf_sample_kernel(SdfDev s, const flo
   }
 }
 
+// The same values from the bricked copy of the grid (egx_common.h: egx_sdf_bricks_offset; built by egx_sdf_build_coarse): what
+// bounds the kernel above is the number of 128-byte lines its corner gathers pull from L2, and a point's eight corners span four
+// lines of the row-major grid but 2.3 on average of the bricked one.  Same samples, same arithmetic: bit-identical values.
+__device__ __forceinline__ float egx_brick_at(const float* __restrict__ bricks, unsigned nb1, unsigned nb2, unsigned x, unsigned y, unsigned z) {
+  const unsigned b = ((x >> 2) * nb1 + (y >> 2)) * nb2 + (z >> 2);
+  return bricks[(size_t)b * 64 + ((x & 3) << 4) + ((y & 3) << 2) + (z & 3)];
+}
+__device__ __forceinline__ float egx_sdf_neg_trilinear_bricks(const SdfDev& s, const float* __restrict__ bricks, float x, float y, float z) {
+  float px, py, pz;
+  egx_sdf_voxel_coords(s, x, y, z, px, py, pz);
+  const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+  const float wx1 = egx_sub(px, x0), wy1 = egx_sub(py, y0), wz1 = egx_sub(pz, z0);
+  const float wx0 = egx_sub(egx_add(x0, 1.f), px), wy0 = egx_sub(egx_add(y0, 1.f), py), wz0 = egx_sub(egx_add(z0, 1.f), pz);
+  const unsigned ix0 = (unsigned)x0, iy0 = (unsigned)y0, iz0 = (unsigned)z0;
+  const bool x1_in = ix0 + 1 < (unsigned)s.d0, y1_in = iy0 + 1 < (unsigned)s.d1, z1_in = iz0 + 1 < (unsigned)s.d2;
+  const unsigned zb = z1_in ? iz0 : iz0 - 1;                      // pair (zb, zb+1) always inside the row
+  const unsigned ix1 = x1_in ? ix0 + 1 : ix0, iy1 = y1_in ? iy0 + 1 : iy0;   // off-grid corners: weight exactly 0, any valid sample
+  const unsigned nb1 = (unsigned)s.c1, nb2 = (unsigned)s.c2;
+  const float c00x = egx_brick_at(bricks, nb1, nb2, ix0, iy0, zb), c00y = egx_brick_at(bricks, nb1, nb2, ix0, iy0, zb + 1);
+  const float c01x = egx_brick_at(bricks, nb1, nb2, ix0, iy1, zb), c01y = egx_brick_at(bricks, nb1, nb2, ix0, iy1, zb + 1);
+  const float c10x = egx_brick_at(bricks, nb1, nb2, ix1, iy0, zb), c10y = egx_brick_at(bricks, nb1, nb2, ix1, iy0, zb + 1);
+  const float c11x = egx_brick_at(bricks, nb1, nb2, ix1, iy1, zb), c11y = egx_brick_at(bricks, nb1, nb2, ix1, iy1, zb + 1);
+  const float wx1e = x1_in ? wx1 : 0.f, wy1e = y1_in ? wy1 : 0.f, wz1e = z1_in ? wz1 : 0.f;
+  const float v000 = z1_in ? c00x : c00y, v010 = z1_in ? c01x : c01y, v100 = z1_in ? c10x : c10y, v110 = z1_in ? c11x : c11y;
+  const float a00 = egx_mul(wx0, wy0), a01 = egx_mul(wx0, wy1e), a10 = egx_mul(wx1e, wy0), a11 = egx_mul(wx1e, wy1e);
+  float acc;
+  acc = egx_mul(v000, egx_mul(a00, wz0));
+  acc = egx_add(acc, egx_mul(c00y, egx_mul(a00, wz1e)));
+  acc = egx_add(acc, egx_mul(v010, egx_mul(a01, wz0)));
+  acc = egx_add(acc, egx_mul(c01y, egx_mul(a01, wz1e)));
+  acc = egx_add(acc, egx_mul(v100, egx_mul(a10, wz0)));
+  acc = egx_add(acc, egx_mul(c10y, egx_mul(a10, wz1e)));
+  acc = egx_add(acc, egx_mul(v110, egx_mul(a11, wz0)));
+  acc = egx_add(acc, egx_mul(c11y, egx_mul(a11, wz1e)));
+  return -acc;
+}
+__global__ __launch_bounds__(256) void egx_sdf_sample_bricks_kernel(SdfDev s, const float* __restrict__ bricks, const float* __restrict__ pts,
+                                                                   int64_t n, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += EGX_SDF_PPT * stride) {
+    float r[EGX_SDF_PPT];
+#pragma unroll
+    for (int u = 0; u < EGX_SDF_PPT; ++u) {
+      const int64_t i = min(i0 + u * stride, n - 1);
+      r[u] = egx_sdf_neg_trilinear_bricks(s, bricks, pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]);
+    }
+#pragma unroll
+    for (int u = 0; u < EGX_SDF_PPT; ++u)
+      if (i0 + u * stride < n) out[i0 + u * stride] = r[u];
+  }
+}
+__global__ __launch_bounds__(256) void egx_sdf_build_bricks_kernel(const float* __restrict__ grid, int d0, int d1, int d2, int c0, int c1, int c2,
+                                                                  float* __restrict__ bricks) {
+  const size_t n = (size_t)c0 * c1 * c2 * 64;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned e = (unsigned)(i & 63);
+    const size_t b = i >> 6;
+    const int bz = (int)(b % c2), by = (int)((b / c2) % c1), bx = (int)(b / ((size_t)c1 * c2));
+    const int x = min(bx * 4 + (int)(e >> 4), d0 - 1), y = min(by * 4 + (int)((e >> 2) & 3), d1 - 1), z = min(bz * 4 + (int)(e & 3), d2 - 1);
+    bricks[i] = grid[((size_t)x * d1 + y) * d2 + z];
+  }
+}
+
 // Bracket table of the penetration count (egx_lbs_forward): entry (jx,jy,jz) of a [(c0+2)][(c1+2)][(c2+2)] grid holds
 // {min,max} of the fine samples the interpolation can touch for a point whose UNCLAMPED voxel coordinate falls into
 // that cell.  Per axis: j = 0 -> the point is clamped onto the first sample plane {0}; j = c+1 -> onto the last plane
@@ -100,7 +163,7 @@ __global__ __launch_bounds__(256) void egx_sdf_axis_steps_kernel(const float* __
 extern "C" size_t egx_sdf_coarse_bytes(int d0, int d1, int d2) {
   if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
   const int c0 = egx_ceil_div(d0, 4), c1 = egx_ceil_div(d1, 4), c2 = egx_ceil_div(d2, 4);
-  return egx_sdf_aux_offset(c0, c1, c2) + EGX_SDF_AUX_FLOATS * sizeof(float);
+  return egx_sdf_bricks_offset(c0, c1, c2) + (size_t)c0 * c1 * c2 * 64 * sizeof(float);
 }
 
 extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream_) {
@@ -115,6 +178,8 @@ extern "C" int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, v
     hipLaunchKernelGGL(egx_sdf_build_mip_kernel, dim3(egx_ceil_div(ne, 128)), dim3(128), 0, static_cast<hipStream_t>(stream_),
                        static_cast<const float2*>(coarse_out), c0, c1, c2, l, mips + egx_sdf_mip_offset(c0, c1, c2, l));
   }
+  hipLaunchKernelGGL(egx_sdf_build_bricks_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream_), sdf->grid, sdf->d0, sdf->d1, sdf->d2,
+                     c0, c1, c2, reinterpret_cast<float*>(static_cast<char*>(coarse_out) + egx_sdf_bricks_offset(c0, c1, c2)));
   unsigned* aux = reinterpret_cast<unsigned*>(static_cast<char*>(coarse_out) + egx_sdf_aux_offset(c0, c1, c2));
   EGX_HIP_CHECK(hipMemsetAsync(aux, 0, EGX_SDF_AUX_FLOATS * sizeof(float), static_cast<hipStream_t>(stream_)));
   hipLaunchKernelGGL(egx_sdf_axis_steps_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream_), sdf->grid, sdf->d0, sdf->d1,
@@ -131,7 +196,13 @@ extern "C" int egx_sdf_sample(const egx_sdf_grid* sdf, const float* pts, int64_t
   SdfDev s{sdf->grid, sdf->d0, sdf->d1, sdf->d2, sdf->center[0], sdf->center[1], sdf->center[2], sdf->scale, nullptr, 0, 0, 0};
   const int64_t blocks = (n + 256 * EGX_SDF_PPT - 1) / (256 * EGX_SDF_PPT);
   const int grid = (int)(blocks < 8192 ? blocks : 8192);
-  hipLaunchKernelGGL(egx_sdf_sample_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), s, pts, n, out);
+  if (sdf->coarse_minmax) {   // the tables of egx_sdf_build_coarse are there: gather from the bricked copy
+    s.c0 = egx_ceil_div(sdf->d0, 4); s.c1 = egx_ceil_div(sdf->d1, 4); s.c2 = egx_ceil_div(sdf->d2, 4);
+    const float* bricks = reinterpret_cast<const float*>(static_cast<const char*>(sdf->coarse_minmax) + egx_sdf_bricks_offset(s.c0, s.c1, s.c2));
+    hipLaunchKernelGGL(egx_sdf_sample_bricks_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), s, bricks, pts, n, out);
+  } else {
+    hipLaunchKernelGGL(egx_sdf_sample_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), s, pts, n, out);
+  }
   EGX_HIP_CHECK(hipGetLastError());
   return EGX_OK;
 }

@@ -89,7 +89,10 @@ typedef struct egx_sdf_grid {
  * contain 0 decides `calc_sdf < 0` exactly without gathering from the 64 MiB grid.  Six face tables follow the block table:
  * a point that border clamping (grid_sample padding_mode="border", utils.py:75-81) puts onto the first / last sample plane
  * of an axis only touches samples of that plane, so it is bracketed over the plane alone - bodies outside the cube are
- * decided without gathers as well. */
+ * decided without gathers as well.  The buffer also holds 64 auxiliary floats (the steepest slope of the interpolated field:
+ * the fix-up band of blend mode 3) and a copy of the grid as 4 x 4 x 4 bricks of 256 contiguous bytes, which egx_sdf_sample
+ * gathers from when the descriptor carries the table (a point's eight corners then span 2.3 cache lines instead of 4):
+ * egx_sdf_coarse_bytes() is the grid's size plus ~4 %. */
 size_t egx_sdf_coarse_bytes(int d0, int d1, int d2);
 int egx_sdf_build_coarse(const egx_sdf_grid* sdf, void* coarse_out, void* stream);
 
@@ -204,7 +207,8 @@ int egx_update_transl_glorot(const float* R, const float* T, int num_frames, con
 
 /*
  * egx_sdf_sample - calc_sdf(vertices, sdf_dict) (crowd_ppo/utils.py:54-84): trilinear, border clamp,
- * align_corners=False, negated.  pts [n,3] -> out [n].
+ * align_corners=False, negated.  pts [n,3] -> out [n].  With sdf->coarse_minmax set (egx_sdf_build_coarse) the corners are
+ * gathered from the bricked copy of the grid in that buffer, otherwise from the row-major grid: bit-identical values.
  */
 int egx_sdf_sample(const egx_sdf_grid* sdf, const float* pts, int64_t n, float* out, void* stream);
 

@@ -37,14 +37,23 @@ from egogen_amd import _lib  # noqa: E402
 lib = _lib.load()
 
 
+plain = _lib.SdfGrid()          # the same grid without its tables: egx_sdf_sample then gathers from the row-major grid
+C.memmove(C.byref(plain), C.byref(scene.desc), C.sizeof(plain))
+plain.coarse_minmax = None
+
+
 def gather(pts, out):
+    _lib.check(lib.egx_sdf_sample(C.byref(plain), _lib.ptr(pts), pts.shape[0] * pts.shape[1], _lib.ptr(out), _lib.current_stream_ptr()), "egx_sdf_sample")
+
+
+def bricks(pts, out):
     _lib.check(lib.egx_sdf_sample(C.byref(scene.desc), _lib.ptr(pts), pts.shape[0] * pts.shape[1], _lib.ptr(out), _lib.current_stream_ptr()), "egx_sdf_sample")
 
 
 for name, pts in (("bodies", verts), ("uniform", uni)):
     n = pts.shape[0] * pts.shape[1]
     ref = None
-    for kname, fn in (("egx_sdf_sample (gathers)", gather),):
+    for kname, fn in (("row-major grid (egx_sdf_sample_kernel)", gather), ("4x4x4 bricks (egx_sdf_sample_bricks_kernel)", bricks)):
         out = torch.empty(pts.shape[0], pts.shape[1], device="cuda")
         for _ in range(5):
             fn(pts, out)
